@@ -1,0 +1,387 @@
+"""ctypes front-end of the CPU ORACLE (oracle/bcp_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product (bc_gym_planning_env_amd/) never does; it fails loudly without its HIP library.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libbcp_oracle.so")
+
+MAX_VERTS = 32
+MODEL_TRICYCLE, MODEL_DIFFDRIVE = 0, 1
+ERR_ANGLE_JUMP = 1
+
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class Params(C.Structure):
+    """Mirror of `bco_params` (bcp_oracle.h)."""
+    _fields_ = [
+        ("model", C.c_int32),
+        ("n_verts", C.c_int32),
+        ("verts", (C.c_double * 2) * MAX_VERTS),
+        ("dt", C.c_double),
+        ("front_wheel_from_axis", C.c_double),
+        ("max_front_wheel_angle", C.c_double),
+        ("max_front_wheel_speed", C.c_double),
+        ("max_linear_acceleration", C.c_double),
+        ("max_angular_acceleration", C.c_double),
+        ("front_column_p_gain", C.c_double),
+        ("dynamic_model", C.c_int32),
+        ("model_front_column_pid", C.c_int32),
+        ("noise_on", C.c_int32),
+        ("iteration_timeout", C.c_int32),
+        ("alpha", C.c_double * 6),
+        ("spatial_precision", C.c_double),
+        ("angular_precision", C.c_double),
+        ("spatial_progress_multiplier", C.c_double),
+    ]
+
+
+class Batch(C.Structure):
+    """Mirror of `bco_batch` (bcp_oracle.h)."""
+    _fields_ = [
+        ("n", C.c_int64),
+        ("st", _f64p * 7),
+        ("min_dist", _f64p),
+        ("target_idx", _i32p),
+        ("cur_iter", _i32p),
+        ("cur_time", _f64p),
+        ("collided", _u8p),
+        ("maps", _u8p), ("map_stride", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
+        ("rows_per_env", _i32p), ("cols_per_env", _i32p),
+        ("origins", _f64p), ("origin_stride", C.c_int64),
+        ("resolution", C.c_double),
+        ("paths", _f64p), ("path_stride", C.c_int64), ("lens", _i32p),
+        ("actions", _f64p),
+        ("z", _f64p),
+        ("reward", _f64p), ("done", _u8p), ("collided_now", _u8p), ("err", _i32p),
+        ("auto_reset", C.c_int32),
+        ("init_st", _f64p * 7), ("init_min_dist", _f64p), ("init_target_idx", _i32p),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (make -C oracle)."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "bcp_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.bco_normalize_angle.restype = C.c_double
+        L.bco_normalize_angle.argtypes = [C.c_double]
+        L.bco_world_to_pixel.argtypes = [_f64p, C.c_int64, _f64p, C.c_double, _i64p]
+        L.bco_path_velocity.argtypes = [_f64p, _f64p, C.c_double, _f64p, _f64p]
+        L.bco_path_velocity.restype = C.c_int
+        L.bco_kinematic_step.argtypes = [_f64p, C.c_double, C.c_double, C.c_double, _f64p]
+        L.bco_kinematic_step_noise.argtypes = [_f64p, C.c_double, C.c_double, C.c_double, _f64p, _f64p, _f64p,
+                                               C.POINTER(C.c_int)]
+        L.bco_robot_step.argtypes = [C.POINTER(Params), _f64p, _f64p, _f64p, C.POINTER(C.c_int)]
+        L.bco_robot_step.restype = C.c_int
+        L.bco_footprint_vertices.argtypes = [C.c_double, _f64p, C.c_int, C.c_double, _i32p, _i32p]
+        L.bco_fill_poly.argtypes = [_u8p, C.c_int, C.c_int, _i32p, C.c_int, C.c_uint8]
+        L.bco_line.argtypes = [_u8p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint8]
+        L.bco_pixel_footprint.argtypes = [C.c_double, _f64p, C.c_int, C.c_double, _u8p, C.c_int,
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.bco_pose_collides.argtypes = [C.c_double, C.c_double, C.c_double, _f64p, C.c_int, _u8p, C.c_int, C.c_int,
+                                        _f64p, C.c_double]
+        L.bco_pose_collides.restype = C.c_int
+        L.bco_find_last_reached.argtypes = [_f64p, _f64p, C.c_int, C.c_double, C.c_double]
+        L.bco_find_last_reached.restype = C.c_int
+        L.bco_reward.argtypes = [C.POINTER(Params), _f64p, _f64p, C.c_int, _f64p, _i32p]
+        L.bco_reward.restype = C.c_double
+        L.bco_initial_reward_state.argtypes = [_f64p, C.c_int, C.c_double, C.c_double, _f64p, _i32p]
+        L.bco_initial_reward_state.restype = C.c_int
+        L.bco_step_batch.argtypes = [C.POINTER(Params), C.POINTER(Batch), C.c_int]
+        L.bco_step_batch.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# --------------------------------------------------------------------------- robot constants
+# Values of robot_models/robot_dimensions_examples.py (tricycle :108-188, diffdrive :53-82), in millimetres
+# divided by 1000 exactly as the reference does.
+TRICYCLE_FOOTPRINT = np.array([
+    [1348.35, 0.], [1338.56, 139.75], [1306.71, 280.12], [1224.36, 338.62], [1093.81, 374.64], [-214.37, 374.64],
+    [-313.62, 308.56], [-366.36, 117.44], [-374.01, -135.75], [-227.96, -459.13], [-156.72, -458.78],
+    [759.8, -442.96], [849.69, -426.4], [1171.05, -353.74], [1303.15, -286.54], [1341.34, -118.37]]) / 1000.
+DIFFDRIVE_FOOTPRINT = np.array([
+    [644.5, 0], [634.86, 61], [571.935, 130.54], [553.38, 161], [360.36, 186], [250, 186], [250, 186], [100, 186],
+    [100, 186], [0, 196], [-119.21, 190.5], [-173.4, 146], [-193, 0], [-173.4, -143], [-111.65, -246],
+    [-71.57, -246], [100, -246], [100, -246], [250, -246], [250, -246], [413.085, -223], [491.5, -204.5],
+    [553, -161], [634.86, -62]]) / 1000.
+PLANENV_NOISE = (0.0, 0.0, 1.e-2, 1.e-2, 1.e-3, 1.e-3)  # envs/base/env.py:228-231
+
+
+def make_params(model="tricycle", dt=0.05, noise=None, iteration_timeout=1200, spatial_precision=1.0,
+                angular_precision=np.pi / 2, spatial_progress_multiplier=0.0, footprint=None, footprint_scale=1.0,
+                dynamic_model=True, model_front_column_pid=True):
+    p = Params()
+    p.model = MODEL_TRICYCLE if model == "tricycle" else MODEL_DIFFDRIVE
+    fp = footprint if footprint is not None else (TRICYCLE_FOOTPRINT if model == "tricycle" else DIFFDRIVE_FOOTPRINT)
+    fp = np.asarray(fp, dtype=np.float64) * footprint_scale
+    assert len(fp) <= MAX_VERTS
+    p.n_verts = len(fp)
+    for i, (x, y) in enumerate(fp):
+        p.verts[i][0] = x
+        p.verts[i][1] = y
+    p.dt = dt
+    p.front_wheel_from_axis = 0.964
+    p.max_front_wheel_angle = 0.5 * 170 * np.pi / 180.
+    p.max_front_wheel_speed = 60. * np.pi / 180.
+    p.max_linear_acceleration = 1. / 2.5
+    p.max_angular_acceleration = 1. / 2.
+    p.front_column_p_gain = 0.16
+    p.dynamic_model = int(dynamic_model)
+    p.model_front_column_pid = int(model_front_column_pid)
+    p.noise_on = int(noise is not None)
+    for i in range(6):
+        p.alpha[i] = 0.0 if noise is None else float(noise[i])
+    p.iteration_timeout = iteration_timeout
+    p.spatial_precision = spatial_precision
+    p.angular_precision = angular_precision
+    p.spatial_progress_multiplier = spatial_progress_multiplier
+    return p
+
+
+def footprint_of(p):
+    return np.array([[p.verts[i][0], p.verts[i][1]] for i in range(p.n_verts)], dtype=np.float64)
+
+
+# --------------------------------------------------------------------------- scalar wrappers
+def normalize_angle(z):
+    z = np.asarray(z, dtype=np.float64)
+    return np.vectorize(lib().bco_normalize_angle, otypes=[np.float64])(z)
+
+
+def world_to_pixel(xy, origin, resolution):
+    xy = _f64(xy)
+    flat = xy.reshape(-1, 2)
+    out = np.empty(flat.shape, dtype=np.int64)
+    origin = _f64(origin)
+    lib().bco_world_to_pixel(_p(flat, _f64p), flat.shape[0], _p(origin, _f64p), float(resolution), _p(out, _i64p))
+    return out.reshape(xy.shape)
+
+
+def path_velocity(pose0, pose1, dt):
+    p0, p1 = _f64(pose0), _f64(pose1)
+    v, w = C.c_double(), C.c_double()
+    err = lib().bco_path_velocity(_p(p0, _f64p), _p(p1, _f64p), float(dt), C.byref(v), C.byref(w))
+    return v.value, w.value, err
+
+
+def kinematic_step(pose, v, w, dt):
+    pose = _f64(pose)
+    out = np.empty(3)
+    lib().bco_kinematic_step(_p(pose, _f64p), float(v), float(w), float(dt), _p(out, _f64p))
+    return out
+
+
+def kinematic_step_noise(pose, v, w, dt, alpha, z):
+    pose, alpha, z = _f64(pose), _f64(alpha), _f64(z)
+    out = np.empty(3)
+    drawn = C.c_int()
+    lib().bco_kinematic_step_noise(_p(pose, _f64p), float(v), float(w), float(dt), _p(alpha, _f64p), _p(z, _f64p),
+                                   _p(out, _f64p), C.byref(drawn))
+    return out, drawn.value
+
+
+def robot_step(params, state7, cmd, z=None):
+    st = _f64(state7).copy()
+    cmd = _f64(cmd)
+    zz = _f64(z) if z is not None else None
+    drawn = C.c_int()
+    err = lib().bco_robot_step(C.byref(params), _p(st, _f64p), _p(cmd, _f64p),
+                               _p(zz, _f64p) if zz is not None else None, C.byref(drawn))
+    return st, err, drawn.value
+
+
+def footprint_vertices(angle, verts, resolution):
+    verts = _f64(verts)
+    k = verts.shape[0]
+    out = np.empty((k, 2), dtype=np.int32)
+    half = np.empty(2, dtype=np.int32)
+    lib().bco_footprint_vertices(float(angle), _p(verts, _f64p), k, float(resolution), _p(out, _i32p), _p(half, _i32p))
+    return out, half
+
+
+def fill_poly(img, pts, value=255):
+    assert img.dtype == np.uint8 and img.flags.c_contiguous and img.ndim == 2
+    pts = np.ascontiguousarray(pts, dtype=np.int32)
+    lib().bco_fill_poly(_p(img, _u8p), img.shape[0], img.shape[1], _p(pts, _i32p), pts.shape[0], int(value))
+    return img
+
+
+def line(img, p0, p1, value):
+    assert img.dtype == np.uint8 and img.flags.c_contiguous and img.ndim == 2
+    lib().bco_line(_p(img, _u8p), img.shape[0], img.shape[1], int(p0[0]), int(p0[1]), int(p1[0]), int(p1[1]),
+                   int(value))
+    return img
+
+
+def pixel_footprint(angle, verts, resolution):
+    v, half = footprint_vertices(angle, verts, resolution)
+    img = np.zeros((2 * half[1] + 1, 2 * half[0] + 1), dtype=np.uint8)
+    return fill_poly(img, v, 255)
+
+
+def pose_collides(x, y, angle, verts, costmap, origin, resolution):
+    verts, origin = _f64(verts), _f64(origin)
+    costmap = np.ascontiguousarray(costmap, dtype=np.uint8)
+    r = lib().bco_pose_collides(float(x), float(y), float(angle), _p(verts, _f64p), verts.shape[0],
+                                _p(costmap, _u8p), costmap.shape[0], costmap.shape[1], _p(origin, _f64p),
+                                float(resolution))
+    assert r >= 0
+    return bool(r)
+
+
+def find_last_reached(pose, path, sp, ap):
+    pose, path = _f64(pose), _f64(path)
+    r = lib().bco_find_last_reached(_p(pose, _f64p), _p(path, _f64p), path.shape[0], float(sp), float(ap))
+    return None if r < 0 else r
+
+
+def reward(params, pose, path, min_dist, target_idx):
+    pose, path = _f64(pose), _f64(path)
+    md = C.c_double(min_dist)
+    ti = C.c_int32(target_idx)
+    r = lib().bco_reward(C.byref(params), _p(pose, _f64p), _p(path, _f64p), path.shape[0], C.byref(md), C.byref(ti))
+    return r, md.value, ti.value
+
+
+def initial_reward_state(path, sp, ap):
+    path = _f64(path)
+    md = C.c_double()
+    ti = C.c_int32()
+    rc = lib().bco_initial_reward_state(_p(path, _f64p), path.shape[0], float(sp), float(ap), C.byref(md), C.byref(ti))
+    if rc != 0:
+        raise ValueError("Goal pose too close to initial pose")
+    return md.value, ti.value
+
+
+# --------------------------------------------------------------------------- batched SoA env
+class OracleBatch(object):
+    """N envs stepped by the oracle; same SoA inputs/outputs as the HIP path, numpy arrays on the host."""
+
+    def __init__(self, params, n, costmaps, origins, resolution, paths, lens=None, rows=None, cols=None):
+        self.params = params
+        self.n = int(n)
+        self.resolution = float(resolution)
+        cm = np.ascontiguousarray(costmaps, dtype=np.uint8)
+        self.shared_map = cm.ndim == 2
+        self.maps = cm
+        self.map_rows, self.map_cols = cm.shape[-2], cm.shape[-1]
+        self.rows_per_env = None if rows is None else np.ascontiguousarray(rows, dtype=np.int32)
+        self.cols_per_env = None if cols is None else np.ascontiguousarray(cols, dtype=np.int32)
+        self.origins = _f64(origins)
+        self.shared_origin = self.origins.ndim == 1
+        pa = _f64(paths)
+        self.shared_path = pa.ndim == 2
+        self.paths = pa
+        if self.shared_path:
+            self.lens = np.array([pa.shape[0]], dtype=np.int32)
+        else:
+            self.lens = np.ascontiguousarray(lens if lens is not None else np.full(n, pa.shape[1]), dtype=np.int32)
+        self.st = [np.zeros(n) for _ in range(7)]
+        self.min_dist = np.zeros(n)
+        self.target_idx = np.zeros(n, dtype=np.int32)
+        self.cur_iter = np.zeros(n, dtype=np.int32)
+        self.cur_time = np.zeros(n)
+        self.collided = np.zeros(n, dtype=np.uint8)
+        self.reward = np.zeros(n)
+        self.done = np.zeros(n, dtype=np.uint8)
+        self.collided_now = np.zeros(n, dtype=np.uint8)
+        self.err = np.zeros(n, dtype=np.int32)
+        self.init_st = None
+
+    def reset_from_paths(self, initial_wheel_angle=0.0):
+        """make_initial_state (envs/base/env.py:179-214): pose = path[0], v=w=0, reward state from the path."""
+        sp, ap = self.params.spatial_precision, self.params.angular_precision
+        for i in range(self.n):
+            path = self.paths if self.shared_path else self.paths[i, :self.lens[i]]
+            if i == 0 or not self.shared_path:
+                md, ti = initial_reward_state(path, sp, ap)
+            self.st[0][i], self.st[1][i], self.st[2][i] = path[0]
+            self.min_dist[i], self.target_idx[i] = md, ti
+        for f in (3, 4, 5):
+            self.st[f][:] = 0.0
+        self.st[6][:] = initial_wheel_angle
+        self.cur_iter[:] = 0
+        self.cur_time[:] = 0.0
+        self.collided[:] = 0
+        self.snapshot_initial()
+
+    def snapshot_initial(self):
+        self.init_st = [a.copy() for a in self.st]
+        self.init_min_dist = self.min_dist.copy()
+        self.init_target_idx = self.target_idx.copy()
+
+    def step(self, actions, z=None, auto_reset=False, threads=1):
+        actions = _f64(actions)
+        assert actions.shape == (self.n, 2)
+        b = Batch()
+        b.n = self.n
+        for f in range(7):
+            b.st[f] = _p(self.st[f], _f64p)
+        b.min_dist = _p(self.min_dist, _f64p)
+        b.target_idx = _p(self.target_idx, _i32p)
+        b.cur_iter = _p(self.cur_iter, _i32p)
+        b.cur_time = _p(self.cur_time, _f64p)
+        b.collided = _p(self.collided, _u8p)
+        b.maps = _p(self.maps, _u8p)
+        b.map_stride = 0 if self.shared_map else self.map_rows * self.map_cols
+        b.rows, b.cols = self.map_rows, self.map_cols
+        b.rows_per_env = _p(self.rows_per_env, _i32p) if self.rows_per_env is not None else None
+        b.cols_per_env = _p(self.cols_per_env, _i32p) if self.cols_per_env is not None else None
+        b.origins = _p(self.origins, _f64p)
+        b.origin_stride = 0 if self.shared_origin else 2
+        b.resolution = self.resolution
+        b.paths = _p(self.paths, _f64p)
+        b.path_stride = 0 if self.shared_path else self.paths.shape[1] * 3
+        b.lens = _p(self.lens, _i32p)
+        b.actions = _p(actions, _f64p)
+        zz = None
+        if z is not None:
+            zz = _f64(z)
+            assert zz.shape == (self.n, 3)
+            b.z = _p(zz, _f64p)
+        b.reward = _p(self.reward, _f64p)
+        b.done = _p(self.done, _u8p)
+        b.collided_now = _p(self.collided_now, _u8p)
+        b.err = _p(self.err, _i32p)
+        b.auto_reset = int(auto_reset)
+        if auto_reset:
+            assert self.init_st is not None
+            for f in range(7):
+                b.init_st[f] = _p(self.init_st[f], _f64p)
+            b.init_min_dist = _p(self.init_min_dist, _f64p)
+            b.init_target_idx = _p(self.init_target_idx, _i32p)
+        rc = lib().bco_step_batch(C.byref(self.params), C.byref(b), int(threads))
+        assert rc == 0
+        return self.reward, self.done
