@@ -1,0 +1,411 @@
+"""BatchedPlanEnv: N PlanEnv instances advanced by one fused HIP kernel per step.
+
+Mirrors the reference's object API (envs/base/env.py:217-439): reset() / step() / get_state() / set_state() /
+seed() / action_space, batched over N envs, plus `envs[i]` views that hand back reference-shaped
+Observation / State objects for one env.  Device tensors are torch tensors only because they cross the C ABI as
+raw pointers (tensor.data_ptr()); all arithmetic happens in libbcplan.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, host_init, robots
+from .api import (Action, Box, ContinuousRewardProviderState, CostMap2D, DiffdriveRobotState, EnvParams,
+                  INDUSTRIAL_TRICYCLE_V1, Observation, State, TricycleRobotState)
+
+_STATE_FIELDS = ("x", "y", "angle", "v", "w", "steering_motor_command", "wheel_angle")
+
+
+def _as_device_actions(actions, n, device):
+    """list[Action] | ndarray | tensor -> contiguous [n,2] float32/float64 tensor on the device."""
+    if isinstance(actions, torch.Tensor):
+        t = actions
+    else:
+        if isinstance(actions, Action):
+            actions = [actions]
+        if isinstance(actions, (list, tuple)) and len(actions) and isinstance(actions[0], Action):
+            actions = np.stack([np.asarray(a.command) for a in actions])
+        t = torch.from_numpy(np.ascontiguousarray(actions))
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.to(torch.float64)
+    t = t.to(device).contiguous()
+    if tuple(t.shape) != (n, 2):
+        raise ValueError("actions must have shape (%d, 2), got %s" % (n, tuple(t.shape)))
+    return t
+
+
+class BatchedState(object):
+    """Snapshot of every env's mutable state (what PlanEnv.get_state() deep-copies, env.py:287-291)."""
+
+    def __init__(self, robot, min_spat_dist_so_far, target_idx, current_iter, robot_collided):
+        self.robot = robot                      # float64 [7, N]: x, y, angle, v, w, steering_motor_command, wheel_angle
+        self.min_spat_dist_so_far = min_spat_dist_so_far
+        self.target_idx = target_idx
+        self.current_iter = current_iter
+        self.robot_collided = robot_collided
+
+    def copy(self):
+        return BatchedState(self.robot.clone(), self.min_spat_dist_so_far.clone(), self.target_idx.clone(),
+                            self.current_iter.clone(), self.robot_collided.clone())
+
+
+class BatchedObservation(object):
+    """Observation of all envs after a step: references to the live device tensors (as the reference's Observation
+    holds references, obs.py:14-23).  `obs[i]` builds the reference-shaped Observation of env i."""
+
+    def __init__(self, env):
+        self._env = env
+        self.pose = env.state.robot[0:3]          # [3, N] view
+        self.robot_state = env.state.robot[3:7]   # [4, N] view: v, w, steering_motor_command, wheel_angle
+        self.target_idx = env.state.target_idx
+        self.current_iter = env.state.current_iter
+        self.dt = env.params.dt
+
+    @property
+    def time(self):
+        return self._env.time_of(self.current_iter)
+
+    def __len__(self):
+        return self._env.n_envs
+
+    def __getitem__(self, i):
+        return self._env.envs[i].observation()
+
+
+class EnvView(object):
+    """One env of the batch behind the reference's per-env API (copies a few scalars from the device on demand)."""
+
+    def __init__(self, env, i):
+        self._env, self._i = env, i
+
+    def _robot_state(self, col):
+        if self._env.is_tricycle:
+            return TricycleRobotState(*[float(v) for v in col])
+        return DiffdriveRobotState(*[float(v) for v in col[:5]])
+
+    def get_state(self):
+        e, i = self._env, self._i
+        col = e.state.robot[:, i].cpu().numpy()
+        path = e.path_of(i)
+        tidx = int(e.state.target_idx[i])
+        it = int(e.state.current_iter[i])
+        rps = ContinuousRewardProviderState(min_spat_dist_so_far=float(e.state.min_spat_dist_so_far[i]), path=path,
+                                            target_idx=tidx)
+        return State(reward_provider_state=rps, path=rps.current_path(), original_path=np.copy(path),
+                     costmap=e.costmap_of(i), iter_timeout=e.params.iteration_timeout,
+                     current_time=float(e.time_table[min(it, len(e.time_table) - 1)]), current_iter=it,
+                     robot_collided=bool(e.state.robot_collided[i]), poses_queue=[], robot_state_queue=[],
+                     control_queue=[], pose=col[:3].copy(), robot_state=self._robot_state(col))
+
+    def set_state(self, state):
+        e, i = self._env, self._i
+        rs = state.robot_state
+        col = [rs.x, rs.y, rs.angle, rs.v, rs.w, getattr(rs, "steering_motor_command", 0.0),
+               getattr(rs, "wheel_angle", 0.0)]
+        e.state.robot[:, i] = torch.tensor(col, dtype=torch.float64)
+        e.state.min_spat_dist_so_far[i] = state.reward_provider_state.min_spat_dist_so_far
+        e.state.target_idx[i] = state.reward_provider_state.target_idx
+        e.state.current_iter[i] = state.current_iter
+        e.state.robot_collided[i] = int(state.robot_collided)
+
+    def observation(self):
+        s = self.get_state()
+        return Observation(pose=s.pose, path=s.path, costmap=s.costmap, robot_state=s.robot_state,
+                           time=s.current_time, dt=self._env.params.dt)
+
+
+class _EnvViews(object):
+    def __init__(self, env):
+        self._env = env
+
+    def __len__(self):
+        return self._env.n_envs
+
+    def __getitem__(self, i):
+        if not -self._env.n_envs <= i < self._env.n_envs:
+            raise IndexError(i)
+        return EnvView(self._env, i % self._env.n_envs)
+
+
+class BatchedPlanEnv(object):
+    """N planning envs on one MI355X.
+
+    :param costmap: CostMap2D shared by all envs, or a list of N CostMap2D of equal resolution (private maps)
+    :param path: array(M, 3) shared oriented path, or a list of N such arrays (private paths)
+    :param params EnvParams: as the reference (delays must be 0; continuous reward provider)
+    :param n_envs int: number of envs on this device
+    :param device: torch device / index of the GPU
+    :param robot_name: robot model + footprint; default params.robot_name (PlanEnv itself always drives a tricycle)
+    :param noise_parameters: 'planenv' = the odometry noise PlanEnv hard-codes (env.py:226-232), None = off, or a
+        dict alpha1..alpha6
+    :param auto_reset bool: restore an env's initial state right after the step that finished it
+    :param env_id_base int: global index of env 0 (rank * n_envs when sharded over GPUs); keys the noise stream
+    """
+
+    def __init__(self, costmap, path, params=None, n_envs=1, device=0, robot_name=None, noise_parameters='planenv',
+                 auto_reset=False, env_id_base=0, seed=0, footprint_scale=1.0, dynamic_model=True,
+                 model_front_column_pid=True):
+        params = EnvParams() if params is None else params
+        if params.pose_delay or params.control_delay or params.state_delay:
+            raise NotImplementedError("pose/control/state delays > 0 are not supported by the batched step")
+        if params.reward_provider_name != 'continuous_reward':
+            raise NotImplementedError("only the continuous reward provider is supported")
+        self.params = params
+        self.n_envs = int(n_envs)
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.robot_name = params.robot_name if robot_name is None else robot_name
+        self.is_tricycle = self.robot_name == INDUSTRIAL_TRICYCLE_V1
+        if noise_parameters == 'planenv':
+            noise_parameters = dict(robots.PLANENV_NOISE)
+        self.noise_parameters = noise_parameters
+        self.auto_reset = bool(auto_reset)
+        self._lib = _lib.load()  # raises when libbcplan.so is missing: no fallback
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedPlanEnv needs a GPU (libbcplan has no CPU path)")
+        self._bcp_params = robots.make_bcp_params(params, self.robot_name, noise_parameters, footprint_scale,
+                                                  dynamic_model, model_front_column_pid)
+        self._h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self._lib.bcp_create(C.byref(self._bcp_params), self.n_envs, dev_index, int(env_id_base),
+                                        C.byref(self._h)))
+        self.action_space = Box(low=np.array([robots.MAX_FRONT_WHEEL_SPEED / 10, -np.pi / 2]),
+                                high=np.array([robots.MAX_FRONT_WHEEL_SPEED / 2, np.pi / 2]), dtype=np.float32)
+        self.reward_range = (0.0, 1.0)
+        self.time_table = host_init.time_table(params.dt, params.iteration_timeout + 1)
+        self._time_table_dev = torch.from_numpy(self.time_table).to(self.device)
+
+        n, dev = self.n_envs, self.device
+        self.state = BatchedState(torch.zeros(7, n, dtype=torch.float64, device=dev),
+                                  torch.zeros(n, dtype=torch.float64, device=dev),
+                                  torch.zeros(n, dtype=torch.int32, device=dev),
+                                  torch.zeros(n, dtype=torch.int32, device=dev),
+                                  torch.zeros(n, dtype=torch.uint8, device=dev))
+        self.reward = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.collided_now = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.err = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.envs = _EnvViews(self)
+        self._keep = {}  # device buffers the library holds pointers to
+
+        self._set_costmaps(costmap)
+        self._set_paths(path)
+        self._bind(self.state, self._lib.bcp_bind_state)
+        self._initial_state = self._make_initial_state()
+        self._bind(self._initial_state, self._lib.bcp_bind_initial_state)
+        self.seed(seed)
+        self.reset()
+
+    # ------------------------------------------------------------------ construction helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _bind(self, s, fn):
+        st = _lib.BcpState()
+        for k, name in enumerate(_STATE_FIELDS):
+            setattr(st, name, s.robot[k].data_ptr())
+        st.min_spat_dist_so_far = s.min_spat_dist_so_far.data_ptr()
+        st.target_idx = s.target_idx.data_ptr()
+        st.current_iter = s.current_iter.data_ptr()
+        st.robot_collided = s.robot_collided.data_ptr()
+        _lib.check(fn(self._h, C.byref(st)))
+
+    def _set_costmaps(self, costmap):
+        n = self.n_envs
+        if isinstance(costmap, CostMap2D) or hasattr(costmap, "get_data") and not isinstance(costmap, (list, tuple)):
+            self._costmaps, self._shared_map = [costmap], True
+            data = np.ascontiguousarray(costmap.get_data(), dtype=np.uint8)
+            rows, cols = data.shape
+            origins = np.ascontiguousarray(costmap.get_origin(), dtype=np.float64)
+            res = float(costmap.get_resolution())
+            data_dev = torch.from_numpy(data).to(self.device)
+            self._keep["map"] = data_dev
+            self._origin_host = origins
+            _lib.check(self._lib.bcp_set_costmaps(self._h, data_dev.data_ptr(), rows, cols, 1, None, None,
+                                                  origins.ctypes.data, 0, res, self._stream()))
+        else:
+            costmaps = list(costmap)
+            if len(costmaps) != n:
+                raise ValueError("need one costmap per env (%d), got %d" % (n, len(costmaps)))
+            res = float(costmaps[0].get_resolution())
+            if any(float(c.get_resolution()) != res for c in costmaps):
+                raise ValueError("all costmaps must share one resolution")
+            self._costmaps, self._shared_map = costmaps, False
+            rows = max(c.get_data().shape[0] for c in costmaps)
+            cols = max(c.get_data().shape[1] for c in costmaps)
+            data = np.zeros((n, rows, cols), dtype=np.uint8)
+            vr = np.zeros(n, dtype=np.int32)
+            vc = np.zeros(n, dtype=np.int32)
+            origins = np.zeros((n, 2), dtype=np.float64)
+            for i, c in enumerate(costmaps):
+                d = c.get_data()
+                data[i, :d.shape[0], :d.shape[1]] = d
+                vr[i], vc[i] = d.shape
+                origins[i] = c.get_origin()
+            self.set_costmap_tensors(torch.from_numpy(data).to(self.device), torch.from_numpy(origins).to(self.device),
+                                     res, torch.from_numpy(vr).to(self.device), torch.from_numpy(vc).to(self.device))
+        self.resolution = res
+
+    def set_costmap_tensors(self, data, origins, resolution, valid_rows=None, valid_cols=None):
+        """Private costmaps straight from device tensors: data uint8 [N, rows, cols], origins float64 [N, 2]."""
+        n = self.n_envs
+        assert data.dtype == torch.uint8 and data.dim() == 3 and data.shape[0] == n and data.is_contiguous()
+        assert origins.dtype == torch.float64 and tuple(origins.shape) == (n, 2) and origins.is_contiguous()
+        self._keep.update(map=data, origins=origins, vr=valid_rows, vc=valid_cols)
+        self._shared_map = False
+        self.resolution = float(resolution)
+        _lib.check(self._lib.bcp_set_costmaps(
+            self._h, data.data_ptr(), data.shape[1], data.shape[2], 0,
+            valid_rows.data_ptr() if valid_rows is not None else None,
+            valid_cols.data_ptr() if valid_cols is not None else None, origins.data_ptr(), 1, float(resolution),
+            self._stream()))
+
+    def _set_paths(self, path):
+        refine = (lambda p: host_init.refine_path(p, self.params.path_delta)) if self.params.refine_path else (lambda p: p)
+        if isinstance(path, np.ndarray) and path.ndim == 2:
+            p = np.ascontiguousarray(refine(path), dtype=np.float64)
+            assert p.shape[1] == 3
+            self._paths, self._shared_path = [p], True
+            dev = torch.from_numpy(p).to(self.device)
+            self._keep["path"] = dev
+            _lib.check(self._lib.bcp_set_paths(self._h, dev.data_ptr(), None, p.shape[0], 1, self._stream()))
+        else:
+            paths = [np.ascontiguousarray(refine(np.asarray(p)), dtype=np.float64) for p in path]
+            if len(paths) != self.n_envs:
+                raise ValueError("need one path per env (%d), got %d" % (self.n_envs, len(paths)))
+            self._paths, self._shared_path = paths, False
+            max_len = max(len(p) for p in paths)
+            buf = np.zeros((self.n_envs, max_len, 3), dtype=np.float64)
+            lens = np.zeros(self.n_envs, dtype=np.int32)
+            for i, p in enumerate(paths):
+                buf[i, :len(p)] = p
+                lens[i] = len(p)
+            dev, lens_dev = torch.from_numpy(buf).to(self.device), torch.from_numpy(lens).to(self.device)
+            self._keep.update(path=dev, lens=lens_dev)
+            _lib.check(self._lib.bcp_set_paths(self._h, dev.data_ptr(), lens_dev.data_ptr(), max_len, 0,
+                                               self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()  # the [.,3] staging tensor may now be released
+
+    def _make_initial_state(self):
+        """make_initial_state (env.py:179-214): pose = path[0], v = w = 0, wheel at initial_wheel_angle... the
+        reference's TricycleRobotState() default wheel angle is 0.0 and PlanEnv never applies
+        params.initial_wheel_angle to it, so neither do we."""
+        n = self.n_envs
+        robot = np.zeros((7, n), dtype=np.float64)
+        md = np.zeros(n, dtype=np.float64)
+        ti = np.zeros(n, dtype=np.int32)
+        rp = self.params.reward_provider_params
+        if self._shared_path:
+            p = self._paths[0]
+            m0, t0 = host_init.initial_reward_state(p, rp)
+            robot[0:3, :] = p[0][:, None]
+            md[:], ti[:] = m0, t0
+        else:
+            for i, p in enumerate(self._paths):
+                md[i], ti[i] = host_init.initial_reward_state(p, rp)
+                robot[0:3, i] = p[0]
+        dev = self.device
+        return BatchedState(torch.from_numpy(robot).to(dev), torch.from_numpy(md).to(dev), torch.from_numpy(ti).to(dev),
+                            torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev))
+
+    # ------------------------------------------------------------------ per-env lookups
+    def path_of(self, i):
+        return self._paths[0] if self._shared_path else self._paths[i]
+
+    def costmap_of(self, i):
+        if self._shared_map or len(self._costmaps) == 1:
+            return self._costmaps[0]
+        return self._costmaps[i]
+
+    def time_of(self, current_iter):
+        """Observation.time for iteration counters (device tensor): dt accumulated current_iter times."""
+        idx = current_iter.to(torch.int64).clamp_(max=len(self.time_table) - 1)
+        return self._time_table_dev[idx]
+
+    # ------------------------------------------------------------------ reference API
+    def seed(self, seed=None):
+        """Seeds the on-device odometry-noise stream (the reference draws from numpy's global RNG)."""
+        if seed is not None:
+            _lib.check(self._lib.bcp_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def reset(self, mask=None):
+        """PlanEnv.reset for all envs, or for those with mask[i] != 0 (uint8/bool device tensor)."""
+        ptr = None
+        if mask is not None:
+            mask = mask.to(self.device).to(torch.uint8).contiguous()
+            ptr = mask.data_ptr()
+        _lib.check(self._lib.bcp_reset_masked(self._h, ptr, self._stream()))
+        return BatchedObservation(self)
+
+    def get_state(self):
+        return self.state.copy()
+
+    def set_state(self, state):
+        s = self.state
+        s.robot.copy_(state.robot)
+        s.min_spat_dist_so_far.copy_(state.min_spat_dist_so_far)
+        s.target_idx.copy_(state.target_idx)
+        s.current_iter.copy_(state.current_iter)
+        s.robot_collided.copy_(state.robot_collided)
+
+    def step(self, actions, noise_z=None, noise_z_out=None):
+        """One tick for every env.  actions: [N,2] (float32 or float64) tensor / array, or a list of Action.
+        noise_z: optional [N,3] float64 standard normals (slot order) replacing the on-device RNG.
+        Returns (BatchedObservation, reward float64[N], done uint8[N], {}) -- device tensors, no sync."""
+        a = _as_device_actions(actions, self.n_envs, self.device)
+        io = _lib.BcpStepIO()
+        io.actions = a.data_ptr()
+        flags = _lib.STEP_ACTIONS_F32 if a.dtype == torch.float32 else 0
+        if self.auto_reset:
+            flags |= _lib.STEP_AUTO_RESET
+        z = None
+        if noise_z is not None:
+            z = noise_z if isinstance(noise_z, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(noise_z))
+            z = z.to(self.device, torch.float64).contiguous()
+            assert tuple(z.shape) == (self.n_envs, 3)
+            io.noise_z = z.data_ptr()
+        if noise_z_out is not None:
+            assert noise_z_out.dtype == torch.float64 and tuple(noise_z_out.shape) == (self.n_envs, 3)
+            io.noise_z_out = noise_z_out.data_ptr()
+        io.reward = self.reward.data_ptr()
+        io.done = self.done.data_ptr()
+        io.collided_now = self.collided_now.data_ptr()
+        io.err = self.err.data_ptr()
+        _lib.check(self._lib.bcp_step(self._h, C.byref(io), flags, self._stream()))
+        self._last_inputs = (a, z)  # keep inputs alive until the stream has consumed them
+        return BatchedObservation(self), self.reward, self.done, {}
+
+    def check_errors(self):
+        """Raise what the reference would have raised during the last step (synchronises)."""
+        bad = torch.nonzero(self.err).flatten()
+        if len(bad):
+            raise Exception("Path has missing/corrupted angle data at env indices: %s" % bad.cpu().numpy())
+
+    def time_steps(self, actions, steps, noise_z=None):
+        """Average device time (ms) of one fused step launch over `steps` launches, measured with HIP events on the
+        launch stream (bench.py's roofline.achieved)."""
+        a = _as_device_actions(actions, self.n_envs, self.device)
+        io = _lib.BcpStepIO()
+        io.actions = a.data_ptr()
+        flags = (_lib.STEP_ACTIONS_F32 if a.dtype == torch.float32 else 0) | (_lib.STEP_AUTO_RESET if self.auto_reset else 0)
+        if noise_z is not None:
+            io.noise_z = noise_z.data_ptr()
+        io.reward, io.done = self.reward.data_ptr(), self.done.data_ptr()
+        io.collided_now, io.err = self.collided_now.data_ptr(), self.err.data_ptr()
+        ms = C.c_float()
+        _lib.check(self._lib.bcp_time_steps(self._h, C.byref(io), flags, int(steps), self._stream(), C.byref(ms)))
+        return ms.value
+
+    def render(self, mode='human'):
+        raise NotImplementedError("rendering is out of scope of the batched step path")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.bcp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,204 @@
+// bcp_device.h -- device-side arithmetic of the PlanEnv.step() path (gfx950, fp64, no FMA contraction).
+//
+// Every function states the reference lines it implements (paths relative to bc_gym_planning_env/).
+// The translation unit is compiled with -ffp-contract=off: products and sums round separately exactly as
+// numpy's ufuncs do; the only fused operations are the explicit fma() calls in footprint_vertex().
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bcplan.h"
+
+namespace bcp {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kTwoPi = 2.0 * kPi;
+
+// Device copy of the parameters (kernel argument, lives in SGPRs / scalar cache).
+struct DevParams {
+    int32_t model, n_verts, dynamic_model, model_front_column_pid, noise_on, iteration_timeout;
+    double dt, L, max_wheel_angle, max_wheel_speed, max_lin_acc, max_ang_acc, p_gain;
+    double alpha[6];
+    double sp, ap, progress_mult;
+    double par_thr;          // -sp / 9, utilities/path_tools.py:423
+    double sp_prune;         // sp nudged up two ulps: |dx| > sp_prune  =>  hypot(dx,dy) >= sp for any faithful hypot
+    double qverts[BCP_MAX_VERTS][2];  // footprint / resolution (path_tools.py:145), divided on the host in fp64
+};
+
+// numpy float `%`: the result takes the sign of the divisor (npy_divmod)
+__device__ __forceinline__ double py_mod(double a, double b)
+{
+    double r = fmod(a, b);
+    if (r != 0.0) {
+        if ((b < 0.0) != (r < 0.0)) r += b;
+    } else {
+        r = copysign(0.0, b);
+    }
+    return r;
+}
+
+// utilities/coordinate_transformations.py:28-36
+__device__ __forceinline__ double normalize_angle(double z) { return py_mod(z + kPi, kTwoPi) - kPi; }
+
+// np.clip == minimum(maximum(a, lo), hi)
+__device__ __forceinline__ double clipd(double a, double lo, double hi)
+{
+    double t = a < lo ? lo : a;
+    return t > hi ? hi : t;
+}
+
+__device__ __forceinline__ double signd(double a) { return (double)((a > 0.0) - (a < 0.0)); }
+
+struct Pose {
+    double x, y, th;
+};
+
+// robot_models/differential_drive.py:21-40
+__device__ __forceinline__ Pose kinematic_step(Pose p, double v, double w, double dt)
+{
+    double half_wdt = 0.5 * w * dt;
+    double t = half_wdt / kPi;                     // np.sinc(half_wdt / np.pi)
+    double yy = kPi * (t == 0.0 ? 1.0e-20 : t);
+    double sinc = sin(yy) / yy;
+    double v_factor = v * dt * sinc;
+    double a = p.th + half_wdt;
+    Pose o;
+    o.x = p.x + v_factor * cos(a);
+    o.y = p.y + v_factor * sin(a);
+    o.th = normalize_angle(p.th + w * dt);
+    return o;
+}
+
+// robot_models/differential_drive.py:43-74.  z[k] is consumed only when variance_k > 0; `drawn` gets the mask.
+__device__ __forceinline__ Pose kinematic_step_noise(Pose p, double v, double w, double dt, const double* alpha,
+                                                     const double z[3], int& drawn)
+{
+    double var0 = alpha[0] * (v * v) + alpha[1] * (w * w);
+    if (var0 > 0.0) {
+        v = v + (0.0 + sqrt(var0) * z[0]);
+        drawn |= 1;
+    } else {
+        v = v + 0.0;
+    }
+    double var1 = alpha[2] * (v * v) + alpha[3] * (w * w);
+    if (var1 > 0.0) {
+        w = w + (0.0 + sqrt(var1) * z[1]);
+        drawn |= 2;
+    } else {
+        w = w + 0.0;
+    }
+    double var2 = alpha[4] * (v * v) + alpha[5] * (w * w);
+    double rot = 0.0;
+    if (var2 > 0.0) {
+        rot = 0.0 + sqrt(var2) * z[2];
+        drawn |= 4;
+    }
+    Pose o = kinematic_step(p, v, w, dt);
+    o.th = normalize_angle(o.th + rot * dt);
+    return o;
+}
+
+// utilities/path_tools.py:298-323 for the two-row call of tricycle_model.py:520-529
+__device__ __forceinline__ int path_velocity(Pose p0, Pose p1, double dt, double& v, double& w)
+{
+    double dx = p1.x - p0.x, dy = p1.y - p0.y;
+    double c0 = cos(p0.th), s0 = sin(p0.th);
+    double sign = signd(c0 * dx + s0 * dy);
+    if (sign == 0.0) sign = signd(s0 * dy);
+    double ds = sqrt(dx * dx + dy * dy) * sign;
+    double da = p1.th - p0.th;
+    if (da < -kPi) da += kTwoPi;
+    if (da > kPi) da -= kTwoPi;
+    v = ds / dt;
+    w = da / dt;
+    return (fabs(da) < kPi) ? 0 : BCP_ERR_ANGLE_JUMP;
+}
+
+struct Robot {
+    Pose p;
+    double v, w, steer, wheel;
+};
+
+// TricycleRobot.step (robot_models/tricycle_model.py:478-538, with :71-188) and
+// DiffDriveRobot.step (robot_models/differential_drive.py:236-265)
+__device__ __forceinline__ int robot_step(const DevParams& P, Robot& r, double cmd0, double cmd1, const double z[3],
+                                          int& drawn)
+{
+    Pose last = r.p, np_;
+    double mv, mw;
+    if (P.model == BCP_MODEL_TRICYCLE) {
+        double wa = r.wheel, new_wa, nv, nw;
+        if (P.model_front_column_pid) {   // tricycle_model.py:127-154
+            double max_delta = P.max_wheel_speed * P.dt;
+            double delta = clipd(P.p_gain * (cmd1 - wa), -max_delta, max_delta);
+            new_wa = clipd(wa + delta, -P.max_wheel_angle, P.max_wheel_angle);
+        } else {
+            new_wa = clipd(cmd1, -P.max_wheel_angle, P.max_wheel_angle);
+        }
+        double des_v = cmd0 * cos(new_wa);
+        double des_w = cmd0 * sin(new_wa) / P.L;
+        if (P.dynamic_model) {            // tricycle_model.py:157-188
+            double acc_v = (des_v - r.v) / P.dt;
+            double acc_w = (des_w - r.w) / P.dt;
+            double lin = clipd(acc_v, -2 * P.max_lin_acc, P.max_lin_acc);
+            double ang = clipd(acc_w, -P.max_ang_acc, P.max_ang_acc);
+            nv = r.v + lin * P.dt;
+            nw = r.w + ang * P.dt;
+            if (0.0 > nv) nv = 0.0;
+            np_ = P.noise_on ? kinematic_step_noise(last, nv, nw, P.dt, P.alpha, z, drawn)
+                             : kinematic_step(last, nv, nw, P.dt);
+        } else {                          // tricycle_kinematic_step :38-68
+            np_ = kinematic_step(last, des_v, des_w, P.dt);
+        }
+        r.steer = wa - cmd1;              // :532
+        r.wheel = new_wa;
+    } else {
+        np_ = P.noise_on ? kinematic_step_noise(last, cmd0, cmd1, P.dt, P.alpha, z, drawn)
+                         : kinematic_step(last, cmd0, cmd1, P.dt);
+    }
+    int err = path_velocity(last, np_, P.dt, mv, mw);
+    r.p = np_;
+    r.v = mv;
+    r.w = mw;
+    return err;
+}
+
+// Philox4x32-10 (Salmon et al., SC'11), counter = (env_lo, env_hi, step_lo, step_hi), key = seed.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// three standard normals for (seed, env, step): Box-Muller on 32-bit uniforms, evaluated in fp32 and widened.
+// The noise only has to be N(0,1)-distributed; parity runs replay the exact values through noise_z.
+__device__ __forceinline__ void device_normals(uint64_t seed, uint64_t env, uint64_t step, double z[3])
+{
+    uint32_t c[4] = {(uint32_t)env, (uint32_t)(env >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float k = 2.3283064365386963e-10f;  // 2^-32
+    float u0 = ((float)c[0] + 0.5f) * k, u1 = (float)c[1] * k;
+    float u2 = ((float)c[2] + 0.5f) * k, u3 = (float)c[3] * k;
+    u0 = fminf(fmaxf(u0, 1.0e-10f), 1.0f);
+    u2 = fminf(fmaxf(u2, 1.0e-10f), 1.0f);
+    float r0 = sqrtf(-2.0f * __logf(u0)), r1 = sqrtf(-2.0f * __logf(u2));
+    float s0, c0, s1;
+    __sincosf(6.283185307179586f * u1, &s0, &c0);
+    s1 = __sinf(6.283185307179586f * u3);
+    z[0] = (double)(r0 * c0);
+    z[1] = (double)(r0 * s0);
+    z[2] = (double)(r1 * s1);
+}
+
+}  // namespace bcp

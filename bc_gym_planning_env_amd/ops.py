@@ -1,0 +1,106 @@
+"""Operator-level seams: GPU stand-ins for the reference's optional native hooks (`*_impl` imports guarded by
+try/except ImportError), batched over many inputs.
+
+  get_pixel_footprint   utilities/path_tools.py:101-162       (get_pixel_footprint_impl)
+  pose_collides         envs/base/env.py:464-489, utilities/costmap_utils.py:178-203
+  normalize_angle       utilities/coordinate_transformations.py:17-36   (normalize_angle_impl)
+  world_to_pixel        utilities/coordinate_transformations.py:169-205 (world_to_pixel_impl)
+  robot_step            IRobot.step: tricycle_model.py:478-538 / differential_drive.py:236-265
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, robots
+from .api import EnvParams, INDUSTRIAL_TRICYCLE_V1
+
+
+class NativeOps(object):
+    """A libbcplan handle used only for the stand-alone operators (no env state bound)."""
+
+    def __init__(self, robot_name=INDUSTRIAL_TRICYCLE_V1, device=0, noise_parameters=None, params=None,
+                 footprint_scale=1.0, dynamic_model=True, model_front_column_pid=True):
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativeOps needs a GPU (libbcplan has no CPU path)")
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.params = EnvParams() if params is None else params
+        self._p = robots.make_bcp_params(self.params, robot_name, noise_parameters, footprint_scale, dynamic_model,
+                                         model_front_column_pid)
+        self._h = C.c_void_p()
+        self._n_maps = 1
+        _lib.check(self._lib.bcp_create(C.byref(self._p), 1, self.device.index or 0, 0, C.byref(self._h)))
+        self._keep = {}
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, dtype):
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(self.device, dtype).contiguous()
+
+    def normalize_angle(self, z):
+        zin = self._dev(np.atleast_1d(z) if not isinstance(z, torch.Tensor) else z, torch.float64)
+        out = torch.empty_like(zin)
+        _lib.check(self._lib.bcp_normalize_angle(self._h, zin.data_ptr(), out.data_ptr(), zin.numel(), self._stream()))
+        return out
+
+    def world_to_pixel(self, world_coords, origin, resolution):
+        xy = self._dev(world_coords, torch.float64)
+        flat = xy.reshape(-1, 2)
+        out = torch.empty(flat.shape, dtype=torch.int64, device=self.device)
+        org = np.ascontiguousarray(origin, dtype=np.float64)
+        _lib.check(self._lib.bcp_world_to_pixel(self._h, flat.data_ptr(), flat.shape[0],
+                                                org.ctypes.data_as(C.POINTER(C.c_double)), float(resolution),
+                                                out.data_ptr(), self._stream()))
+        return out.reshape(xy.shape)
+
+    def get_pixel_footprint(self, angles, map_resolution, side=None):
+        """-> (masks uint8 [n, side, side], shape_hw int32 [n, 2]); image i is masks[i, :h, :w]."""
+        ang = self._dev(np.atleast_1d(angles) if not isinstance(angles, torch.Tensor) else angles, torch.float64)
+        n = ang.numel()
+        if side is None:
+            fp = np.array([[self._p.verts[k][0], self._p.verts[k][1]] for k in range(self._p.n_verts)])
+            side = 2 * int(np.ceil(np.linalg.norm(fp, axis=1).max() / map_resolution)) + 3
+        masks = torch.empty((n, side, side), dtype=torch.uint8, device=self.device)
+        shape = torch.zeros((n, 2), dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.bcp_pixel_footprint(self._h, ang.data_ptr(), n, float(map_resolution), masks.data_ptr(),
+                                                 side, shape.data_ptr(), self._stream()))
+        return masks, shape
+
+    def set_costmap(self, data, origin, resolution):
+        d = self._dev(data, torch.uint8)
+        org = np.ascontiguousarray(origin, dtype=np.float64)
+        self._keep["map"] = d
+        _lib.check(self._lib.bcp_set_costmaps(self._h, d.data_ptr(), d.shape[0], d.shape[1], 1, None, None,
+                                              org.ctypes.data, 0, float(resolution), self._stream()))
+
+    def pose_collides(self, poses):
+        """poses [n,3] against the costmap given to set_costmap -> uint8 [n]."""
+        p = self._dev(poses, torch.float64)
+        out = torch.empty(p.shape[0], dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.bcp_pose_collides(self._h, p.data_ptr(), p.shape[0], out.data_ptr(), self._stream()))
+        return out
+
+    def robot_step(self, state7, actions, noise_z=None):
+        """state7 [n,7] rows {x,y,angle,v,w,steering_motor_command,wheel_angle}, actions [n,2] -> (new [n,7], err)."""
+        st = self._dev(state7, torch.float64).t().contiguous()  # SoA [7, n]
+        a = self._dev(actions, torch.float64)
+        n = a.shape[0]
+        z = self._dev(noise_z, torch.float64) if noise_z is not None else None
+        err = torch.zeros(n, dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.bcp_robot_step(self._h, st.data_ptr(), n, a.data_ptr(),
+                                            z.data_ptr() if z is not None else None, err.data_ptr(), self._stream()))
+        return st.t().contiguous(), err
+
+    def close(self):
+        if self._h:
+            self._lib.bcp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

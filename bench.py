@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/s of the fused PlanEnv.step() kernel on RandomMiniEnv at 65 536 envs per GPU.
+
+python bench.py --gpus N --steps K --warmup W     (N > 1: launched through torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[2], "C3"): 65 536 replicas per GPU of the RandomMiniEnv seed-0 geometry (shared
+183x183 uint8 costmap, shared refined path), tricycle dynamic model with PlanEnv's odometry noise drawn on the
+device (Philox4x32-10), float32 actions ~ U(action_space) pre-staged in HBM, reset-on-done inside the kernel.
+A "step" is one fused kernel launch over all envs of the rank.  With N > 1 ranks the env index space is sharded in
+contiguous blocks (weak scaling) and each step ends with ONE RCCL all-gather of the uint8 done mask.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 65536
+# ALGORITHMIC bytes per env-step (DESIGN.md "Bytes"): SoA state in + out (7 f64 robot + min_dist f64 + target_idx
+# i32 + current_iter i32 + robot_collided u8 = 73 B each way) + action 2 x f32 + reward f64 + done u8.
+# The shared costmap / path are LDS- and cache-resident and contribute no compulsory HBM traffic.
+BYTES_PER_ENV_STEP = 73 + 73 + 8 + 8 + 1
+HBM_PEAK_GBS = 8000.0
+
+
+def make_env(n, device, env_id_base, seed):
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g8_traj_mini_00.npz"))
+    res = float(g["resolution"])
+    params = EnvParams(goal_spat_dist=0.2, goal_ang_dist=np.pi / 8, resolution=res, refine_path=False)
+    env = BatchedPlanEnv(CostMap2D(g["costmap"], res, g["origin"]), g["path"], params, n_envs=n, device=device,
+                         auto_reset=True, env_id_base=env_id_base, seed=seed)
+    return env, g
+
+
+def cpu_baseline(g, envs, steps):
+    """The oracle (C restatement, kind "port") on the host cores of this box, same workload, bounded sample."""
+    import oracle
+    threads = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE, spatial_precision=0.2, angular_precision=np.pi / 8)
+    ref = oracle.OracleBatch(p, envs, g["costmap"], g["origin"], float(g["resolution"]), g["path"])
+    ref.reset_from_paths()
+    rng = np.random.RandomState(1)
+    lo = np.array([np.pi / 30, -np.pi / 2])
+    hi = np.array([np.pi / 6, np.pi / 2])
+    acts = [rng.uniform(lo, hi, (envs, 2)).astype(np.float32).astype(np.float64) for _ in range(4)]
+    zs = [rng.standard_normal((envs, 3)) for _ in range(4)]
+    for k in range(3):
+        ref.step(acts[k % 4], zs[k % 4], auto_reset=True, threads=threads)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ref.step(acts[k % 4], zs[k % 4], auto_reset=True, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d envs x %d steps of the same workload (C oracle, %d threads, %.1f s)" % (envs, steps, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from bc_gym_planning_env_amd import distributed as bdist
+
+    rank, world, local_rank = bdist.init_from_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    device = local_rank
+    torch.cuda.set_device(device)
+    n = args.envs_per_gpu
+    env, g = make_env(n, device, env_id_base=rank * n, seed=2024)
+    gather = bdist.DoneGather(n, torch.device("cuda", device)) if world > 1 else None
+
+    # pre-staged synthetic actions: a pool of 16 batches ~ U(action_space), float32, resident in HBM
+    rng = np.random.RandomState(1234 + rank)
+    pool = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(16)])).to(env.device)
+
+    def one_step(k):
+        env.step(pool[k % 16])
+        if gather is not None:
+            gather(env.done)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        one_step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(args.warmup + k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=env.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    env.check_errors()
+
+    # dominant kernel: the fused step.  Average launch duration from HIP events on the launch stream.
+    kernel_ms = env.time_steps(pool[0], max(20, min(args.steps, 200)))
+    achieved = BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        total_envs = n * world
+        out = {
+            "metric": "env-steps/sec at N=65536 RandomMiniEnv, 1/2/4/8 MI355X; % HBM roofline",
+            "value": total_envs * args.steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C3: RandomMiniEnv seed-0 geometry, %d envs/GPU, tricycle dynamic model + PlanEnv "
+                                   "odometry noise (on-device Philox), shared 183x183 costmap, reset on done" % n,
+                       "envs_total": total_envs, "envs_per_gpu": n, "actions": "float32 U(action_space), pre-staged",
+                       "sharding": "env blocks per rank, 1 RCCL all-gather of done per step" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "step_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n,
+                         "note": "shared-map config is ALU/latency-bound (SURVEY 8d): HBM fraction is low by construction"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(g, 8192, 40)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

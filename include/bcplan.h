@@ -1,0 +1,185 @@
+/*
+ * bcplan.h -- C ABI of libbcplan.so: batched, MI355X-native PlanEnv.step() (gfx950 HIP kernels).
+ *
+ * This is the drop-in boundary for the ONE hot path of braincorp/bc-gym-planning-env:
+ *     PlanEnv.step()                         envs/base/env.py:334-361
+ *       -> _env_step / pose_collides         envs/base/env.py:442-489
+ *       -> TricycleRobot.step                robot_models/tricycle_model.py:478-538
+ *          DiffDriveRobot.step               robot_models/differential_drive.py:236-265
+ *       -> get_pixel_footprint (+fillPoly)   utilities/path_tools.py:122-162
+ *       -> ContinuousRewardProvider.reward   envs/base/reward.py:214-259
+ * The reference has no FFI layer of its own; what it does have is a set of optional native hooks
+ * (`try: from brain.shining_utils... import *_impl`, see below).  Every entry point here cites the
+ * reference interface it replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C symbols, no exceptions, no torch types.  Return 0 on success, a negative BCP_E_* code
+ *     otherwise; bcp_last_error() returns a thread-local message for the last failure.
+ *   - Unless a parameter says "host", every pointer is a DEVICE pointer on the handle's GPU
+ *     (e.g. torch_tensor.data_ptr()); buffers are caller-owned and must outlive their use.
+ *   - All launches are asynchronous on the `stream` argument (a hipStream_t, NULL = default stream).
+ *     Nothing in bcp_step()/bcp_reset_masked() allocates, synchronises or copies to the host, so the calls
+ *     can be captured in a hipGraph.
+ *   - One handle per GPU / process rank.  A handle is not thread-safe; different handles are independent.
+ *   - There is NO CPU fallback in this library: without a GPU bcp_create() fails with BCP_E_NO_DEVICE.
+ */
+#ifndef BCPLAN_H
+#define BCPLAN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BCP_ABI_VERSION 1
+#define BCP_MAX_VERTS 32
+#define BCP_LETHAL 254 /* CostMap2D.LETHAL_OBSTACLE, utilities/costmap_2d.py:20-22 */
+#define BCP_MAX_KERNEL_HALF 127 /* footprint mask is at most 255x255 px (circumscribed radius / resolution) */
+
+enum { BCP_MODEL_TRICYCLE = 0, BCP_MODEL_DIFFDRIVE = 1 };
+
+enum {
+    BCP_OK = 0,
+    BCP_E_INVALID = -1,   /* bad argument / unsupported configuration */
+    BCP_E_NO_DEVICE = -2, /* no usable GPU: the product has no CPU path */
+    BCP_E_HIP = -3,       /* a HIP runtime call failed (message has the hipError string) */
+    BCP_E_STATE = -4      /* call order violated (e.g. step before costmaps/paths/state were bound) */
+};
+
+/* per-env error bits written to bcp_step_io.err (mirror of the reference's Python exceptions) */
+enum {
+    BCP_ERR_ANGLE_JUMP = 1 /* path_velocity raises when |dtheta| >= pi, utilities/path_tools.py:319-322 */
+};
+
+/* bcp_step flags */
+enum {
+    BCP_STEP_AUTO_RESET = 1, /* after outputs are written, envs with done=1 are restored to the bound initial
+                                state (what a VecEnv does: scripts/rl_runners/ppo_runner.py:35-36) */
+    BCP_STEP_ACTIONS_F32 = 2 /* actions are float32[N,2] (action_space dtype, envs/base/env.py:237-240);
+                                otherwise float64[N,2].  float32 is widened to float64 before any arithmetic */
+};
+
+/* POD flattening of EnvParams (envs/base/params.py:14-42), RewardParams (envs/base/reward.py:162-171),
+ * the TricycleRobot switches (robot_models/tricycle_model.py:296-300) and the robot constants
+ * (robot_models/robot_dimensions_examples.py:108-188).  host struct. */
+typedef struct bcp_params {
+    int32_t abi_version;            /* = BCP_ABI_VERSION */
+    int32_t model;                  /* BCP_MODEL_* */
+    int32_t n_verts;                /* footprint vertices, <= BCP_MAX_VERTS */
+    int32_t dynamic_model;          /* TricycleRobot._dynamic_model */
+    int32_t model_front_column_pid; /* TricycleRobot._model_front_column_pid */
+    int32_t noise_on;               /* noise_parameters is not None (env.py:226-232) */
+    int32_t iteration_timeout;      /* EnvParams.iteration_timeout */
+    int32_t reserved0;
+    double verts[BCP_MAX_VERTS][2]; /* metres, robot frame, already multiplied by footprint_scale */
+    double dt;
+    double front_wheel_from_axis;
+    double max_front_wheel_angle;
+    double max_front_wheel_speed;
+    double max_linear_acceleration;
+    double max_angular_acceleration;
+    double front_column_p_gain;
+    double alpha[6];                /* alpha1..alpha6 of the odometry noise model (differential_drive.py:55-74) */
+    double spatial_precision;       /* RewardParams */
+    double angular_precision;
+    double spatial_progress_multiplier;
+} bcp_params;
+
+/* Struct-of-arrays env state, caller-owned device memory, n_envs elements per array.
+ * Field names follow State / TricycleRobotState / ContinuousRewardProviderState
+ * (envs/base/env.py:52-68, robot_models/tricycle_model.py:234-244, envs/base/reward.py:12-23).
+ * `current_time` is not stored: it is the running float64 sum of dt over current_iter steps (env.py:382) and the
+ * host layer rebuilds it bit-exactly from current_iter. */
+typedef struct bcp_state {
+    double *x, *y, *angle;            /* robot pose == State.pose (delays 0) */
+    double *v, *w;                    /* measured velocities */
+    double *steering_motor_command;   /* tricycle only (may alias a dummy array for diff-drive) */
+    double *wheel_angle;              /* tricycle only */
+    double *min_spat_dist_so_far;     /* reward provider */
+    int32_t *target_idx;              /* reward provider */
+    int32_t *current_iter;
+    uint8_t *robot_collided;          /* sticky */
+} bcp_state;
+
+/* per-step inputs/outputs, device pointers, N = n_envs */
+typedef struct bcp_step_io {
+    const void *actions;     /* [N,2] (wheel_v, wheel_angle) tricycle / (v, w) diff-drive; dtype by flag */
+    const double *noise_z;   /* [N,3] standard normals in slot order, or NULL: then, if params.noise_on, normals
+                                come from the on-device Philox4x32-10 stream keyed (seed, env, step counter) */
+    double *noise_z_out;     /* optional [N,3]: the normals this step used (NaN where no draw happened) */
+    double *reward;          /* [N] */
+    uint8_t *done;           /* [N] goal reached | timed out | robot_collided (env.py:407-419) */
+    uint8_t *collided_now;   /* optional [N]: this step's pose_collides verdict (return of _env_step) */
+    int32_t *err;            /* optional [N]: BCP_ERR_* bits */
+} bcp_step_io;
+
+typedef struct bcp_handle bcp_handle;
+
+/* ---- lifetime ----------------------------------------------------------------------------------------- */
+const char *bcp_last_error(void);
+int bcp_abi_version(void);
+/* replaces PlanEnv.__init__ (env.py:219-249) for a batch of n_envs envs on GPU `device`.
+ * env_id_base: global index of this handle's env 0 (rank * n_envs when sharded); keys the RNG stream. */
+int bcp_create(const bcp_params *params /*host*/, int64_t n_envs, int device, int64_t env_id_base, bcp_handle **out);
+int bcp_destroy(bcp_handle *h);
+/* PlanEnv.seed / np.random.seed for the noise stream (differential_drive.py:50 uses the global numpy RNG) */
+int bcp_seed(bcp_handle *h, uint64_t seed);
+
+/* ---- static per-episode inputs ------------------------------------------------------------------------ */
+/* CostMap2D (utilities/costmap_2d.py:13-37).  data: uint8 [rows, cols] when shared, else [N, rows, cols]
+ * (row-major, `rows`/`cols` is the padded allocation).  valid_rows/valid_cols (optional, [N] int32) give each
+ * env's true map shape for the bounds test of env.py:483-484; NULL => rows/cols.  origins: host double[2] when
+ * origins_per_env == 0, else device double [N,2].  Builds the library-owned 1-bit lethal mask
+ * (cell == 254) that the step kernel reads; call again whenever the costmap content changes. */
+int bcp_set_costmaps(bcp_handle *h, const uint8_t *data, int32_t rows, int32_t cols, int32_t shared,
+                     const int32_t *valid_rows, const int32_t *valid_cols, const double *origins,
+                     int32_t origins_per_env, double resolution, void *stream);
+/* Static path of the reward provider (ContinuousRewardProviderState.path, reward.py:17-18), already refined.
+ * xytheta: double [max_len,3] when shared, else [N,max_len,3]; lens: NULL when shared (then len = max_len) else
+ * int32 [N].  Precomputes cos/sin of the waypoint headings (path_tools.py:405) on the device. */
+int bcp_set_paths(bcp_handle *h, const double *xytheta, const int32_t *lens, int32_t max_len, int32_t shared,
+                  void *stream);
+
+/* ---- state -------------------------------------------------------------------------------------------- */
+/* PlanEnv.set_state / get_state (env.py:278-291): the library reads and writes the caller's SoA arrays in
+ * place, so "get_state" is reading these tensors and "set_state" is writing them. */
+int bcp_bind_state(bcp_handle *h, const bcp_state *state /*host struct of device pointers*/);
+/* PlanEnv._initial_state (env.py:247): the snapshot reset()/auto-reset restores. */
+int bcp_bind_initial_state(bcp_handle *h, const bcp_state *initial /*host struct of device pointers*/);
+/* PlanEnv.reset (env.py:293-303) for every env with mask[i] != 0 (mask NULL = all). */
+int bcp_reset_masked(bcp_handle *h, const uint8_t *mask, void *stream);
+
+/* ---- the hot path ------------------------------------------------------------------------------------- */
+/* PlanEnv.step (env.py:334-361) for all envs: one fused kernel launch. */
+int bcp_step(bcp_handle *h, const bcp_step_io *io /*host struct*/, uint32_t flags, void *stream);
+
+/* ---- operator-level seams (the reference's optional native hooks) -------------------------------------- */
+/* IRobot.step for n robots (tricycle_model.py:478 / differential_drive.py:236): kinematics only, no collision.
+ * state7_io: [7][n] SoA {x,y,angle,v,w,steering_motor_command,wheel_angle}; actions float64 [n,2]. */
+int bcp_robot_step(bcp_handle *h, double *state7_io, int64_t n, const double *actions, const double *noise_z,
+                   int32_t *err, void *stream);
+/* pose_collides(x, y, angle, robot, costmap) (env.py:464-489; twin costmap_utils.py:178-203) for n poses
+ * [n,3]; pose i is tested against env (i % n_envs)'s costmap.  out: uint8 [n]. */
+int bcp_pose_collides(bcp_handle *h, const double *poses, int64_t n, uint8_t *out, void *stream);
+/* get_pixel_footprint_impl(angle, footprint, resolution, fill=True) (path_tools.py:101-162) for n angles.
+ * masks: uint8 [n, side, side] (side >= 2*half+1 for every angle), zero-filled then 255 inside; the kernel
+ * image of angle i occupies the top-left shape_hw[i] = {2*half_y+1, 2*half_x+1} corner. */
+int bcp_pixel_footprint(bcp_handle *h, const double *angles, int64_t n, double resolution, uint8_t *masks,
+                        int32_t side, int32_t *shape_hw, void *stream);
+/* normalize_angle_impl (coordinate_transformations.py:17-36) */
+int bcp_normalize_angle(bcp_handle *h, const double *in, double *out, int64_t n, void *stream);
+/* world_to_pixel_impl (coordinate_transformations.py:169-205): xy [n,2] -> int64 [n,2]; origin host double[2] */
+int bcp_world_to_pixel(bcp_handle *h, const double *xy, int64_t n, const double *origin, double resolution,
+                       int64_t *out, void *stream);
+
+/* ---- measurement -------------------------------------------------------------------------------------- */
+/* Runs `steps` bcp_step() launches back to back on `stream` bracketed by HIP events recorded on that stream and
+ * returns the average kernel-launch duration in milliseconds (synchronises).  Used by bench.py for
+ * roofline.achieved. */
+int bcp_time_steps(bcp_handle *h, const bcp_step_io *io, uint32_t flags, int32_t steps, void *stream, float *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BCPLAN_H */

@@ -1,0 +1,439 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes -> libbcplan.so), against
+  (a) golden vectors captured from the genuine reference (tests/golden), and
+  (b) the CPU oracle on the same seeded inputs.
+done / collision / target_idx / pixel masks are compared bit-exactly; float64 state and reward within ATOL=1e-9
+(the north star allows 1e-5)."""
+import os
+
+import numpy as np
+import pytest
+
+from util import ATOL, GOLDEN, TRAJ, env_from_traj, oracle_params_for, z_in
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def test_native_library_is_loaded(torch_cuda):
+    from bc_gym_planning_env_amd import _lib
+    L = _lib.load()
+    assert L.bcp_abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libbcplan.so" in f.read()
+
+
+def test_scalar_ops_bit_exact(torch_cuda):
+    from bc_gym_planning_env_amd import NativeOps
+    ops = NativeOps()
+    g = load("g4_scalar_utils.npz")
+    np.testing.assert_array_equal(ops.normalize_angle(g["na_in"]).cpu().numpy(), g["na_out"])
+    np.testing.assert_array_equal(ops.normalize_angle(g["da_a"] - g["da_b"]).cpu().numpy(), g["da_out"])
+    for i in range(7):
+        out = ops.world_to_pixel(g["w2p%d_xy" % i], g["w2p%d_origin" % i], float(g["w2p%d_res" % i]))
+        np.testing.assert_array_equal(out.cpu().numpy(), g["w2p%d_out" % i])
+
+
+@pytest.mark.parametrize("fixture,robot,noisy", [("g1_tricycle_step.npz", "industrial_tricycle_v1", False),
+                                                ("g2_tricycle_step_noise.npz", "industrial_tricycle_v1", True),
+                                                ("g3_diffdrive_step.npz", "industrial_diffdrive_v1", False)])
+def test_robot_step_vs_reference(torch_cuda, fixture, robot, noisy):
+    from bc_gym_planning_env_amd import NativeOps
+    g = load(fixture)
+    if noisy:
+        for ai, alpha in enumerate(g["alphas"]):
+            sel = g["alpha_idx"] == ai
+            noise = dict(("alpha%d" % (k + 1), alpha[k]) for k in range(6))
+            ops = NativeOps(robot, noise_parameters=noise)
+            out, err = ops.robot_step(g["state"][sel], g["cmd"][sel], z_in(g["z"][sel]))
+            np.testing.assert_allclose(out.cpu().numpy(), g["out"][sel], rtol=0, atol=ATOL)
+            assert int(err.sum()) == 0
+    else:
+        ops = NativeOps(robot)
+        out, err = ops.robot_step(g["state"], g["cmd"])
+        np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=0, atol=ATOL)
+        assert int(err.sum()) == 0
+
+
+@pytest.mark.parametrize("variant,dyn,pid", [("kin_pid", False, True), ("kin_nopid", False, False),
+                                             ("dyn_nopid", True, False)])
+def test_tricycle_variants(torch_cuda, variant, dyn, pid):
+    from bc_gym_planning_env_amd import NativeOps
+    g = load("g1b_tricycle_variants.npz")
+    ops = NativeOps(dynamic_model=dyn, model_front_column_pid=pid)
+    out, _ = ops.robot_step(g["state"], g["cmd"])
+    np.testing.assert_allclose(out.cpu().numpy(), g[variant], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("robot,fp_name", [("industrial_tricycle_v1", "tri"), ("industrial_diffdrive_v1", "dd")])
+@pytest.mark.parametrize("res_name", ["r003", "r64", "r256"])
+def test_pixel_footprint_masks_bit_exact(torch_cuda, oracle, robot, fp_name, res_name):
+    """get_pixel_footprint: shape from the reference's own pre-fill arithmetic (g5), pixels from the oracle fill."""
+    from bc_gym_planning_env_amd import NativeOps
+    g = load("g5_footprint_vertices.npz")
+    key = "%s_%s" % (fp_name, res_name)
+    res = float(g[key + "_res"])
+    rng = np.random.RandomState(11)
+    angles = np.concatenate([g[key + "_angles"], rng.uniform(-np.pi, np.pi, 6000)])
+    ops = NativeOps(robot)
+    masks, shapes = ops.get_pixel_footprint(angles, res)
+    masks, shapes = masks.cpu().numpy(), shapes.cpu().numpy()
+    np.testing.assert_array_equal(shapes[:len(g[key + "_shape"])], g[key + "_shape"])
+    fp = oracle.TRICYCLE_FOOTPRINT if fp_name == "tri" else oracle.DIFFDRIVE_FOOTPRINT
+    for i, a in enumerate(angles):
+        exp = oracle.pixel_footprint(a, fp, res)
+        h, w = shapes[i]
+        assert (h, w) == exp.shape
+        np.testing.assert_array_equal(masks[i, :h, :w], exp, err_msg="angle %r" % a)
+        assert not masks[i, h:, :].any() and not masks[i, :, w:].any()
+
+
+@pytest.mark.parametrize("tag", ["mini0", "mini3", "mini64"])
+def test_pose_collides_vs_reference(torch_cuda, tag):
+    from bc_gym_planning_env_amd import NativeOps
+    g = load("g6_pose_collides.npz")
+    robot = "industrial_tricycle_v1" if int(g[tag + "_robot"]) == 0 else "industrial_diffdrive_v1"
+    ops = NativeOps(robot)
+    ops.set_costmap(g[tag + "_map"], g[tag + "_origin"], float(g[tag + "_res"]))
+    got = ops.pose_collides(g[tag + "_poses"]).cpu().numpy()
+    np.testing.assert_array_equal(got, g[tag + "_collides"])
+
+
+def test_kat_collision_table(torch_cuda):
+    """The reference's 20-pose truth table (utilities/test_costmap_utils.py:251-314) through the HIP path."""
+    from bc_gym_planning_env_amd import NativeOps
+    from bc_gym_planning_env_amd import EnvParams
+    g = load("kat_collision_map.npz")
+    rect = np.array([[-0.77, -0.385], [-0.77, 0.385], [0.67, 0.385], [0.67, -0.385]])
+    from bc_gym_planning_env_amd import robots
+    robots.FOOTPRINTS["kat_rect"] = rect
+    robots.MODELS["kat_rect"] = 1
+    try:
+        ops = NativeOps("kat_rect")
+        ops.set_costmap(g["costmap"], g["origin"], float(g["resolution"]))
+        poses = [(x, 0., 0.2) for x in range(7)] + [(x, 1.2, np.pi / 2 + 0.4) for x in range(7)]
+        poses += [(0., -3, 0.2), (1., -3, 0.2), (2., -3, 0.2), (0., -3.2, 0.2), (1., -3.2, 0.2), (2., -3.2, 0.2)]
+        expected = [0, 1, 1, 0, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 0, 1, 1, 0, 0, 0]
+        got = ops.pose_collides(np.array(poses, dtype=np.float64)).cpu().numpy()
+        pix = ops.world_to_pixel(np.array(poses)[:, :2], g["origin"], float(g["resolution"])).cpu().numpy()
+        inside = (pix[:, 0] >= 0) & (pix[:, 0] < 200) & (pix[:, 1] >= 0) & (pix[:, 1] < 120)
+        np.testing.assert_array_equal(got * inside, expected)
+        masks, shapes = ops.get_pixel_footprint(np.array([0.]), 0.05)
+        assert int((masks[0] > 0).sum()) == 493  # test_path_tools.py:465-468
+    finally:
+        del robots.FOOTPRINTS["kat_rect"], robots.MODELS["kat_rect"]
+
+
+@pytest.mark.parametrize("path", TRAJ, ids=[os.path.basename(p)[8:-4] for p in TRAJ])
+def test_full_step_trajectories_vs_reference(torch_cuda, path):
+    """PlanEnv.step replayed on the GPU with the recorded actions and normals (golden g8)."""
+    torch = torch_cuda
+    g = np.load(path)
+    name = os.path.basename(path)
+    env = env_from_traj(g, name, n_envs=1)
+    assert int(env.state.target_idx[0]) == int(g["init_target_idx"])
+    assert float(env.state.min_spat_dist_so_far[0]) == float(g["init_min_dist"])
+    T = len(g["actions"])
+    actions = torch.from_numpy(g["actions"].astype(np.float32)).cuda()
+    z = torch.from_numpy(z_in(g["z"])).cuda()
+    states = torch.zeros(T, 7, dtype=torch.float64, device="cuda")
+    rew = torch.zeros(T, dtype=torch.float64, device="cuda")
+    done = torch.zeros(T, dtype=torch.uint8, device="cuda")
+    coll = torch.zeros(T, dtype=torch.uint8, device="cuda")
+    tidx = torch.zeros(T, dtype=torch.int32, device="cuda")
+    mind = torch.zeros(T, dtype=torch.float64, device="cuda")
+    tm = torch.zeros(T, dtype=torch.float64, device="cuda")
+    noisy = env.noise_parameters is not None
+    for t in range(T):
+        obs, r, d, info = env.step(actions[t:t + 1], z[t:t + 1] if noisy else None)
+        states[t] = env.state.robot[:, 0]
+        rew[t], done[t], coll[t] = r[0], d[0], env.state.robot_collided[0]
+        tidx[t], mind[t], tm[t] = env.state.target_idx[0], env.state.min_spat_dist_so_far[0], obs.time[0]
+        assert info == {}
+    env.check_errors()
+    np.testing.assert_array_equal(done.cpu().numpy(), g["done"])
+    np.testing.assert_array_equal(coll.cpu().numpy(), g["collided"])
+    np.testing.assert_array_equal(tidx.cpu().numpy(), g["target_idx"])
+    np.testing.assert_array_equal(tm.cpu().numpy(), g["time"])
+    np.testing.assert_allclose(states.cpu().numpy(), g["states"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(rew.cpu().numpy(), g["reward"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(mind.cpu().numpy(), g["min_dist"], rtol=0, atol=ATOL)
+    # reference-shaped per-env view
+    o = obs[0]
+    assert o.path.shape[0] == max(len(g["path"]) - int(g["target_idx"][-1]), 0)
+    assert o.time == g["time"][-1] and o.dt == 0.05
+    s = env.envs[0].get_state()
+    assert s.current_iter == T and s.robot_collided == bool(g["collided"][-1])
+
+
+def _random_batch(oracle, rng, n, g, name):
+    """n envs on the recorded map/path, started from random poses near the path (many collide or progress)."""
+    path = g["path"]
+    idx = rng.randint(0, len(path), n)
+    st = np.zeros((7, n))
+    st[0] = path[idx, 0] + rng.normal(0, 0.15, n)
+    st[1] = path[idx, 1] + rng.normal(0, 0.15, n)
+    st[2] = path[idx, 2] + rng.normal(0, 0.3, n)
+    st[3] = rng.uniform(0, 0.5, n)
+    st[4] = rng.uniform(-0.5, 0.5, n)
+    st[6] = rng.uniform(-1.0, 1.0, n)
+    tgt = np.clip(idx + rng.randint(-3, 4, n), 1, len(path) - 1).astype(np.int32)
+    md = np.hypot(path[tgt, 0] - st[0], path[tgt, 1] - st[1]) + rng.uniform(-0.01, 0.05, n)
+    it = rng.randint(0, 1200, n).astype(np.int32)
+    it[:8] = 1199  # timeout on this very step
+    return st, md, tgt, it
+
+
+@pytest.mark.parametrize("fixture", ["g8_traj_mini_00.npz", "g8_traj_mini_05.npz", "g8_traj_aisle_default.npz"])
+def test_batch_vs_oracle_multi_step(torch_cuda, oracle, fixture):
+    """4096 envs, 40 steps, auto-reset, on-device Philox noise (its normals are read back and replayed through the
+    oracle): exact done / collided / target_idx, state within ATOL."""
+    torch = torch_cuda
+    g = load(fixture)
+    n, steps = 4096, 40
+    rng = np.random.RandomState(7)
+    env = env_from_traj(g, fixture, n_envs=n, auto_reset=True, seed=123)
+    p = oracle_params_for(oracle, fixture)
+    ref = oracle.OracleBatch(p, n, g["costmap"], g["origin"], float(g["resolution"]), g["path"])
+    ref.reset_from_paths()
+    st, md, tgt, it = _random_batch(oracle, rng, n, g, fixture)
+    for f in range(7):
+        ref.st[f][:] = st[f]
+    ref.min_dist[:], ref.target_idx[:], ref.cur_iter[:] = md, tgt, it
+    env.state.robot.copy_(torch.from_numpy(st))
+    env.state.min_spat_dist_so_far.copy_(torch.from_numpy(md))
+    env.state.target_idx.copy_(torch.from_numpy(tgt))
+    env.state.current_iter.copy_(torch.from_numpy(it))
+    zout = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    n_done = n_coll = n_rew = 0
+    for t in range(steps):
+        a = env.action_space.sample_batch(n, rng)
+        env.step(a, noise_z_out=zout)
+        z = zout.cpu().numpy()
+        ref.step(a.astype(np.float64), z_in(z), auto_reset=True, threads=8)
+        np.testing.assert_array_equal(env.done.cpu().numpy(), ref.done, err_msg="step %d" % t)
+        np.testing.assert_array_equal(env.collided_now.cpu().numpy(), ref.collided_now, err_msg="step %d" % t)
+        np.testing.assert_array_equal(env.state.target_idx.cpu().numpy(), ref.target_idx)
+        np.testing.assert_array_equal(env.state.current_iter.cpu().numpy(), ref.cur_iter)
+        np.testing.assert_array_equal(env.state.robot_collided.cpu().numpy(), ref.collided)
+        np.testing.assert_allclose(env.state.robot.cpu().numpy(), np.stack(ref.st), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(env.reward.cpu().numpy(), ref.reward, rtol=0, atol=ATOL)
+        np.testing.assert_allclose(env.state.min_spat_dist_so_far.cpu().numpy(), ref.min_dist, rtol=0, atol=ATOL)
+        n_done += int(ref.done.sum())
+        n_coll += int(ref.collided_now.sum())
+        n_rew += int((ref.reward == 1.0).sum())
+        if t == 0:
+            zz = z[~np.isnan(z)]
+            assert len(zz) > n and abs(zz.mean()) < 0.05 and abs(zz.std() - 1.0) < 0.05
+    env.check_errors()
+    assert n_done > 50 and n_coll > 50 and n_rew > 50, (n_done, n_coll, n_rew)
+
+
+def test_diffdrive_shared_64x64_vs_oracle(torch_cuda, oracle):
+    """C2 shape: diff-drive robot, shared 64x64 costmap (res 5.5/64), noise off, float32 actions."""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    g = load("g6_pose_collides.npz")
+    cm, origin, res = g["mini64_map"], g["mini64_origin"], float(g["mini64_res"])
+    assert cm.shape == (64, 64)
+    n, steps = 4096, 60
+    rng = np.random.RandomState(3)
+    path = np.array([[-1.5, -1.0, 0.4], [1.2, 0.6, 0.9]])
+    params = EnvParams(goal_spat_dist=0.2, goal_ang_dist=np.pi / 8, resolution=res,
+                       robot_name='industrial_diffdrive_v1')
+    env = BatchedPlanEnv(CostMap2D(cm, res, origin), path, params, n_envs=n, noise_parameters=None, auto_reset=True)
+    p = oracle.make_params("diffdrive", spatial_precision=0.2, angular_precision=np.pi / 8)
+    ref = oracle.OracleBatch(p, n, cm, origin, res, env.path_of(0))
+    ref.reset_from_paths()
+    np.testing.assert_array_equal(env.state.robot.cpu().numpy(), np.stack(ref.st))
+    st0 = np.stack(ref.st)
+    st0[0] += rng.uniform(-0.5, 2.0, n)
+    st0[1] += rng.uniform(-0.5, 1.5, n)
+    st0[2] += rng.uniform(-1, 1, n)
+    for f in range(7):
+        ref.st[f][:] = st0[f]
+    env.state.robot.copy_(torch.from_numpy(st0))
+    tot = 0
+    for t in range(steps):
+        a = np.stack([rng.uniform(0.105, 0.524, n), rng.uniform(-np.pi / 2, np.pi / 2, n)], 1).astype(np.float32)
+        env.step(a)
+        ref.step(a.astype(np.float64), None, auto_reset=True, threads=8)
+        np.testing.assert_array_equal(env.done.cpu().numpy(), ref.done)
+        np.testing.assert_array_equal(env.collided_now.cpu().numpy(), ref.collided_now)
+        np.testing.assert_array_equal(env.state.target_idx.cpu().numpy(), ref.target_idx)
+        np.testing.assert_allclose(env.state.robot.cpu().numpy(), np.stack(ref.st), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(env.reward.cpu().numpy(), ref.reward, rtol=0, atol=ATOL)
+        tot += int(ref.collided_now.sum())
+    assert tot > 100
+
+
+def test_private_maps_and_paths_vs_oracle(torch_cuda, oracle):
+    """C4 shape at reduced N: per-env costmaps (different shapes, padded) and per-env paths of different length."""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    names = ["g8_traj_aisle_c4_00.npz", "g8_traj_aisle_c4_10.npz", "g8_traj_aisle_c4_01.npz", "g8_traj_aisle_c4_11.npz"]
+    gs = [load(nm) for nm in names]
+    n, steps = 1024, 50
+    rng = np.random.RandomState(9)
+    res = float(gs[0]["resolution"])
+    costmaps = [CostMap2D(gs[i % 4]["costmap"], res, gs[i % 4]["origin"]) for i in range(n)]
+    paths = [gs[i % 4]["path"][:len(gs[i % 4]["path"]) - (i % 3)] for i in range(n)]
+    params = EnvParams(resolution=res, refine_path=False)
+    env = BatchedPlanEnv(costmaps, paths, params, n_envs=n, auto_reset=True, seed=5)
+    rows = max(c.get_data().shape[0] for c in costmaps)
+    cols = max(c.get_data().shape[1] for c in costmaps)
+    maps = np.zeros((n, rows, cols), dtype=np.uint8)
+    vr, vc = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    for i, c in enumerate(costmaps):
+        d = c.get_data()
+        # poison the padding: it must never be read as in-map
+        maps[i] = 254
+        maps[i, :d.shape[0], :d.shape[1]] = d
+        vr[i], vc[i] = d.shape
+    origins = np.stack([c.get_origin() for c in costmaps])
+    max_len = max(len(p) for p in paths)
+    pbuf = np.zeros((n, max_len, 3))
+    for i, p_ in enumerate(paths):
+        pbuf[i, :len(p_)] = p_
+    # give the HIP path the poisoned maps as well
+    env.set_costmap_tensors(torch.from_numpy(maps).cuda(), torch.from_numpy(origins).cuda(), res,
+                            torch.from_numpy(vr).cuda(), torch.from_numpy(vc).cuda())
+    p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE)
+    ref = oracle.OracleBatch(p, n, maps, origins, res, pbuf, lens=[len(p_) for p_ in paths], rows=vr, cols=vc)
+    ref.reset_from_paths()
+    np.testing.assert_array_equal(env.state.target_idx.cpu().numpy(), ref.target_idx)
+    zout = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    tot_c = tot_r = 0
+    for t in range(steps):
+        a = env.action_space.sample_batch(n, rng)
+        a[:, 0] *= 2.0
+        env.step(a, noise_z_out=zout)
+        ref.step(a.astype(np.float64), z_in(zout.cpu().numpy()), auto_reset=True, threads=8)
+        np.testing.assert_array_equal(env.done.cpu().numpy(), ref.done)
+        np.testing.assert_array_equal(env.collided_now.cpu().numpy(), ref.collided_now)
+        np.testing.assert_array_equal(env.state.target_idx.cpu().numpy(), ref.target_idx)
+        np.testing.assert_allclose(env.state.robot.cpu().numpy(), np.stack(ref.st), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(env.reward.cpu().numpy(), ref.reward, rtol=0, atol=ATOL)
+        tot_c += int(ref.collided_now.sum())
+        tot_r += int((ref.reward == 1.0).sum())
+    assert tot_r > 100
+
+
+def test_full_size_properties_65536(torch_cuda, oracle):
+    """BASELINE size (65 536 envs, tricycle + noise, shared 183x183 map): size-independent properties.
+      * replicas fed identical actions and normals stay bit-identical;
+      * the batch is permutation-equivariant (env i's result does not depend on its slot);
+      * robot_collided is sticky and done == goal | timeout | collided;
+      * a random sample of envs matches the oracle stepped on exactly those envs."""
+    torch = torch_cuda
+    name = "g8_traj_mini_00.npz"
+    g = load(name)
+    n, steps = 65536, 25
+    rng = np.random.RandomState(21)
+    env = env_from_traj(g, name, n_envs=n, auto_reset=False, seed=77)
+    st, md, tgt, it = _random_batch(oracle, rng, n, g, name)
+    # first 1024 envs: replicas of env 0
+    for arr in (st,):
+        arr[:, :1024] = arr[:, :1]
+    md[:1024], tgt[:1024], it[:1024] = md[0], tgt[0], it[0]
+    perm = rng.permutation(n)
+    env2 = env_from_traj(g, name, n_envs=n, auto_reset=False, seed=77)
+
+    def put(e, order):
+        e.state.robot.copy_(torch.from_numpy(st[:, order]))
+        e.state.min_spat_dist_so_far.copy_(torch.from_numpy(md[order]))
+        e.state.target_idx.copy_(torch.from_numpy(tgt[order]))
+        e.state.current_iter.copy_(torch.from_numpy(it[order]))
+    ident = np.arange(n)
+    put(env, ident)
+    put(env2, perm)
+    sample = np.sort(rng.choice(np.arange(1024, n), 2048, replace=False))
+    p = oracle_params_for(oracle, name)
+    ref = oracle.OracleBatch(p, len(sample), g["costmap"], g["origin"], float(g["resolution"]), g["path"])
+    ref.reset_from_paths()
+    for f in range(7):
+        ref.st[f][:] = st[f, sample]
+    ref.min_dist[:], ref.target_idx[:], ref.cur_iter[:] = md[sample], tgt[sample], it[sample]
+    prev_coll = np.zeros(n, dtype=np.uint8)
+    for t in range(steps):
+        a = env.action_space.sample_batch(n, rng)
+        a[:1024] = a[0]
+        z = rng.standard_normal((n, 3))
+        z[:1024] = z[0]
+        env.step(a, z)
+        env2.step(a[perm], z[perm])
+        rob = env.state.robot.cpu().numpy()
+        # replicas
+        assert (rob[:, :1024] == rob[:, :1]).all()
+        # permutation equivariance
+        np.testing.assert_array_equal(env2.state.robot.cpu().numpy(), rob[:, perm])
+        np.testing.assert_array_equal(env2.done.cpu().numpy(), env.done.cpu().numpy()[perm])
+        np.testing.assert_array_equal(env2.reward.cpu().numpy(), env.reward.cpu().numpy()[perm])
+        # sticky collision flag and the done law
+        coll = env.state.robot_collided.cpu().numpy()
+        assert (coll >= prev_coll).all()
+        np.testing.assert_array_equal(coll, prev_coll | env.collided_now.cpu().numpy())
+        prev_coll = coll
+        goal = env.state.target_idx.cpu().numpy() > len(g["path"]) - 1
+        timeout = env.state.current_iter.cpu().numpy() >= 1200
+        np.testing.assert_array_equal(env.done.cpu().numpy().astype(bool), goal | timeout | coll.astype(bool))
+        # oracle on the sample
+        ref.step(a[sample].astype(np.float64), z[sample], threads=8)
+        np.testing.assert_array_equal(env.done.cpu().numpy()[sample], ref.done)
+        np.testing.assert_array_equal(env.collided_now.cpu().numpy()[sample], ref.collided_now)
+        np.testing.assert_array_equal(env.state.target_idx.cpu().numpy()[sample], ref.target_idx)
+        np.testing.assert_allclose(rob[:, sample], np.stack(ref.st), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(env.reward.cpu().numpy()[sample], ref.reward, rtol=0, atol=ATOL)
+    assert prev_coll.sum() > 1000
+
+
+def test_reset_and_state_roundtrip(torch_cuda):
+    torch = torch_cuda
+    name = "g8_traj_mini_01.npz"
+    g = load(name)
+    n = 512
+    env = env_from_traj(g, name, n_envs=n, seed=1)
+    s0 = env.get_state()
+    rng = np.random.RandomState(0)
+    for _ in range(10):
+        env.step(env.action_space.sample_batch(n, rng))
+    s1 = env.get_state()
+    assert not torch.equal(s0.robot, s1.robot)
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    mask[::2] = 1
+    env.reset(mask)
+    assert torch.equal(env.state.robot[:, ::2], s0.robot[:, ::2])
+    assert torch.equal(env.state.robot[:, 1::2], s1.robot[:, 1::2])
+    assert torch.equal(env.state.current_iter[::2], s0.current_iter[::2])
+    env.set_state(s1)
+    assert torch.equal(env.state.robot, s1.robot) and torch.equal(env.state.current_iter, s1.current_iter)
+    # per-env reference-shaped State round trip
+    st = env.envs[3].get_state()
+    env.envs[5].set_state(st)
+    st5 = env.envs[5].get_state()
+    assert st5.robot_state == st.robot_state and st5.current_iter == st.current_iter
+    assert st5.reward_provider_state == st.reward_provider_state
+    env.reset()
+    assert torch.equal(env.state.robot, s0.robot)
+
+
+def test_action_list_api(torch_cuda):
+    """step() also accepts the reference's Action objects."""
+    from bc_gym_planning_env_amd import Action
+    name = "g8_traj_mini_02.npz"
+    g = load(name)
+    env = env_from_traj(g, name, n_envs=2)
+    a = Action(command=np.array([0.3, 0.1], dtype=np.float32))
+    obs, r, d, info = env.step([a, a], noise_z=np.zeros((2, 3)))
+    o = obs[0]
+    assert o.pose.shape == (3,) and o.robot_state.wheel_angle != 0.0
+    assert np.array_equal(obs[1].pose, o.pose)
