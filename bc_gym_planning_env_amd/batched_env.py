@@ -94,7 +94,7 @@ class EnvView(object):
                                             target_idx=tidx)
         return State(reward_provider_state=rps, path=rps.current_path(), original_path=np.copy(path),
                      costmap=e.costmap_of(i), iter_timeout=e.params.iteration_timeout,
-                     current_time=float(e.time_table[min(it, len(e.time_table) - 1)]), current_iter=it,
+                     current_time=float(e.time_of(e.state.current_iter[i:i + 1])[0]), current_iter=it,
                      robot_collided=bool(e.state.robot_collided[i]), poses_queue=[], robot_state_queue=[],
                      control_queue=[], pose=col[:3].copy(), robot_state=self._robot_state(col))
 
@@ -319,7 +319,11 @@ class BatchedPlanEnv(object):
 
     def time_of(self, current_iter):
         """Observation.time for iteration counters (device tensor): dt accumulated current_iter times."""
-        idx = current_iter.to(torch.int64).clamp_(max=len(self.time_table) - 1)
+        idx = current_iter.to(torch.int64)
+        top = int(idx.max()) if idx.numel() else 0
+        if top >= len(self.time_table):  # envs stepped past the timeout without a reset: grow the table
+            self.time_table = host_init.time_table(self.params.dt, 2 * top)
+            self._time_table_dev = torch.from_numpy(self.time_table).to(self.device)
         return self._time_table_dev[idx]
 
     # ------------------------------------------------------------------ reference API

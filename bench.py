@@ -38,10 +38,12 @@ def make_env(n, device, env_id_base, seed):
     return env, g
 
 
-def cpu_baseline(g, envs, steps):
-    """The oracle (C restatement, kind "port") on the host cores of this box, same workload, bounded sample."""
+def cpu_baseline(g, envs=16384, budget_s=12.0):
+    """The oracle (C restatement, kind "port") on the host cores of this box: same workload, bounded sample
+    (about `budget_s` seconds of wall time on at most 16 threads, the CPU share of a one-GPU box)."""
     import oracle
-    threads = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(16, avail))
     p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE, spatial_precision=0.2, angular_precision=np.pi / 8)
     ref = oracle.OracleBatch(p, envs, g["costmap"], g["origin"], float(g["resolution"]), g["path"])
     ref.reset_from_paths()
@@ -50,14 +52,20 @@ def cpu_baseline(g, envs, steps):
     hi = np.array([np.pi / 6, np.pi / 2])
     acts = [rng.uniform(lo, hi, (envs, 2)).astype(np.float32).astype(np.float64) for _ in range(4)]
     zs = [rng.standard_normal((envs, 3)) for _ in range(4)]
-    for k in range(3):
+    for k in range(20):  # de-synchronise the replicas as the GPU warm-up does
         ref.step(acts[k % 4], zs[k % 4], auto_reset=True, threads=threads)
+    steps = 0
     t0 = time.perf_counter()
-    for k in range(steps):
-        ref.step(acts[k % 4], zs[k % 4], auto_reset=True, threads=threads)
-    dt = time.perf_counter() - t0
+    while True:
+        for k in range(10):
+            ref.step(acts[(steps + k) % 4], zs[(steps + k) % 4], auto_reset=True, threads=threads)
+        steps += 10
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or steps >= 2000:
+            break
     return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": "%d envs x %d steps of the same workload (C oracle, %d threads, %.1f s)" % (envs, steps, threads, dt)}
+            "sample": "%d envs x %d steps of the same workload (C oracle restatement, %d threads, %.1f s)"
+                      % (envs, steps, threads, dt)}
 
 
 def main():
@@ -143,7 +151,7 @@ def main():
                          "note": "shared-map config is ALU/latency-bound (SURVEY 8d): HBM fraction is low by construction"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(g, 8192, 40)
+            out["cpu_baseline"] = cpu_baseline(g)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

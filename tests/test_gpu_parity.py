@@ -186,6 +186,15 @@ def _random_batch(oracle, rng, n, g, name):
     st[3] = rng.uniform(0, 0.5, n)
     st[4] = rng.uniform(-0.5, 0.5, n)
     st[6] = rng.uniform(-1.0, 1.0, n)
+    # a third of the robots start next to a lethal cell, so that collisions (and rollbacks) really happen
+    ly, lx = np.nonzero(g["costmap"] == 254)
+    near = rng.rand(n) < 0.33
+    pick = rng.randint(0, len(ly), n)
+    res = float(g["resolution"])
+    ang = rng.uniform(-np.pi, np.pi, n)
+    rad = rng.uniform(0.3, 1.0, n)
+    st[0] = np.where(near, g["origin"][0] + lx[pick] * res + rad * np.cos(ang), st[0])
+    st[1] = np.where(near, g["origin"][1] + ly[pick] * res + rad * np.sin(ang), st[1])
     tgt = np.clip(idx + rng.randint(-3, 4, n), 1, len(path) - 1).astype(np.int32)
     md = np.hypot(path[tgt, 0] - st[0], path[tgt, 1] - st[1]) + rng.uniform(-0.01, 0.05, n)
     it = rng.randint(0, 1200, n).astype(np.int32)
@@ -393,7 +402,7 @@ def test_full_size_properties_65536(torch_cuda, oracle):
         np.testing.assert_array_equal(env.state.target_idx.cpu().numpy()[sample], ref.target_idx)
         np.testing.assert_allclose(rob[:, sample], np.stack(ref.st), rtol=0, atol=ATOL)
         np.testing.assert_allclose(env.reward.cpu().numpy()[sample], ref.reward, rtol=0, atol=ATOL)
-    assert prev_coll.sum() > 1000
+    assert prev_coll.sum() > 1000, prev_coll.sum()
 
 
 def test_reset_and_state_roundtrip(torch_cuda):
