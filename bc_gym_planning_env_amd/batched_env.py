@@ -392,6 +392,7 @@ class BatchedPlanEnv(object):
         io = _lib.BcpStepIO()
         io.actions = a.data_ptr()
         flags = (_lib.STEP_ACTIONS_F32 if a.dtype == torch.float32 else 0) | (_lib.STEP_AUTO_RESET if self.auto_reset else 0)
+        flags |= getattr(self, "_debug_flags", 0)
         if noise_z is not None:
             io.noise_z = noise_z.data_ptr()
         io.reward, io.done = self.reward.data_ptr(), self.done.data_ptr()

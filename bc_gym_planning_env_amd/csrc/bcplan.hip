@@ -202,7 +202,7 @@ struct StepArgs {
     int64_t env_id_base;
 };
 
-// dynamic LDS: [bitmap words (when staged)] [edge table: n_verts * 3 * kBlock words]
+// dynamic LDS: [bitmap words (when staged)] [vertex scratch: n_verts * 2 * kBlock words]
 extern __shared__ uint32_t lds_dyn[];
 
 __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     uint32_t* lds_bits = lds_dyn;
     const int map_words = a.map.in_lds ? a.map.rows * a.map.wpr : 0;
     for (int k = tid; k < map_words; k += kBlock) lds_bits[k] = a.map.bits[k];
-    EdgeLds E;
+    VertLds E;
     E.base = lds_dyn + map_words + tid;
     E.stride = kBlock;
     __syncthreads();
@@ -272,8 +272,9 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
         X.ox = a.map.ox;
         X.oy = a.map.oy;
     }
-    bool hit;
-    if (a.map.in_lds) {
+    bool hit = false;
+    if (a.flags & (1u << 16)) {
+    } else if (a.map.in_lds) {
         hit = pose_collides(P, r.p.x, r.p.y, r.p.th, X, (const uint32_t*)lds_bits, a.map.rows, a.map.cols, a.map.wpr, E);
     } else {
         const uint32_t* bits = a.map.bits + (a.map.shared ? 0 : i * a.map.env_stride);
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     // ---- reward / done (env.py:352, :407-419)
     const double* path = a.path.pts + (a.path.shared ? 0 : i * (int64_t)a.path.max_len * 5);
     const int m = a.path.shared ? a.path.max_len : a.path.lens[i];
-    const double rew = reward_step(P, path, m, r.p.x, r.p.y, r.p.th, min_dist, target);
+    const double rew = (a.flags & (1u << 17)) ? 0.0 : reward_step(P, path, m, r.p.x, r.p.y, r.p.th, min_dist, target);
     const bool done = (target > m - 1) || (iter >= P.iteration_timeout) || collided;
 
     a.reward[i] = rew;
@@ -394,7 +395,7 @@ __global__ void __launch_bounds__(kBlock) pose_collides_kernel(DevParams P, MapD
 {
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kBlock + tid;
-    EdgeLds E;
+    VertLds E;
     E.base = lds_dyn + tid;
     E.stride = kBlock;
     if (i >= n) return;
@@ -410,19 +411,15 @@ __global__ void __launch_bounds__(kBlock) pose_collides_kernel(DevParams P, MapD
 
 struct MaskSink {
     uint8_t* img;
-    int side;
-    int32_t* shape;
-    __device__ __forceinline__ void begin(int hx, int hy)
+    int side, hx, hy;
+    __device__ __forceinline__ bool span(int v, int ua, int ub) const
     {
-        shape[0] = 2 * hy + 1;
-        shape[1] = 2 * hx + 1;
-    }
-    __device__ __forceinline__ bool emit(int y, int xa, int xb) const
-    {
+        const int y = v + hy;
         if ((unsigned)y < (unsigned)side)
-            for (int x = max(xa, 0); x <= min(xb, side - 1); ++x) img[y * side + x] = 255;
+            for (int x = max(ua + hx, 0); x <= min(ub + hx, side - 1); ++x) img[y * side + x] = 255;
         return false;
     }
+    __device__ __forceinline__ bool pixel(int v, int u) const { return span(v, u, u); }
 };
 
 __global__ void __launch_bounds__(kBlock) pixel_footprint_kernel(DevParams P, const double* __restrict__ angles, int64_t n,
@@ -431,15 +428,18 @@ __global__ void __launch_bounds__(kBlock) pixel_footprint_kernel(DevParams P, co
 {
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kBlock + tid;
-    EdgeLds E;
+    VertLds E;
     E.base = lds_dyn + tid;
     E.stride = kBlock;
     if (i >= n) return;
     MaskSink sink;
     sink.img = masks + i * (int64_t)side * side;
     sink.side = side;
-    sink.shape = shape_hw + 2 * i;
-    raster_footprint(P, angles[i], E, sink);
+    const double c = cos(angles[i]), s = sin(angles[i]);
+    footprint_half_sizes(P, c, s, sink.hx, sink.hy);
+    shape_hw[2 * i] = 2 * sink.hy + 1;
+    shape_hw[2 * i + 1] = 2 * sink.hx + 1;
+    raster_runs(P, c, s, E, sink);
 }
 
 __global__ void normalize_angle_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n)
@@ -499,7 +499,7 @@ static int check_kernel_size(const bcp_params& p, double res)
     return std::sqrt(r2) / res + 2.0 <= BCP_MAX_KERNEL_HALF;
 }
 
-static size_t edge_lds_bytes(const bcp_handle* h) { return (size_t)h->params.n_verts * 3 * kBlock * sizeof(uint32_t); }
+static size_t edge_lds_bytes(const bcp_handle* h) { return (size_t)h->params.n_verts * 2 * kBlock * sizeof(uint32_t); }
 
 extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, int64_t env_id_base, bcp_handle** out)
 {
