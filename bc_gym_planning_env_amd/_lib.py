@@ -11,6 +11,7 @@ MAX_VERTS = 32
 MODEL_TRICYCLE, MODEL_DIFFDRIVE = 0, 1
 STEP_AUTO_RESET, STEP_ACTIONS_F32 = 1, 2
 ERR_ANGLE_JUMP = 1
+TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL = 0, 1, 2
 E_NO_DEVICE = -2
 
 _f64p = C.POINTER(C.c_double)
@@ -56,6 +57,7 @@ SYMBOLS = {
     "bcp_create": (C.c_int, [C.POINTER(BcpParams), C.c_int64, C.c_int, C.c_int64, C.POINTER(_H)]),
     "bcp_destroy": (C.c_int, [_H]),
     "bcp_seed": (C.c_int, [_H, C.c_uint64]),
+    "bcp_set_tuning": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "bcp_set_costmaps": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
     "bcp_set_paths": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

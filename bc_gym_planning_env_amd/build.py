@@ -4,8 +4,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bcplan.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "bcp_device.h"), os.path.join(HERE, "csrc", "bcp_raster.h"),
-        os.path.join(os.path.dirname(HERE), "include", "bcplan.h")]
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("bcp_device.h", "bcp_raster.h", "bcp_coop.h")] + \
+       [os.path.join(os.path.dirname(HERE), "include", "bcplan.h")]
 OUT = os.path.join(HERE, "libbcplan.so")
 
 # -ffp-contract=off: numpy rounds every product and sum on its own; hipcc's default would fuse them into FMAs.

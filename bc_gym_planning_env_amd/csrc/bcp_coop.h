@@ -1,0 +1,247 @@
+// bcp_coop.h -- wave-cooperative exact footprint test and the distance-field pre-classification.
+//
+// 1. classify(): a per-env O(1) test that settles most poses without rasterising anything.  It reads a Euclidean
+//    distance transform of the lethal cells (uint8 floor of the distance in pixels, built once per costmap) at a
+//    few sample points on the robot's long axis:
+//      * every footprint pixel lies within R_out of some OUTER sample  -> all samples farther than R_out from any
+//        lethal cell  => no collision;
+//      * a disc of radius R_in around an INNER sample lies inside the filled footprint -> a lethal cell closer than
+//        that => collision.
+//    The radii carry the worst-case pixel slack of the reference pipeline (vertex rounding 0.7071 px, Bresenham
+//    0.5 px, 16.16 truncation, sample-centre rounding 0.7071 px), so both verdicts are provably what the exact test
+//    would return; everything else is AMBIGUOUS and goes to 2.
+// 2. coop_collides(): the exact test for ONE pose executed by all 64 lanes of a wave: lane = mask row, loop over
+//    polygon edges with the edge parameters broadcast from the lane that owns the edge.  Row coverage is built as
+//    bit masks:  OUTLINE runs are OR-ed in,  SPANS use the parity form of the even-odd scanline
+//        x is inside a span   <=>   #{active edges with x_e < x} is odd   (or x == x_e, which is an OUTLINE pixel)
+//    i.e. XOR of suffix masks starting at floor(x_e) + 1 -- no sorting, any contour.
+#pragma once
+
+#include "bcp_raster.h"
+
+namespace bcp {
+
+constexpr int kMaxSamples = 8;
+
+// distance-field description (kernel argument)
+struct CullDesc {
+    const uint8_t* edt;   // [(rows + 2 pad) * (cols + 2 pad)] floor(min(255, distance to nearest lethal cell))
+    int32_t on;           // 0: no distance field (per-env maps) -> every in-map pose is AMBIGUOUS
+    int32_t pad, width;   // padding on each side, padded row width
+    int32_t reach;        // any footprint pixel is within `reach` px of the robot pixel (off-map test)
+    int32_t n_out, n_in;
+    int32_t t_out;        // free  <=>  edt >= t_out at every outer sample
+    int32_t t_in[kMaxSamples];   // hit <=  edt <= t_in[j] at inner sample j
+    double out_x[kMaxSamples], in_x[kMaxSamples];  // sample abscissae on the robot axis, in pixels
+    double axis_y;        // ordinate of the sample axis in the robot frame, in pixels
+};
+
+enum { kFree = 0, kHit = 1, kAmbiguous = 2 };
+
+__device__ __forceinline__ int classify(const CullDesc& C, int rows, int cols, int px, int py, double c, double s)
+{
+    // the whole kernel image misses the map -> nothing to collide with (env.py:483-484 drops off-map cells)
+    if (px + C.reach < 0 || px - C.reach >= cols || py + C.reach < 0 || py - C.reach >= rows) return kFree;
+    if (!C.on) return kAmbiguous;
+    const double ay_c = C.axis_y * c, ay_s = C.axis_y * s;
+    const uint8_t* base = C.edt + (int64_t)(py + C.pad) * C.width + (px + C.pad);
+    bool all_far = true;
+    for (int i = 0; i < C.n_out; ++i) {
+        const int du = (int)rint(C.out_x[i] * c - ay_s), dv = (int)rint(C.out_x[i] * s + ay_c);
+        all_far = all_far && (int)base[dv * C.width + du] >= C.t_out;
+    }
+    if (all_far) return kFree;
+    bool hit = false;
+    for (int j = 0; j < C.n_in; ++j) {
+        const int du = (int)rint(C.in_x[j] * c - ay_s), dv = (int)rint(C.in_x[j] * s + ay_c);
+        hit = hit || (int)base[dv * C.width + du] <= C.t_in[j];
+    }
+    return hit ? kHit : kAmbiguous;
+}
+
+// ---- wave helpers -------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+
+__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+__device__ __forceinline__ double bcast_d(double v, int src)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+// bits [pos, 32*NW) of an NW-word row mask, word w
+__device__ __forceinline__ uint32_t suffix_word(int pos, int w)
+{
+    const int rel = pos - 32 * w;
+    return rel <= 0 ? 0xFFFFFFFFu : (rel >= 32 ? 0u : 0xFFFFFFFFu << rel);
+}
+
+// Per-lane description of edge l = (V[l-1] -> V[l]); lanes >= K hold an inert edge.
+struct EdgeRegs {
+    int y0, y1;        // span activity y0 <= y < y1 (y0 == y1: horizontal, never active)
+    int x0fp, dxfp;    // 16.16 x at y0 and slope (CollectPolyEdges)
+    int sx, sy;        // Bresenham start point (end with the smaller x)
+    int dx, dy;        // |dx|, |dy| after the left-to-right normalisation
+    int ystep;         // +1 / -1
+    uint32_t inv;      // floor(2^32 / D) + 1 with D = 2*dy: floor(n / D) == umulhi(n, inv) for n * D < 2^32
+};
+
+// Row coverage sink of the cooperative rasteriser: called once per 64-row chunk with each lane's row masks.
+//   bool rows(int y /*this lane's centred row*/, bool valid, const uint32_t cover[NW], int ubase /*centred u of bit 0*/)
+// returns a wave-uniform "stop".
+template <int NW, typename RowSink>
+__device__ __forceinline__ bool coop_raster(const DevParams& P, LdsF64 qverts_lds, double c, double s, RowSink& sink)
+{
+    const int K = P.n_verts;
+    const int lane = lane_id();
+    // ---- lane k < K owns vertex k and edge k
+    int u = 0, v = 0;
+    if (lane < K) {
+        const double qx = qverts_lds[2 * lane], qy = qverts_lds[2 * lane + 1];
+        u = (int)rint(fma(qy, -s, qx * c));   // path_tools.py:142-150
+        v = (int)rint(fma(qy, c, qx * s));
+    }
+    const int prev = lane == 0 ? K - 1 : lane - 1;
+    const int up = __shfl(u, prev), vp = __shfl(v, prev);
+    const bool owner = lane < K;
+    const int vmin = wave_min_i(owner ? v : 0x7fffffff), vmax = wave_max_i(owner ? v : -0x7fffffff);
+    const int umin = wave_min_i(owner ? u : 0x7fffffff);
+    EdgeRegs E;
+    {
+        // span edge (CollectPolyEdges): top = end with the smaller y
+        const int ddy = v - vp;
+        E.y0 = min(v, vp);
+        E.y1 = owner ? max(v, vp) : E.y0;
+        E.x0fp = (vp < v ? up : u) << 16;
+        E.dxfp = ddy != 0 ? ((u - up) * 65536) / ddy : 0;
+        // Bresenham (LineIterator, leftToRight): start from the end with the smaller x
+        int sx = up, sy = vp, dx = u - up, dy = v - vp;
+        if (dx < 0) {
+            dx = -dx;
+            dy = -dy;
+            sx = u;
+            sy = v;
+        }
+        E.ystep = 1;
+        if (dy < 0) {
+            dy = -dy;
+            E.ystep = -1;
+        }
+        E.sx = sx;
+        E.sy = sy;
+        E.dx = dx;
+        E.dy = owner ? dy : -1;  // dy < 0: inert
+        const uint32_t D = 2u * (uint32_t)(dy > 0 ? dy : 1);
+        E.inv = (uint32_t)(0x100000000ull / D) + 1u;
+    }
+    const int ubase = umin;  // bit 0 of the row masks <-> centred column umin
+
+    for (int ybase = vmin; ybase <= vmax; ybase += 64) {
+        const int y = ybase + lane;
+        const bool valid = y <= vmax;
+        uint32_t cov_or[NW], cov_xor[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) cov_or[w] = cov_xor[w] = 0;
+        for (int e = 0; e < K; ++e) {
+            const int ey0 = bcast_i(E.y0, e), ey1 = bcast_i(E.y1, e);
+            const int sy = bcast_i(E.sy, e), sx = bcast_i(E.sx, e);
+            const int dx = bcast_i(E.dx, e), dy = bcast_i(E.dy, e), ystep = bcast_i(E.ystep, e);
+            // SPANS: crossing of the active edge, parity mask starts one past floor(x_e)
+            if (y >= ey0 && y < ey1) {
+                const int xe = bcast_i(E.x0fp, e) + (y - ey0) * bcast_i(E.dxfp, e);
+                const int pos = (xe >> 16) + 1 - ubase;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) cov_xor[w] ^= suffix_word(pos, w);
+            }
+            // OUTLINE: the run of this edge on row y (i = |y - sy| steps along the minor / major axis)
+            const int i = (y - sy) * ystep;
+            if (i >= 0 && i <= dy) {
+                int lo, hi;
+                if (dy > dx) {         // y-major: x = sx + floor((2*dx*i + dy - 1) / (2*dy))
+                    lo = hi = sx + (int)__umulhi((uint32_t)(2 * dx * i + dy - 1), bcast_i((int)E.inv, e));
+                } else if (dy == 0) {  // horizontal edge / single point
+                    lo = sx;
+                    hi = sx + dx;
+                } else {               // x-major: steps floor((2*dx*(i-1)+dx)/(2*dy)) + 1 .. min(dx, floor((2*dx*i+dx)/(2*dy)))
+                    const uint32_t inv = (uint32_t)bcast_i((int)E.inv, e);
+                    const int qhi = (int)__umulhi((uint32_t)(2 * dx * i + dx), inv);
+                    const int qlo = i == 0 ? -1 : (int)__umulhi((uint32_t)(2 * dx * (i - 1) + dx), inv);
+                    lo = sx + qlo + 1;
+                    hi = sx + (qhi > dx ? dx : qhi);
+                }
+                const int p0 = lo - ubase, p1 = hi + 1 - ubase;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) cov_or[w] |= suffix_word(p0, w) & ~suffix_word(p1, w);
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) cov_or[w] |= cov_xor[w];
+        if (sink.rows(y, valid, cov_or, ubase)) return true;
+    }
+    return false;
+}
+
+// Row sink testing coverage against the lethal bitmap (pose_collides, env.py:464-489)
+template <int NW, typename WordPtr>
+struct CoopCollisionSink {
+    WordPtr words;
+    int n_rows, n_cols, wpr, px, py;
+    __device__ __forceinline__ bool rows_hit(int y, bool valid, const uint32_t cover[NW], int ubase) const
+    {
+        const int r = py + y;
+        const int c0 = px + ubase;     // map column of mask bit 0
+        const int w0 = c0 >> 5;        // arithmetic shift: floor
+        const int sh = c0 & 31;
+        bool hit = false;
+        if (valid && (unsigned)r < (unsigned)n_rows) {
+            // lethal bits of columns c0 .. c0 + 32*NW - 1, re-aligned so that bit 0 <-> column c0
+            uint32_t lo = (unsigned)w0 < (unsigned)wpr ? words[r * wpr + w0] : 0u;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int wi = w0 + w + 1;
+                const uint32_t hiw = (unsigned)wi < (unsigned)wpr ? words[r * wpr + wi] : 0u;
+                const uint32_t leth = sh ? (lo >> sh) | (hiw << (32 - sh)) : lo;
+                hit = hit || (leth & cover[w]) != 0;
+                lo = hiw;
+            }
+        }
+        return hit;
+    }
+    __device__ __forceinline__ bool rows(int y, bool valid, const uint32_t cover[NW], int ubase) const
+    {
+        return __any(rows_hit(y, valid, cover, ubase));
+    }
+};
+
+// exact pose_collides for ONE pose, all 64 lanes cooperating; returns a wave-uniform verdict.
+// `wide`: the kernel image may be wider than 96 px (use the 8-word row masks).
+template <typename WordPtr>
+__device__ __forceinline__ bool coop_collides(const DevParams& P, LdsF64 qverts_lds, double c, double s, int px,
+                              int py, WordPtr words, int rows, int cols, int wpr, bool wide)
+{
+    if (!wide) {
+        CoopCollisionSink<3, WordPtr> sink{words, rows, cols, wpr, px, py};
+        return coop_raster<3>(P, qverts_lds, c, s, sink);
+    }
+    CoopCollisionSink<8, WordPtr> sink{words, rows, cols, wpr, px, py};
+    return coop_raster<8>(P, qverts_lds, c, s, sink);
+}
+
+}  // namespace bcp

@@ -22,6 +22,7 @@ struct DevParams {
     double alpha[6];
     double sp, ap, progress_mult;
     double par_thr;          // -sp / 9, utilities/path_tools.py:423
+    double sp2_lo, sp2_hi;   // sp^2 (1 -+ 1e-13): dx^2+dy^2 outside this band decides hypot(dx,dy) < sp on its own
     double sp_prune;         // sp nudged up two ulps: |dx| > sp_prune  =>  hypot(dx,dy) >= sp for any faithful hypot
     double qverts[BCP_MAX_VERTS][2];  // footprint / resolution (path_tools.py:145), divided on the host in fp64
 };
@@ -38,8 +39,27 @@ __device__ __forceinline__ double py_mod(double a, double b)
     return r;
 }
 
+// a % (2 pi) with numpy semantics.  fmod is exact (a - k*b is representable); for |a| < 2b it is a itself or one
+// exact subtraction / addition (Sterbenz), so the library call is only needed for far-out arguments.
+__device__ __forceinline__ double py_mod_two_pi(double a)
+{
+    const double b = kTwoPi;
+    double r;
+    if (a >= 0.0) {
+        r = a < b ? a : (a < 2.0 * b ? a - b : fmod(a, b));
+    } else {
+        r = a > -b ? a : (a > -2.0 * b ? a + b : fmod(a, b));
+    }
+    if (r != 0.0) {
+        if (r < 0.0) r += b;
+    } else {
+        r = 0.0;
+    }
+    return r;
+}
+
 // utilities/coordinate_transformations.py:28-36
-__device__ __forceinline__ double normalize_angle(double z) { return py_mod(z + kPi, kTwoPi) - kPi; }
+__device__ __forceinline__ double normalize_angle(double z) { return py_mod_two_pi(z + kPi) - kPi; }
 
 // np.clip == minimum(maximum(a, lo), hi)
 __device__ __forceinline__ double clipd(double a, double lo, double hi)

@@ -27,8 +27,13 @@ struct MapXform {
 
 // Per-thread scratch in LDS: 2 words per footprint vertex, laid out [word][vertex][thread] so that the lanes of a
 // wave hit consecutive banks.
+// LDS pointers keep their address space in the type: every access is a ds_* instruction, never a flat one.
+typedef __attribute__((address_space(3))) uint32_t* LdsU32;
+typedef const __attribute__((address_space(3))) uint32_t* LdsWords;
+typedef const __attribute__((address_space(3))) double* LdsF64;
+
 struct VertLds {
-    uint32_t* base;  // this thread's column
+    LdsU32 base;     // this thread's column
     int stride;      // threads per block
     __device__ __forceinline__ void put_vertex(int k, int u, int v) const
     {
@@ -113,7 +118,7 @@ __device__ __forceinline__ bool outline_edge(int x0, int y0, int x1, int y1, Sin
 //   sink.pixel(v, u) / sink.span(v, ua, ub) -> bool   (return true to stop early)
 // Runs may overlap; their union is exactly the pixel set cv2.fillPoly writes.  Returns true if stopped.
 template <typename Sink>
-__device__ bool raster_runs(const DevParams& P, double c, double s, const VertLds& L, Sink& sink)
+__device__ __forceinline__ bool raster_runs(const DevParams& P, double c, double s, const VertLds& L, Sink& sink)
 {
     const int K = P.n_verts;
     // ---- integer vertices (path_tools.py:150), OUTLINE, slopes, monotone-chain analysis

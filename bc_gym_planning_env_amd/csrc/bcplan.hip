@@ -9,11 +9,14 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "bcp_device.h"
 #include "bcp_raster.h"
+#include "bcp_coop.h"
 
 using namespace bcp;
 
@@ -56,7 +59,8 @@ struct MapDesc {
 };
 
 struct PathDesc {
-    const double* pts;  // [len][5] = x, y, theta, cos(theta), sin(theta); shared or [N][max_len][5]
+    const double* pts;   // [len][5] = x, y, theta, cos(theta), sin(theta); shared or [N][max_len][5]
+    const double* bbox;  // [4] = xmin, xmax, ymin, ymax of the way points; shared or [N][4]
     const int32_t* lens;
     int32_t max_len, shared;
 };
@@ -75,9 +79,20 @@ struct bcp_handle {
     size_t bitmap_bytes;
     double* path5;         // owned
     size_t path5_bytes;
+    double* path_bbox;     // owned
+    size_t path_bbox_bytes;
+    uint8_t* edt;          // owned: distance transform of the shared costmap (padded)
+    size_t edt_bytes;
+    int32_t* edt_col;      // owned scratch of the transform
+    size_t edt_col_bytes;
     MapDesc map;
+    CullDesc cull;
     PathDesc path;
     DevState st, init;
+    int32_t exact_mode;       // 0 auto, 1 cooperative only, 2 per-thread only
+    int32_t dense_threshold;  // auto: more ambiguous lanes than this in a wave -> per-thread rasteriser
+    int32_t cull_enabled;
+    int32_t wide;             // kernel image may exceed 96 px: 8-word row masks in the cooperative path
 };
 
 static DevState to_dev_state(const bcp_state* s)
@@ -139,31 +154,76 @@ __global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restr
     }
 }
 
+// bounding box of each path's way points: one thread per path
+__global__ void path_bbox_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
+                                 int64_t n_paths, double* __restrict__ bbox)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_paths) return;
+    const int m = lens ? lens[p] : max_len;
+    const double* q = xyt + p * (int64_t)max_len * 3;
+    double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    for (int j = 0; j < m; ++j) {
+        x0 = fmin(x0, q[3 * j]);
+        x1 = fmax(x1, q[3 * j]);
+        y0 = fmin(y0, q[3 * j + 1]);
+        y1 = fmax(y1, q[3 * j + 1]);
+    }
+    bbox[4 * p + 0] = x0;
+    bbox[4 * p + 1] = x1;
+    bbox[4 * p + 2] = y0;
+    bbox[4 * p + 3] = y1;
+}
+
 // find_last_reached restricted to j >= target (utilities/path_tools.py:408-448): the reward only asks whether the
 // LAST reached index is >= target_idx (envs/base/reward.py:234), so indices below target never matter.
-__device__ __forceinline__ int last_reached_from(const DevParams& P, const double* __restrict__ path, int m, int target,
+// The loop index is kept wave-uniform (every lane walks the same j) so that a shared path is read through the
+// scalar cache; lanes that are finished, or whose target lies above j, simply sit the iteration out.
+__device__ __forceinline__ int last_reached_from(const DevParams& P, const double* __restrict__ path,
+                                                 const double* __restrict__ bbox, int m, int m_loop, int target,
                                                  double x, double y, double th)
 {
-    for (int j = m - 1; j >= target; --j) {
-        const double* s = path + 5 * j;
-        const double dx = s[0] - x, dy = s[1] - y;
-        if (fabs(dx) > P.sp_prune || fabs(dy) > P.sp_prune) continue;  // then hypot(dx,dy) >= sp
-        const double dist = hypot(dx, dy);
-        if (!(dist < P.sp)) continue;
-        const double ang = fabs(normalize_angle(th - s[2]));
-        if (!(ang < P.ap)) continue;
-        const double par = s[3] * (x - s[0]) + s[4] * (y - s[1]);
-        if (par >= P.par_thr) return j;
+    // no way point can be within spatial_precision of a pose that far outside the path's bounding box
+    bool open = target <= m - 1 && !(x < bbox[0] - P.sp_prune || x > bbox[1] + P.sp_prune ||
+                                     y < bbox[2] - P.sp_prune || y > bbox[3] + P.sp_prune);
+    int found = -1;
+    for (int j = m_loop - 1; j >= 0; --j) {
+        if (!__any(open)) break;
+        if (open && j < m) {
+            if (j < target) {
+                open = false;
+            } else {
+                const double* s = path + 5 * j;
+                const double dx = s[0] - x, dy = s[1] - y;
+                // the three reach conditions are independent predicates; evaluate the cheap ones first
+                if (!(fabs(dx) > P.sp_prune || fabs(dy) > P.sp_prune)) {  // else hypot(dx,dy) >= sp
+                    const double par = s[3] * (x - s[0]) + s[4] * (y - s[1]);   // path_tools.py:405
+                    if (par >= P.par_thr) {
+                        const double q = dx * dx + dy * dy;
+                        bool near = q < P.sp2_lo;
+                        if (!near && q <= P.sp2_hi) near = hypot(dx, dy) < P.sp;  // too close to call from q
+                        if (near) {
+                            const double ang = fabs(normalize_angle(th - s[2]));
+                            if (ang < P.ap) {
+                                found = j;
+                                open = false;
+                            }
+                        }
+                    }
+                }
+            }
+        }
     }
-    return -1;
+    return found;
 }
 
 // ContinuousRewardProvider.reward (envs/base/reward.py:214-259)
-__device__ __forceinline__ double reward_step(const DevParams& P, const double* __restrict__ path, int m, double x,
-                                              double y, double th, double& min_dist, int& target)
+__device__ __forceinline__ double reward_step(const DevParams& P, const double* __restrict__ path,
+                                              const double* __restrict__ bbox, int m, int m_loop, double x, double y,
+                                              double th, double& min_dist, int& target)
 {
+    const int last = last_reached_from(P, path, bbox, m, m_loop, target, x, y, th);  // every lane joins the loop
     if (target > m - 1) return 0.0;
-    const int last = last_reached_from(P, path, m, target, x, y, th);
     if (last >= 0) {
         target = last + 1;
         if (!(target > m - 1)) {
@@ -187,6 +247,7 @@ __device__ __forceinline__ double reward_step(const DevParams& P, const double* 
 struct StepArgs {
     DevParams P;
     MapDesc map;
+    CullDesc cull;
     PathDesc path;
     DevState st, init;
     int64_t n;
@@ -198,29 +259,111 @@ struct StepArgs {
     uint8_t* collided_now;
     int32_t* err;
     uint32_t flags;
+    int32_t exact_mode, dense_threshold, wide;
     uint64_t seed, step_counter;
     int64_t env_id_base;
 };
 
-// dynamic LDS: [bitmap words (when staged)] [vertex scratch: n_verts * 2 * kBlock words]
+// dynamic LDS of the collision kernels:
+//   [lethal bitmap words (when the shared map is staged)] [qverts: n_verts * 2 doubles] [vertex scratch of the
+//   per-thread rasteriser: n_verts * 2 * kBlock words]
 extern __shared__ uint32_t lds_dyn[];
+
+struct CollisionLds {
+    bool staged;      // the shared lethal bitmap sits at LDS offset 0
+    LdsWords bits;
+    LdsF64 qverts;
+    VertLds scratch;
+};
+
+__device__ __forceinline__ CollisionLds collision_lds_setup(const DevParams& P, const MapDesc& map, int tid)
+{
+    CollisionLds L;
+    const int map_words = map.in_lds ? map.rows * map.wpr : 0;
+    const LdsU32 lds = (LdsU32)lds_dyn;
+    for (int k = tid; k < map_words; k += kBlock) lds[k] = map.bits[k];
+    const int q_off = (map_words + 1) & ~1;  // 8-byte alignment for the doubles
+    __attribute__((address_space(3))) double* q = (__attribute__((address_space(3))) double*)(lds + q_off);
+    for (int k = tid; k < 2 * P.n_verts; k += kBlock) q[k] = P.qverts[k >> 1][k & 1];
+    L.staged = map.in_lds != 0;
+    L.bits = lds;
+    L.qverts = q;
+    L.scratch.base = lds + q_off + 4 * P.n_verts + tid;
+    L.scratch.stride = kBlock;
+    __syncthreads();
+    return L;
+}
+
+static size_t collision_lds_bytes(int n_verts, int in_lds, int rows, int wpr)
+{
+    size_t words = in_lds ? (size_t)rows * wpr : 0;
+    words = (words + 1) & ~(size_t)1;
+    words += 4 * (size_t)n_verts;            // qverts (doubles)
+    words += 2 * (size_t)n_verts * kBlock;   // per-thread vertex scratch
+    return words * sizeof(uint32_t);
+}
+
+// pose_collides (envs/base/env.py:464-489) for the pose held by each lane.  EVERY lane of the wave must call this
+// (inactive lanes pass active = false): ambiguous poses are settled one at a time by the whole wave.
+__device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc& map, const CullDesc& cull,
+                                              const CollisionLds& L, int exact_mode, int dense_threshold, bool wide,
+                                              bool active, int64_t env, double x, double y, double th)
+{
+    double ox = map.ox, oy = map.oy;
+    if (map.origins) {
+        ox = map.origins[2 * env + 0];
+        oy = map.origins[2 * env + 1];
+    }
+    const int px = (int)rint((x - ox) * map.inv_res);   // world_to_pixel, coordinate_transformations.py:185-205
+    const int py = (int)rint((y - oy) * map.inv_res);
+    const double c = cos(th), s = sin(th);
+    int cls = active ? classify(cull, map.rows, map.cols, px, py, c, s) : kFree;
+    bool hit = cls == kHit;
+    uint64_t amb = __ballot(cls == kAmbiguous);
+    if (amb == 0) return hit;
+    const bool dense = exact_mode == 2 || (exact_mode == 0 && __popcll(amb) > dense_threshold);
+    if (dense) {
+        // many undecided lanes: one per-thread rasteriser pass settles them all at once
+        if (cls == kAmbiguous) {
+            if (L.staged) {
+                CollisionSink<LdsWords> sink{L.bits, map.rows, map.cols, map.wpr, px, py};
+                hit = raster_runs(P, c, s, L.scratch, sink);
+            } else {
+                const uint32_t* words = map.bits + (map.shared ? 0 : env * map.env_stride);
+                CollisionSink<const uint32_t*> sink{words, map.rows, map.cols, map.wpr, px, py};
+                hit = raster_runs(P, c, s, L.scratch, sink);
+            }
+        }
+        return hit;
+    }
+    // few undecided lanes: the wave rasterises them cooperatively, one pose at a time
+    while (amb) {
+        const int src = __ffsll((unsigned long long)amb) - 1;
+        amb &= amb - 1;
+        const double c_ = bcast_d(c, src), s_ = bcast_d(s, src);
+        const int px_ = bcast_i(px, src), py_ = bcast_i(py, src);
+        bool h;
+        if (L.staged) {
+            h = coop_collides(P, L.qverts, c_, s_, px_, py_, L.bits, map.rows, map.cols, map.wpr, wide);
+        } else {
+            const int64_t env_ = ((int64_t)bcast_i((int)(env >> 32), src) << 32) | (uint32_t)bcast_i((int)env, src);
+            const uint32_t* words = map.bits + (map.shared ? 0 : env_ * map.env_stride);
+            h = coop_collides(P, L.qverts, c_, s_, px_, py_, words, map.rows, map.cols, map.wpr, wide);
+        }
+        if (lane_id() == src) hit = h;
+    }
+    return hit;
+}
 
 __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
 {
     const DevParams& P = a.P;
     const int tid = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + tid;
-    const bool active = i < a.n;
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
+    const bool active = gi < a.n;
+    const int64_t i = active ? gi : a.n - 1;  // inactive lanes of the last wave shadow env n-1 and never store
 
-    // stage the shared lethal bitmap in LDS
-    uint32_t* lds_bits = lds_dyn;
-    const int map_words = a.map.in_lds ? a.map.rows * a.map.wpr : 0;
-    for (int k = tid; k < map_words; k += kBlock) lds_bits[k] = a.map.bits[k];
-    VertLds E;
-    E.base = lds_dyn + map_words + tid;
-    E.stride = kBlock;
-    __syncthreads();
-    if (!active) return;
+    const CollisionLds L = collision_lds_setup(P, a.map, tid);
 
     // ---- load state
     Robot r;
@@ -263,23 +406,10 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     int drawn = 0;
     const int err = robot_step(P, r, cmd0, cmd1, z, drawn);
 
-    MapXform X;
-    X.inv_res = a.map.inv_res;
-    if (a.map.origins) {
-        X.ox = a.map.origins[2 * i + 0];
-        X.oy = a.map.origins[2 * i + 1];
-    } else {
-        X.ox = a.map.ox;
-        X.oy = a.map.oy;
-    }
     bool hit = false;
-    if (a.flags & (1u << 16)) {
-    } else if (a.map.in_lds) {
-        hit = pose_collides(P, r.p.x, r.p.y, r.p.th, X, (const uint32_t*)lds_bits, a.map.rows, a.map.cols, a.map.wpr, E);
-    } else {
-        const uint32_t* bits = a.map.bits + (a.map.shared ? 0 : i * a.map.env_stride);
-        hit = pose_collides(P, r.p.x, r.p.y, r.p.th, X, bits, a.map.rows, a.map.cols, a.map.wpr, E);
-    }
+    if (!(a.flags & (1u << 16)))
+        hit = collides_wave(P, a.map, a.cull, L, a.exact_mode, a.dense_threshold, a.wide != 0, active, i, r.p.x, r.p.y,
+                            r.p.th);
     if (hit) {  // robot.set_pose(*old_position): pose restored, v = w = 0 (tricycle_model.py:471-476)
         r.p = old;
         r.v = 0.0;
@@ -290,10 +420,21 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     collided = collided || hit;
 
     // ---- reward / done (env.py:352, :407-419)
-    const double* path = a.path.pts + (a.path.shared ? 0 : i * (int64_t)a.path.max_len * 5);
-    const int m = a.path.shared ? a.path.max_len : a.path.lens[i];
-    const double rew = (a.flags & (1u << 17)) ? 0.0 : reward_step(P, path, m, r.p.x, r.p.y, r.p.th, min_dist, target);
+    // shared path: uniform pointers, read through the scalar cache; private paths: per-lane pointers
+    double rew = 0.0;
+    int m;
+    if (a.path.shared) {
+        m = a.path.max_len;
+        if (!(a.flags & (1u << 17)))
+            rew = reward_step(P, a.path.pts, a.path.bbox, m, m, r.p.x, r.p.y, r.p.th, min_dist, target);
+    } else {
+        m = a.path.lens[i];
+        if (!(a.flags & (1u << 17)))
+            rew = reward_step(P, a.path.pts + i * (int64_t)a.path.max_len * 5, a.path.bbox + i * 4, m, a.path.max_len,
+                              r.p.x, r.p.y, r.p.th, min_dist, target);
+    }
     const bool done = (target > m - 1) || (iter >= P.iteration_timeout) || collided;
+    if (!active) return;
 
     a.reward[i] = rew;
     a.done[i] = (uint8_t)done;
@@ -390,25 +531,62 @@ __global__ void __launch_bounds__(kBlock) robot_step_kernel(DevParams P, double*
     if (err) err[i] = e;
 }
 
-__global__ void __launch_bounds__(kBlock) pose_collides_kernel(DevParams P, MapDesc map, const double* __restrict__ poses,
-                                                               int64_t n, int64_t n_envs, uint8_t* __restrict__ out)
+__global__ void __launch_bounds__(kBlock) pose_collides_kernel(DevParams P, MapDesc map, CullDesc cull, int exact_mode,
+                                                               int dense_threshold, int wide,
+                                                               const double* __restrict__ poses, int64_t n, int64_t n_envs,
+                                                               uint8_t* __restrict__ out)
 {
     const int tid = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + tid;
-    VertLds E;
-    E.base = lds_dyn + tid;
-    E.stride = kBlock;
-    if (i >= n) return;
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
+    const bool active = gi < n;
+    const int64_t i = active ? gi : n - 1;
+    const CollisionLds L = collision_lds_setup(P, map, tid);
     const int64_t env = i % n_envs;
-    MapXform X;
-    X.inv_res = map.inv_res;
-    X.ox = map.origins ? map.origins[2 * env] : map.ox;
-    X.oy = map.origins ? map.origins[2 * env + 1] : map.oy;
-    const uint32_t* bits = map.bits + (map.shared ? 0 : env * map.env_stride);
-    out[i] = (uint8_t)pose_collides(P, poses[3 * i], poses[3 * i + 1], poses[3 * i + 2], X, bits, map.rows, map.cols,
-                                    map.wpr, E);
+    const bool hit = collides_wave(P, map, cull, L, exact_mode, dense_threshold, wide != 0, active, env, poses[3 * i],
+                                   poses[3 * i + 1], poses[3 * i + 2]);
+    if (active) out[i] = (uint8_t)hit;
 }
 
+// get_pixel_footprint: one wave per angle, rasterised by the cooperative path; lane = image row
+struct MaskRowSink {
+    uint8_t* img;
+    int side, hx, hy;
+    __device__ __forceinline__ bool rows(int y, bool valid, const uint32_t cover[8], int ubase) const
+    {
+        const int ky = y + hy;
+        if (valid && (unsigned)ky < (unsigned)side) {
+            for (int b = 0; b < 256; ++b) {
+                const int kx = ubase + b + hx;
+                if ((cover[b >> 5] >> (b & 31)) & 1u)
+                    if ((unsigned)kx < (unsigned)side) img[ky * side + kx] = 255;
+            }
+        }
+        return false;
+    }
+};
+
+__global__ void __launch_bounds__(kBlock) pixel_footprint_kernel(DevParams P, const double* __restrict__ angles, int64_t n,
+                                                                 uint8_t* __restrict__ masks, int side,
+                                                                 int32_t* __restrict__ shape_hw)
+{
+    const int tid = threadIdx.x;
+    __attribute__((address_space(3))) double* q = (__attribute__((address_space(3))) double*)lds_dyn;
+    for (int k = tid; k < 2 * P.n_verts; k += kBlock) q[k] = P.qverts[k >> 1][k & 1];
+    __syncthreads();
+    const int64_t i = blockIdx.x;
+    const double c = cos(angles[i]), s = sin(angles[i]);
+    MaskRowSink sink;
+    sink.img = masks + i * (int64_t)side * side;
+    sink.side = side;
+    footprint_half_sizes(P, c, s, sink.hx, sink.hy);
+    if (tid == 0) {
+        shape_hw[2 * i] = 2 * sink.hy + 1;
+        shape_hw[2 * i + 1] = 2 * sink.hx + 1;
+    }
+    coop_raster<8>(P, q, c, s, sink);
+}
+
+// same image through the per-thread rasteriser (one thread per angle): cross-checks the two exact paths
 struct MaskSink {
     uint8_t* img;
     int side, hx, hy;
@@ -422,14 +600,14 @@ struct MaskSink {
     __device__ __forceinline__ bool pixel(int v, int u) const { return span(v, u, u); }
 };
 
-__global__ void __launch_bounds__(kBlock) pixel_footprint_kernel(DevParams P, const double* __restrict__ angles, int64_t n,
-                                                                 uint8_t* __restrict__ masks, int side,
-                                                                 int32_t* __restrict__ shape_hw)
+__global__ void __launch_bounds__(kBlock) pixel_footprint_thread_kernel(DevParams P, const double* __restrict__ angles,
+                                                                        int64_t n, uint8_t* __restrict__ masks, int side,
+                                                                        int32_t* __restrict__ shape_hw)
 {
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kBlock + tid;
     VertLds E;
-    E.base = lds_dyn + tid;
+    E.base = (LdsU32)lds_dyn + tid;
     E.stride = kBlock;
     if (i >= n) return;
     MaskSink sink;
@@ -440,6 +618,58 @@ __global__ void __launch_bounds__(kBlock) pixel_footprint_kernel(DevParams P, co
     shape_hw[2 * i] = 2 * sink.hy + 1;
     shape_hw[2 * i + 1] = 2 * sink.hx + 1;
     raster_runs(P, c, s, E, sink);
+}
+
+// ---- Euclidean distance transform of the lethal cells over the padded map (classify(), bcp_coop.h) -------------
+// pass 1: per padded column, vertical distance to the nearest lethal cell of that column (INF if none)
+__global__ void edt_columns_kernel(const uint32_t* __restrict__ bits, int rows, int cols, int wpr, int pad,
+                                   int32_t* __restrict__ g)
+{
+    const int W = cols + 2 * pad, H = rows + 2 * pad;
+    const int cp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cp >= W) return;
+    const int c = cp - pad;
+    const int INF = 1 << 20;
+    const bool in_cols = c >= 0 && c < cols;
+    int d = INF;
+    for (int rp = 0; rp < H; ++rp) {  // downward sweep
+        const int r = rp - pad;
+        const bool leth = in_cols && r >= 0 && r < rows && ((bits[r * wpr + (c >> 5)] >> (c & 31)) & 1u);
+        d = leth ? 0 : (d >= INF ? INF : d + 1);
+        g[rp * W + cp] = d;
+    }
+    d = INF;
+    for (int rp = H - 1; rp >= 0; --rp) {  // upward sweep
+        const int r = rp - pad;
+        const bool leth = in_cols && r >= 0 && r < rows && ((bits[r * wpr + (c >> 5)] >> (c & 31)) & 1u);
+        d = leth ? 0 : (d >= INF ? INF : d + 1);
+        g[rp * W + cp] = min(g[rp * W + cp], d);
+    }
+}
+
+// pass 2: d^2(r,c) = min over c' of (c - c')^2 + g(r,c')^2, stored as floor(min(255, d)).  Only |c - c'| <= 255 can
+// yield a distance below the clamp.
+__global__ void edt_rows_kernel(const int32_t* __restrict__ g, int W, int H, uint8_t* __restrict__ out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)W * H) return;
+    const int cp = (int)(idx % W), rp = (int)(idx / W);
+    const int32_t* row = g + (int64_t)rp * W;
+    int64_t best = (int64_t)255 * 255 + 1;
+    const int lo = max(0, cp - 255), hi = min(W - 1, cp + 255);
+    for (int k = lo; k <= hi; ++k) {
+        const int64_t gv = row[k];
+        if (gv > 255) continue;
+        const int64_t dd = (int64_t)(cp - k) * (cp - k) + gv * gv;
+        best = dd < best ? dd : best;
+    }
+    int sq = 255;
+    if (best <= (int64_t)255 * 255) {
+        sq = (int)sqrt((double)best);
+        while ((int64_t)sq * sq > best) --sq;
+        while ((int64_t)(sq + 1) * (sq + 1) <= best) ++sq;
+    }
+    out[idx] = (uint8_t)sq;
 }
 
 __global__ void normalize_angle_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n)
@@ -458,6 +688,92 @@ __global__ void world_to_pixel_kernel(const double* __restrict__ xy, int64_t n, 
 }
 
 // ------------------------------------------------------------------------------------------------ host API
+// ---- sample points of the distance-field classification (see bcp_coop.h) -----------------------------------
+static double seg_dist(double px, double py, double ax, double ay, double bx, double by)
+{
+    const double vx = bx - ax, vy = by - ay, wx = px - ax, wy = py - ay;
+    const double vv = vx * vx + vy * vy;
+    double t = vv > 0 ? (wx * vx + wy * vy) / vv : 0.0;
+    t = t < 0 ? 0 : (t > 1 ? 1 : t);
+    const double cx = ax + t * vx, cy = ay + t * vy;
+    return std::sqrt((px - cx) * (px - cx) + (py - cy) * (py - cy));
+}
+
+static bool point_in_polygon(double px, double py, const double (*v)[2], int k)
+{
+    bool in = false;
+    for (int i = 0, j = k - 1; i < k; j = i++) {
+        if (((v[i][1] > py) != (v[j][1] > py)) &&
+            (px < (v[j][0] - v[i][0]) * (py - v[i][1]) / (v[j][1] - v[i][1]) + v[i][0]))
+            in = !in;
+    }
+    return in;
+}
+
+// Worst-case slack, in pixels, between the real rotated footprint and the pixel set cv2.fillPoly produces from it:
+// vertex rounding moves the contour by <= sqrt(.5), Bresenham strays <= .5 from the rounded contour, 16.16 slopes
+// add < .01; a sample centre is itself rounded to a pixel (<= sqrt(.5)).
+static const double kSlackOuter = 0.7072 + 0.5 + 0.01 + 0.7072;
+static const double kSlackInner = 0.7072 + 0.7072 + 0.05;
+
+static void build_cull_geometry(const bcp_params& p, double res, CullDesc* C)
+{
+    const int K = p.n_verts;
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300, rmax = 0;
+    for (int k = 0; k < K; ++k) {
+        xmin = std::min(xmin, p.verts[k][0]);
+        xmax = std::max(xmax, p.verts[k][0]);
+        ymin = std::min(ymin, p.verts[k][1]);
+        ymax = std::max(ymax, p.verts[k][1]);
+        rmax = std::max(rmax, std::sqrt(p.verts[k][0] * p.verts[k][0] + p.verts[k][1] * p.verts[k][1]));
+    }
+    C->reach = (int)std::ceil(rmax / res) + 2;
+    C->pad = 2 * C->reach + 4;
+    const double ay = 0.5 * (ymin + ymax), half_w = 0.5 * (ymax - ymin);
+    double a0 = xmin + half_w, a1 = xmax - half_w;
+    if (a0 > a1) a0 = a1 = 0.5 * (xmin + xmax);
+    // OUTER: capsule around the axis segment [a0,a1] x {ay} that contains every vertex (hence the polygon), covered
+    // by n_out discs: a disc row of spacing h covers the capsule of radius rho when its radius is sqrt(rho^2+(h/2)^2)
+    double rho = 0;
+    for (int k = 0; k < K; ++k) rho = std::max(rho, seg_dist(p.verts[k][0], p.verts[k][1], a0, ay, a1, ay));
+    const int n_out = a1 > a0 ? std::min(kMaxSamples, std::max(2, (int)std::ceil((a1 - a0) / (0.5 * rho)) + 1)) : 1;
+    const double h = n_out > 1 ? (a1 - a0) / (n_out - 1) : 0.0;
+    const double r_out = std::sqrt(rho * rho + 0.25 * h * h) / res + kSlackOuter;
+    C->n_out = n_out;
+    for (int i = 0; i < n_out; ++i) C->out_x[i] = (a0 + i * h) / res;
+    C->t_out = (int)std::floor(r_out) + 1;  // floor(d) >= t_out  =>  d > r_out
+    // INNER: discs centred on the same axis that lie inside the polygon
+    C->n_in = 0;
+    for (int j = 0; j < kMaxSamples; ++j) {
+        const double bx = kMaxSamples > 1 ? a0 + (a1 - a0) * j / (kMaxSamples - 1) : a0;
+        if (!point_in_polygon(bx, ay, p.verts, K)) continue;
+        double rin = 1e300;
+        for (int k = 0; k < K; ++k) {
+            const int kn = (k + 1) % K;
+            rin = std::min(rin, seg_dist(bx, ay, p.verts[k][0], p.verts[k][1], p.verts[kn][0], p.verts[kn][1]));
+        }
+        const double r = rin / res - kSlackInner;   // lethal cell within r of the sample pixel => inside the mask
+        const int t = (int)std::floor(r) - 1;       // floor(d) <= t  =>  d < t + 1 <= r
+        if (t < 0) continue;
+        C->in_x[C->n_in] = bx / res;
+        C->t_in[C->n_in] = t;
+        ++C->n_in;
+        if (a1 <= a0) break;
+    }
+    C->axis_y = ay / res;
+}
+
+static int footprint_is_wide(const bcp_params& p, double res)
+{
+    double d2 = 0;
+    for (int i = 0; i < p.n_verts; ++i)
+        for (int j = 0; j < i; ++j) {
+            const double dx = p.verts[i][0] - p.verts[j][0], dy = p.verts[i][1] - p.verts[j][1];
+            d2 = std::max(d2, dx * dx + dy * dy);
+        }
+    return std::sqrt(d2) / res + 3.0 > 96.0;  // row masks of the cooperative path: 3 words unless wider
+}
+
 static void fill_dev_params(bcp_handle* h)
 {
     const bcp_params& p = h->params;
@@ -482,6 +798,8 @@ static void fill_dev_params(bcp_handle* h)
     d.progress_mult = p.spatial_progress_multiplier;
     d.par_thr = -p.spatial_precision / 9;
     d.sp_prune = std::nextafter(std::nextafter(p.spatial_precision, INFINITY), INFINITY);
+    d.sp2_lo = p.spatial_precision * p.spatial_precision * (1.0 - 1e-13);
+    d.sp2_hi = p.spatial_precision * p.spatial_precision * (1.0 + 1e-13);
     const double res = h->resolution > 0 ? h->resolution : 1.0;
     for (int k = 0; k < p.n_verts; ++k) {
         d.qverts[k][0] = p.verts[k][0] / res;  // robot_footprint / map_resolution (path_tools.py:145)
@@ -499,7 +817,6 @@ static int check_kernel_size(const bcp_params& p, double res)
     return std::sqrt(r2) / res + 2.0 <= BCP_MAX_KERNEL_HALF;
 }
 
-static size_t edge_lds_bytes(const bcp_handle* h) { return (size_t)h->params.n_verts * 2 * kBlock * sizeof(uint32_t); }
 
 extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, int64_t env_id_base, bcp_handle** out)
 {
@@ -527,6 +844,9 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->device = device;
     h->env_id_base = env_id_base;
     h->seed = 0;
+    h->exact_mode = 0;
+    h->dense_threshold = 12;
+    h->cull_enabled = 1;
     fill_dev_params(h);
     *out = h;
     return BCP_OK;
@@ -538,6 +858,9 @@ extern "C" int bcp_destroy(bcp_handle* h)
     (void)hipSetDevice(h->device);
     if (h->bitmap) (void)hipFree(h->bitmap);
     if (h->path5) (void)hipFree(h->path5);
+    if (h->path_bbox) (void)hipFree(h->path_bbox);
+    if (h->edt) (void)hipFree(h->edt);
+    if (h->edt_col) (void)hipFree(h->edt_col);
     delete h;
     return BCP_OK;
 }
@@ -548,6 +871,26 @@ extern "C" int bcp_seed(bcp_handle* h, uint64_t seed)
     h->seed = seed;
     h->step_counter = 0;
     return BCP_OK;
+}
+
+extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
+{
+    if (!h) return fail(BCP_E_INVALID, "bcp_set_tuning: null handle");
+    switch (key) {
+        case BCP_TUNE_EXACT_MODE:
+            if (value < 0 || value > 2) return fail(BCP_E_INVALID, "bcp_set_tuning: exact mode must be 0, 1 or 2");
+            h->exact_mode = value;
+            return BCP_OK;
+        case BCP_TUNE_DENSE_THRESHOLD:
+            h->dense_threshold = value;
+            return BCP_OK;
+        case BCP_TUNE_CULL:
+            h->cull_enabled = value ? 1 : 0;
+            h->cull.on = (value && h->cull.edt) ? 1 : 0;
+            return BCP_OK;
+        default:
+            return fail(BCP_E_INVALID, "bcp_set_tuning: unknown key %d", key);
+    }
 }
 
 extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows, int32_t cols, int32_t shared,
@@ -594,9 +937,39 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
         m.ox = origins[0];
         m.oy = origins[1];
     }
-    // stage in LDS when the shared bitmap plus the edge table leaves room for >= 2 workgroups per CU
-    const size_t map_bytes = (size_t)rows * wpr * sizeof(uint32_t);
-    m.in_lds = (shared && map_bytes + edge_lds_bytes(h) <= 64 * 1024) ? 1 : 0;
+    // stage the shared bitmap in LDS when the whole collision scratch then stays within 64 KiB per workgroup
+    m.in_lds = (shared && collision_lds_bytes(h->params.n_verts, 1, rows, wpr) <= 64 * 1024) ? 1 : 0;
+    h->wide = footprint_is_wide(h->params, resolution);
+    // distance field for the O(1) pre-classification (shared maps)
+    CullDesc& C = h->cull;
+    memset(&C, 0, sizeof(C));
+    build_cull_geometry(h->params, resolution, &C);
+    if (shared && h->cull_enabled) {
+        const int W = cols + 2 * C.pad, H = rows + 2 * C.pad;
+        const size_t cells = (size_t)W * H;
+        if (cells > h->edt_bytes) {
+            if (h->edt) HIP_TRY(hipFree(h->edt));
+            h->edt = nullptr;
+            h->edt_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&h->edt, cells));
+            h->edt_bytes = cells;
+        }
+        if (cells * sizeof(int32_t) > h->edt_col_bytes) {
+            if (h->edt_col) HIP_TRY(hipFree(h->edt_col));
+            h->edt_col = nullptr;
+            h->edt_col_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&h->edt_col, cells * sizeof(int32_t)));
+            h->edt_col_bytes = cells * sizeof(int32_t);
+        }
+        hipLaunchKernelGGL(edt_columns_kernel, dim3((W + 63) / 64), dim3(64), 0, s, h->bitmap, rows, cols, wpr, C.pad,
+                           h->edt_col);
+        hipLaunchKernelGGL(edt_rows_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, h->edt_col, W, H,
+                           h->edt);
+        HIP_TRY(hipGetLastError());
+        C.edt = h->edt;
+        C.width = W;
+        C.on = 1;
+    }
     h->have_map = true;
     return BCP_OK;
 }
@@ -622,7 +995,20 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
     const int blocks = (int)std::min<int64_t>((total + threads - 1) / threads, 65536);
     hipLaunchKernelGGL(path_trig_kernel, dim3(blocks), dim3(threads), 0, s, xytheta, h->path5, total);
     HIP_TRY(hipGetLastError());
+    const int64_t n_paths = shared ? 1 : h->n;
+    const size_t bb_bytes = (size_t)n_paths * 4 * sizeof(double);
+    if (bb_bytes > h->path_bbox_bytes) {
+        if (h->path_bbox) HIP_TRY(hipFree(h->path_bbox));
+        h->path_bbox = nullptr;
+        h->path_bbox_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&h->path_bbox, bb_bytes));
+        h->path_bbox_bytes = bb_bytes;
+    }
+    hipLaunchKernelGGL(path_bbox_kernel, dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, s, xytheta,
+                       shared ? nullptr : lens, max_len, n_paths, h->path_bbox);
+    HIP_TRY(hipGetLastError());
     h->path.pts = h->path5;
+    h->path.bbox = h->path_bbox;
     h->path.lens = shared ? nullptr : lens;
     h->path.max_len = max_len;
     h->path.shared = shared ? 1 : 0;
@@ -668,6 +1054,10 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     StepArgs a;
     a.P = h->dev;
     a.map = h->map;
+    a.cull = h->cull;
+    a.exact_mode = h->exact_mode;
+    a.dense_threshold = h->dense_threshold;
+    a.wide = h->wide;
     a.path = h->path;
     a.st = h->st;
     a.init = h->init;
@@ -683,7 +1073,7 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     a.seed = h->seed;
     a.step_counter = h->step_counter;
     a.env_id_base = h->env_id_base;
-    const size_t lds = edge_lds_bytes(h) + (h->map.in_lds ? (size_t)h->map.rows * h->map.wpr * sizeof(uint32_t) : 0);
+    const size_t lds = collision_lds_bytes(h->params.n_verts, h->map.in_lds, h->map.rows, h->map.wpr);
     const int blocks = (int)((h->n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(step_kernel, dim3(blocks), dim3(kBlock), lds, s, a);
     h->step_counter += 1;
@@ -753,8 +1143,10 @@ extern "C" int bcp_pose_collides(bcp_handle* h, const double* poses, int64_t n, 
     if (!h->have_map) return fail(BCP_E_STATE, "bcp_pose_collides: costmaps not set");
     HIP_TRY(hipSetDevice(h->device));
     const int blocks = (int)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(pose_collides_kernel, dim3(blocks), dim3(kBlock), edge_lds_bytes(h), (hipStream_t)stream, h->dev,
-                       h->map, poses, n, h->n, out);
+    hipLaunchKernelGGL(pose_collides_kernel, dim3(blocks), dim3(kBlock),
+                       collision_lds_bytes(h->params.n_verts, h->map.in_lds, h->map.rows, h->map.wpr),
+                       (hipStream_t)stream, h->dev, h->map, h->cull, h->exact_mode, h->dense_threshold, h->wide, poses, n,
+                       h->n, out);
     HIP_TRY(hipGetLastError());
     return BCP_OK;
 }
@@ -774,9 +1166,14 @@ extern "C" int bcp_pixel_footprint(bcp_handle* h, const double* angles, int64_t 
         P.qverts[k][1] = h->params.verts[k][1] / resolution;
     }
     HIP_TRY(hipMemsetAsync(masks, 0, (size_t)n * side * side, s));
-    const int blocks = (int)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(pixel_footprint_kernel, dim3(blocks), dim3(kBlock), edge_lds_bytes(h), s, P, angles, n, masks, side,
-                       shape_hw);
+    if (h->exact_mode == 2) {  // per-thread rasteriser
+        const int blocks = (int)((n + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(pixel_footprint_thread_kernel, dim3(blocks), dim3(kBlock),
+                           (size_t)h->params.n_verts * 2 * kBlock * sizeof(uint32_t), s, P, angles, n, masks, side, shape_hw);
+    } else {                   // cooperative rasteriser: one wave per angle
+        hipLaunchKernelGGL(pixel_footprint_kernel, dim3((unsigned)n), dim3(kBlock),
+                           (size_t)h->params.n_verts * 2 * sizeof(double), s, P, angles, n, masks, side, shape_hw);
+    }
     HIP_TRY(hipGetLastError());
     return BCP_OK;
 }

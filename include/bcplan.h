@@ -126,12 +126,20 @@ int bcp_destroy(bcp_handle *h);
 /* PlanEnv.seed / np.random.seed for the noise stream (differential_drive.py:50 uses the global numpy RNG) */
 int bcp_seed(bcp_handle *h, uint64_t seed);
 
+/* Execution knobs; none of them changes any result (tests run every combination against the oracle).
+ *   BCP_TUNE_EXACT_MODE       0 = auto, 1 = always the wave-cooperative exact rasteriser, 2 = always the per-thread one
+ *   BCP_TUNE_DENSE_THRESHOLD  auto mode: more undecided poses than this in one wavefront -> per-thread rasteriser
+ *   BCP_TUNE_CULL             0 = skip the distance-field pre-classification (every in-map pose is rasterised) */
+enum { BCP_TUNE_EXACT_MODE = 0, BCP_TUNE_DENSE_THRESHOLD = 1, BCP_TUNE_CULL = 2 };
+int bcp_set_tuning(bcp_handle *h, int32_t key, int32_t value);
+
 /* ---- static per-episode inputs ------------------------------------------------------------------------ */
 /* CostMap2D (utilities/costmap_2d.py:13-37).  data: uint8 [rows, cols] when shared, else [N, rows, cols]
  * (row-major, `rows`/`cols` is the padded allocation).  valid_rows/valid_cols (optional, [N] int32) give each
  * env's true map shape for the bounds test of env.py:483-484; NULL => rows/cols.  origins: host double[2] when
  * origins_per_env == 0, else device double [N,2].  Builds the library-owned 1-bit lethal mask
- * (cell == 254) that the step kernel reads; call again whenever the costmap content changes. */
+ * (cell == 254) that the step kernel reads and, for a shared map, the distance transform of the lethal cells used
+ * to settle most poses without rasterising; call again whenever the costmap content changes. */
 int bcp_set_costmaps(bcp_handle *h, const uint8_t *data, int32_t rows, int32_t cols, int32_t shared,
                      const int32_t *valid_rows, const int32_t *valid_cols, const double *origins,
                      int32_t origins_per_env, double resolution, void *stream);

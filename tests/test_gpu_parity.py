@@ -76,8 +76,10 @@ def test_tricycle_variants(torch_cuda, variant, dyn, pid):
 
 @pytest.mark.parametrize("robot,fp_name", [("industrial_tricycle_v1", "tri"), ("industrial_diffdrive_v1", "dd")])
 @pytest.mark.parametrize("res_name", ["r003", "r64", "r256"])
-def test_pixel_footprint_masks_bit_exact(torch_cuda, oracle, robot, fp_name, res_name):
-    """get_pixel_footprint: shape from the reference's own pre-fill arithmetic (g5), pixels from the oracle fill."""
+@pytest.mark.parametrize("exact_mode", [1, 2], ids=["cooperative", "per_thread"])
+def test_pixel_footprint_masks_bit_exact(torch_cuda, oracle, robot, fp_name, res_name, exact_mode):
+    """get_pixel_footprint: shape from the reference's own pre-fill arithmetic (g5), pixels from the oracle fill.
+    Both exact rasterisers of the library (wave-cooperative and per-thread) must reproduce every mask."""
     from bc_gym_planning_env_amd import NativeOps
     g = load("g5_footprint_vertices.npz")
     key = "%s_%s" % (fp_name, res_name)
@@ -85,6 +87,7 @@ def test_pixel_footprint_masks_bit_exact(torch_cuda, oracle, robot, fp_name, res
     rng = np.random.RandomState(11)
     angles = np.concatenate([g[key + "_angles"], rng.uniform(-np.pi, np.pi, 6000)])
     ops = NativeOps(robot)
+    ops.set_tuning(exact_mode=exact_mode)
     masks, shapes = ops.get_pixel_footprint(angles, res)
     masks, shapes = masks.cpu().numpy(), shapes.cpu().numpy()
     np.testing.assert_array_equal(shapes[:len(g[key + "_shape"])], g[key + "_shape"])
@@ -106,6 +109,41 @@ def test_pose_collides_vs_reference(torch_cuda, tag):
     ops.set_costmap(g[tag + "_map"], g[tag + "_origin"], float(g[tag + "_res"]))
     got = ops.pose_collides(g[tag + "_poses"]).cpu().numpy()
     np.testing.assert_array_equal(got, g[tag + "_collides"])
+
+
+MODES = [dict(cull=1, exact_mode=0), dict(cull=1, exact_mode=1), dict(cull=1, exact_mode=2),
+         dict(cull=0, exact_mode=1), dict(cull=0, exact_mode=2), dict(cull=1, exact_mode=0, dense_threshold=0)]
+
+
+@pytest.mark.parametrize("mode", MODES, ids=lambda m: "-".join("%s%d" % (k[:4], v) for k, v in sorted(m.items())))
+@pytest.mark.parametrize("tag", ["mini0", "mini3", "mini64"])
+def test_pose_collides_every_path_vs_oracle(torch_cuda, oracle, tag, mode):
+    """60k random poses per map, a third of them hugging lethal cells, through every execution path of the library
+    (distance-field pre-classification on/off x cooperative / per-thread exact rasteriser): verdicts must equal the
+    oracle's bit for bit."""
+    from bc_gym_planning_env_amd import NativeOps
+    g = load("g6_pose_collides.npz")
+    tri = int(g[tag + "_robot"]) == 0
+    robot = "industrial_tricycle_v1" if tri else "industrial_diffdrive_v1"
+    fp = oracle.TRICYCLE_FOOTPRINT if tri else oracle.DIFFDRIVE_FOOTPRINT
+    cm, origin, res = g[tag + "_map"], g[tag + "_origin"], float(g[tag + "_res"])
+    rng = np.random.RandomState(31)
+    n = 60000
+    poses = np.stack([rng.uniform(-4.5, 4.5, n), rng.uniform(-4.5, 4.5, n), rng.uniform(-np.pi, np.pi, n)], axis=1)
+    ly, lx = np.nonzero(cm == 254)
+    k = n // 3
+    pick = rng.randint(0, len(ly), k)
+    ang, rad = rng.uniform(-np.pi, np.pi, k), rng.uniform(0.0, 1.6, k)
+    poses[:k, 0] = origin[0] + lx[pick] * res + rad * np.cos(ang)
+    poses[:k, 1] = origin[1] + ly[pick] * res + rad * np.sin(ang)
+    ops = NativeOps(robot)
+    ops.set_tuning(**mode)
+    ops.set_costmap(cm, origin, res)
+    got = ops.pose_collides(poses).cpu().numpy()
+    exp = np.array([oracle.pose_collides(p[0], p[1], p[2], fp, cm, origin, res) for p in poses], dtype=np.uint8)
+    bad = np.nonzero(got != exp)[0]
+    assert len(bad) == 0, (len(bad), poses[bad[:5]], got[bad[:5]], exp[bad[:5]])
+    assert 0.05 < exp.mean() < 0.6
 
 
 def test_kat_collision_table(torch_cuda):
