@@ -11,7 +11,7 @@ MAX_VERTS = 32
 MODEL_TRICYCLE, MODEL_DIFFDRIVE = 0, 1
 STEP_AUTO_RESET, STEP_ACTIONS_F32 = 1, 2
 ERR_ANGLE_JUMP = 1
-TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL = 0, 1, 2
+TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL, TUNE_DEFER = 0, 1, 2, 3
 E_NO_DEVICE = -2
 
 _f64p = C.POINTER(C.c_double)

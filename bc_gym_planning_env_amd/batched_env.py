@@ -308,10 +308,10 @@ class BatchedPlanEnv(object):
         return BatchedState(torch.from_numpy(robot).to(dev), torch.from_numpy(md).to(dev), torch.from_numpy(ti).to(dev),
                             torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev))
 
-    def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None):
+    def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None, defer=None):
         """Execution knobs of libbcplan (bcp_set_tuning); results never depend on them."""
         for key, val in ((_lib.TUNE_EXACT_MODE, exact_mode), (_lib.TUNE_DENSE_THRESHOLD, dense_threshold),
-                         (_lib.TUNE_CULL, cull)):
+                         (_lib.TUNE_CULL, cull), (_lib.TUNE_DEFER, defer)):
             if val is not None:
                 _lib.check(self._lib.bcp_set_tuning(self._h, key, int(val)))
 

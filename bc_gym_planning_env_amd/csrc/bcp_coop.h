@@ -45,17 +45,18 @@ __device__ __forceinline__ int classify(const CullDesc& C, int rows, int cols, i
     if (!C.on) return kAmbiguous;
     const double ay_c = C.axis_y * c, ay_s = C.axis_y * s;
     const uint8_t* base = C.edt + (int64_t)(py + C.pad) * C.width + (px + C.pad);
-    bool all_far = true;
+    // all lookups are issued back to back (no short-circuit), so their latencies overlap
+    int near_out = 0, hit_in = 0;
     for (int i = 0; i < C.n_out; ++i) {
         const int du = (int)rint(C.out_x[i] * c - ay_s), dv = (int)rint(C.out_x[i] * s + ay_c);
-        all_far = all_far && (int)base[dv * C.width + du] >= C.t_out;
+        near_out |= (int)base[dv * C.width + du] < C.t_out;
     }
-    if (all_far) return kFree;
-    bool hit = false;
     for (int j = 0; j < C.n_in; ++j) {
         const int du = (int)rint(C.in_x[j] * c - ay_s), dv = (int)rint(C.in_x[j] * s + ay_c);
-        hit = hit || (int)base[dv * C.width + du] <= C.t_in[j];
+        hit_in |= (int)base[dv * C.width + du] <= C.t_in[j];
     }
+    if (!near_out) return kFree;
+    const bool hit = hit_in != 0;
     return hit ? kHit : kAmbiguous;
 }
 

@@ -60,7 +60,8 @@ struct MapDesc {
 
 struct PathDesc {
     const double* pts;   // [len][5] = x, y, theta, cos(theta), sin(theta); shared or [N][max_len][5]
-    const double* bbox;  // [4] = xmin, xmax, ymin, ymax of the way points; shared or [N][4]
+    const double* bbox;  // [8] = xmin, xmax, ymin, ymax of the way points, then the bucket grid x0, 1/wx, y0, 1/wy
+    const int16_t* index; // [2 axes][kPathBuckets][2] = first / last way point index that can be reached from a bucket
     const int32_t* lens;
     int32_t max_len, shared;
 };
@@ -81,6 +82,8 @@ struct bcp_handle {
     size_t path5_bytes;
     double* path_bbox;     // owned
     size_t path_bbox_bytes;
+    int16_t* path_index;   // owned
+    size_t path_index_bytes;
     uint8_t* edt;          // owned: distance transform of the shared costmap (padded)
     size_t edt_bytes;
     int32_t* edt_col;      // owned scratch of the transform
@@ -89,6 +92,9 @@ struct bcp_handle {
     CullDesc cull;
     PathDesc path;
     DevState st, init;
+    void* pending;            // owned: Pending[n]
+    int32_t* pending_count;   // owned: two alternating counters
+    int32_t defer;            // settle undecided envs in a second kernel (shared map with distance field)
     int32_t exact_mode;       // 0 auto, 1 cooperative only, 2 per-thread only
     int32_t dense_threshold;  // auto: more ambiguous lanes than this in a wave -> per-thread rasteriser
     int32_t cull_enabled;
@@ -154,9 +160,11 @@ __global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restr
     }
 }
 
-// bounding box of each path's way points: one thread per path
+constexpr int kPathBuckets = 64;
+
+// Per path: bounding box of the way points and a 1-D bucket grid per axis over [min - sp, max + sp].
 __global__ void path_bbox_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
-                                 int64_t n_paths, double* __restrict__ bbox)
+                                 int64_t n_paths, double sp_prune, double* __restrict__ bbox)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_paths) return;
@@ -169,61 +177,88 @@ __global__ void path_bbox_kernel(const double* __restrict__ xyt, const int32_t* 
         y0 = fmin(y0, q[3 * j + 1]);
         y1 = fmax(y1, q[3 * j + 1]);
     }
-    bbox[4 * p + 0] = x0;
-    bbox[4 * p + 1] = x1;
-    bbox[4 * p + 2] = y0;
-    bbox[4 * p + 3] = y1;
+    double* o = bbox + 8 * p;
+    o[0] = x0;
+    o[1] = x1;
+    o[2] = y0;
+    o[3] = y1;
+    const double wx = fmax((x1 - x0 + 2.0 * sp_prune) / kPathBuckets, 1e-9);
+    const double wy = fmax((y1 - y0 + 2.0 * sp_prune) / kPathBuckets, 1e-9);
+    o[4] = x0 - sp_prune;
+    o[5] = 1.0 / wx;
+    o[6] = y0 - sp_prune;
+    o[7] = 1.0 / wy;
+}
+
+// index[p][axis][b] = {first, last} way point whose coordinate lies within sp of bucket b (widened by a guard band
+// that swallows the rounding of the bucket computation); {32767, -1} when there is none.  Any way point with
+// |x_j - x| <= sp_prune for a query x that falls into bucket b is inside [first, last].
+__global__ void path_index_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
+                                  int64_t n_paths, double sp_prune, const double* __restrict__ bbox,
+                                  int16_t* __restrict__ index)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_paths * 2 * kPathBuckets) return;
+    const int b = (int)(t % kPathBuckets);
+    const int axis = (int)((t / kPathBuckets) % 2);
+    const int64_t p = t / (2 * kPathBuckets);
+    const int m = lens ? lens[p] : max_len;
+    const double* q = xyt + p * (int64_t)max_len * 3;
+    const double o = bbox[8 * p + 4 + 2 * axis], w = 1.0 / bbox[8 * p + 5 + 2 * axis];
+    const double guard = 1e-6 * w + 1e-12;
+    const double lo = o + b * w - sp_prune - guard, hi = o + (b + 1) * w + sp_prune + guard;
+    int first = 32767, last = -1;
+    for (int j = 0; j < m; ++j) {
+        const double v = q[3 * j + axis];
+        if (v >= lo && v <= hi) {
+            first = min(first, j);
+            last = j;
+        }
+    }
+    index[2 * t] = (int16_t)first;
+    index[2 * t + 1] = (int16_t)last;
 }
 
 // find_last_reached restricted to j >= target (utilities/path_tools.py:408-448): the reward only asks whether the
 // LAST reached index is >= target_idx (envs/base/reward.py:234), so indices below target never matter.
-// The loop index is kept wave-uniform (every lane walks the same j) so that a shared path is read through the
-// scalar cache; lanes that are finished, or whose target lies above j, simply sit the iteration out.
+// A way point can only be reached when |x_j - x| and |y_j - y| are both below spatial_precision, so the scan is
+// confined to the index window the two bucket tables allow for this pose (usually a handful of way points).
 __device__ __forceinline__ int last_reached_from(const DevParams& P, const double* __restrict__ path,
-                                                 const double* __restrict__ bbox, int m, int m_loop, int target,
-                                                 double x, double y, double th)
+                                                 const double* __restrict__ bbox, const int16_t* __restrict__ index,
+                                                 int m, int target, double x, double y, double th)
 {
-    // no way point can be within spatial_precision of a pose that far outside the path's bounding box
-    bool open = target <= m - 1 && !(x < bbox[0] - P.sp_prune || x > bbox[1] + P.sp_prune ||
-                                     y < bbox[2] - P.sp_prune || y > bbox[3] + P.sp_prune);
-    int found = -1;
-    for (int j = m_loop - 1; j >= 0; --j) {
-        if (!__any(open)) break;
-        if (open && j < m) {
-            if (j < target) {
-                open = false;
-            } else {
-                const double* s = path + 5 * j;
-                const double dx = s[0] - x, dy = s[1] - y;
-                // the three reach conditions are independent predicates; evaluate the cheap ones first
-                if (!(fabs(dx) > P.sp_prune || fabs(dy) > P.sp_prune)) {  // else hypot(dx,dy) >= sp
-                    const double par = s[3] * (x - s[0]) + s[4] * (y - s[1]);   // path_tools.py:405
-                    if (par >= P.par_thr) {
-                        const double q = dx * dx + dy * dy;
-                        bool near = q < P.sp2_lo;
-                        if (!near && q <= P.sp2_hi) near = hypot(dx, dy) < P.sp;  // too close to call from q
-                        if (near) {
-                            const double ang = fabs(normalize_angle(th - s[2]));
-                            if (ang < P.ap) {
-                                found = j;
-                                open = false;
-                            }
-                        }
-                    }
-                }
-            }
-        }
+    if (target > m - 1) return -1;
+    if (x < bbox[0] - P.sp_prune || x > bbox[1] + P.sp_prune || y < bbox[2] - P.sp_prune || y > bbox[3] + P.sp_prune)
+        return -1;  // farther than spatial_precision from the bounding box of the whole path
+    const int bx = min(max((int)floor((x - bbox[4]) * bbox[5]), 0), kPathBuckets - 1);
+    const int by = min(max((int)floor((y - bbox[6]) * bbox[7]), 0), kPathBuckets - 1);
+    const int16_t* ix = index + 2 * bx;
+    const int16_t* iy = index + 2 * (kPathBuckets + by);
+    const int lo = max(max((int)ix[0], (int)iy[0]), target);
+    const int hi = min(min((int)ix[1], (int)iy[1]), m - 1);
+    for (int j = hi; j >= lo; --j) {
+        const double* s = path + 5 * j;
+        const double dx = s[0] - x, dy = s[1] - y;
+        // the three reach conditions are independent predicates; evaluate the cheap ones first
+        if (fabs(dx) > P.sp_prune || fabs(dy) > P.sp_prune) continue;   // then hypot(dx,dy) >= sp
+        const double par = s[3] * (x - s[0]) + s[4] * (y - s[1]);       // path_tools.py:405
+        if (!(par >= P.par_thr)) continue;
+        const double q = dx * dx + dy * dy;
+        bool near = q < P.sp2_lo;
+        if (!near && q <= P.sp2_hi) near = hypot(dx, dy) < P.sp;        // too close to call from q
+        if (!near) continue;
+        if (fabs(normalize_angle(th - s[2])) < P.ap) return j;
     }
-    return found;
+    return -1;
 }
 
 // ContinuousRewardProvider.reward (envs/base/reward.py:214-259)
 __device__ __forceinline__ double reward_step(const DevParams& P, const double* __restrict__ path,
-                                              const double* __restrict__ bbox, int m, int m_loop, double x, double y,
-                                              double th, double& min_dist, int& target)
+                                              const double* __restrict__ bbox, const int16_t* __restrict__ index, int m,
+                                              double x, double y, double th, double& min_dist, int& target)
 {
-    const int last = last_reached_from(P, path, bbox, m, m_loop, target, x, y, th);  // every lane joins the loop
     if (target > m - 1) return 0.0;
+    const int last = last_reached_from(P, path, bbox, index, m, target, x, y, th);
     if (last >= 0) {
         target = last + 1;
         if (!(target > m - 1)) {
@@ -244,6 +279,8 @@ __device__ __forceinline__ double reward_step(const DevParams& P, const double* 
     return 0.0;
 }
 
+struct Pending;
+
 struct StepArgs {
     DevParams P;
     MapDesc map;
@@ -262,6 +299,9 @@ struct StepArgs {
     int32_t exact_mode, dense_threshold, wide;
     uint64_t seed, step_counter;
     int64_t env_id_base;
+    struct Pending* pending;   // [n] parking slots for undecided envs (nullptr: settle everything in kernel 1)
+    int32_t* pending_count;    // this step's counter of parked envs
+    int32_t* pending_next;     // the next step's counter (the two alternate); kernel 1 zeroes it
 };
 
 // dynamic LDS of the collision kernels:
@@ -355,96 +395,58 @@ __device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc&
     return hit;
 }
 
-__global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
+// One env's state after the robot model ran, before the collision verdict is known.
+struct Pending {
+    Robot r;            // after robot.step()
+    Pose old;           // pose before the step (rollback target)
+    double min_dist;
+    double z[3];
+    int32_t target, iter, err, drawn;
+    int32_t collided;   // sticky flag before this step
+    int32_t env_lo, env_hi;
+};
+
+// Everything of PlanEnv.step() that follows pose_collides(): rollback (env.py:458-459), bookkeeping (:382-396),
+// reward (:352), done (:407-419), outputs, optional reset, state write-back.  Runs on one lane for env i.
+__device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pending& q, bool hit)
 {
     const DevParams& P = a.P;
-    const int tid = threadIdx.x;
-    const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
-    const bool active = gi < a.n;
-    const int64_t i = active ? gi : a.n - 1;  // inactive lanes of the last wave shadow env n-1 and never store
-
-    const CollisionLds L = collision_lds_setup(P, a.map, tid);
-
-    // ---- load state
-    Robot r;
-    r.p.x = a.st.x[i];
-    r.p.y = a.st.y[i];
-    r.p.th = a.st.angle[i];
-    r.v = a.st.v[i];
-    r.w = a.st.w[i];
     const bool tri = P.model == BCP_MODEL_TRICYCLE;
-    r.steer = tri ? a.st.steer[i] : 0.0;
-    r.wheel = tri ? a.st.wheel[i] : 0.0;
-    double min_dist = a.st.min_dist[i];
-    int target = a.st.target_idx[i];
-    int iter = a.st.cur_iter[i];
-    bool collided = a.st.collided[i] != 0;
-
-    double cmd0, cmd1;
-    if (a.flags & BCP_STEP_ACTIONS_F32) {
-        const float2 c = reinterpret_cast<const float2*>(a.actions)[i];
-        cmd0 = (double)c.x;
-        cmd1 = (double)c.y;
-    } else {
-        const double2 c = reinterpret_cast<const double2*>(a.actions)[i];
-        cmd0 = c.x;
-        cmd1 = c.y;
-    }
-    double z[3] = {0.0, 0.0, 0.0};
-    if (P.noise_on) {
-        if (a.noise_z) {
-            z[0] = a.noise_z[3 * i + 0];
-            z[1] = a.noise_z[3 * i + 1];
-            z[2] = a.noise_z[3 * i + 2];
-        } else {
-            device_normals(a.seed, (uint64_t)(a.env_id_base + i), a.step_counter, z);
-        }
-    }
-
-    // ---- _env_step (envs/base/env.py:442-461)
-    const Pose old = r.p;
-    int drawn = 0;
-    const int err = robot_step(P, r, cmd0, cmd1, z, drawn);
-
-    bool hit = false;
-    if (!(a.flags & (1u << 16)))
-        hit = collides_wave(P, a.map, a.cull, L, a.exact_mode, a.dense_threshold, a.wide != 0, active, i, r.p.x, r.p.y,
-                            r.p.th);
+    Robot& r = q.r;
     if (hit) {  // robot.set_pose(*old_position): pose restored, v = w = 0 (tricycle_model.py:471-476)
-        r.p = old;
+        r.p = q.old;
         r.v = 0.0;
         r.w = 0.0;
     }
-    // ---- _resolve_state_transition bookkeeping (env.py:382-396)
-    iter += 1;
-    collided = collided || hit;
+    int iter = q.iter + 1;
+    bool collided = q.collided != 0 || hit;
+    double min_dist = q.min_dist;
+    int target = q.target;
 
-    // ---- reward / done (env.py:352, :407-419)
-    // shared path: uniform pointers, read through the scalar cache; private paths: per-lane pointers
+    // shared path: uniform pointers (scalar cache); private paths: per-lane pointers
     double rew = 0.0;
     int m;
     if (a.path.shared) {
         m = a.path.max_len;
         if (!(a.flags & (1u << 17)))
-            rew = reward_step(P, a.path.pts, a.path.bbox, m, m, r.p.x, r.p.y, r.p.th, min_dist, target);
+            rew = reward_step(P, a.path.pts, a.path.bbox, a.path.index, m, r.p.x, r.p.y, r.p.th, min_dist, target);
     } else {
         m = a.path.lens[i];
         if (!(a.flags & (1u << 17)))
-            rew = reward_step(P, a.path.pts + i * (int64_t)a.path.max_len * 5, a.path.bbox + i * 4, m, a.path.max_len,
-                              r.p.x, r.p.y, r.p.th, min_dist, target);
+            rew = reward_step(P, a.path.pts + i * (int64_t)a.path.max_len * 5, a.path.bbox + i * 8,
+                              a.path.index + i * (int64_t)(4 * kPathBuckets), m, r.p.x, r.p.y, r.p.th, min_dist, target);
     }
     const bool done = (target > m - 1) || (iter >= P.iteration_timeout) || collided;
-    if (!active) return;
 
     a.reward[i] = rew;
     a.done[i] = (uint8_t)done;
     if (a.collided_now) a.collided_now[i] = (uint8_t)hit;
-    if (a.err) a.err[i] = err;
+    if (a.err) a.err[i] = q.err;
     if (a.noise_z_out) {
         const double nan = __builtin_nan("");
-        a.noise_z_out[3 * i + 0] = (drawn & 1) ? z[0] : nan;
-        a.noise_z_out[3 * i + 1] = (drawn & 2) ? z[1] : nan;
-        a.noise_z_out[3 * i + 2] = (drawn & 4) ? z[2] : nan;
+        a.noise_z_out[3 * i + 0] = (q.drawn & 1) ? q.z[0] : nan;
+        a.noise_z_out[3 * i + 1] = (q.drawn & 2) ? q.z[1] : nan;
+        a.noise_z_out[3 * i + 2] = (q.drawn & 4) ? q.z[2] : nan;
     }
 
     if (done && (a.flags & BCP_STEP_AUTO_RESET)) {  // PlanEnv.reset(): set_state(initial_state) (env.py:293-303)
@@ -463,7 +465,6 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
         collided = a.init.collided[i] != 0;
     }
 
-    // ---- store state
     a.st.x[i] = r.p.x;
     a.st.y[i] = r.p.y;
     a.st.angle[i] = r.p.th;
@@ -477,6 +478,120 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     a.st.target_idx[i] = target;
     a.st.cur_iter[i] = iter;
     a.st.collided[i] = (uint8_t)collided;
+}
+
+// Kernel 1 of a step: robot model + collision for every env.  With a distance field (shared map) a pose is
+// classified in O(1); the few undecided envs are parked in `pending` for kernel 2 and everything else is finished
+// here.  Without a distance field the exact rasterisers run in place (collides_wave).
+__global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
+{
+    const DevParams& P = a.P;
+    const int tid = threadIdx.x;
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
+    const bool active = gi < a.n;
+    const int64_t i = active ? gi : a.n - 1;  // inactive lanes of the last wave shadow env n-1 and never store
+    const bool defer = a.pending != nullptr;
+
+    CollisionLds L;
+    if (!defer) L = collision_lds_setup(P, a.map, tid);
+    if (defer && gi == 0) *a.pending_next = 0;  // arm the counter of the NEXT step (the two slots alternate)
+
+    // ---- load state
+    Pending q;
+    Robot& r = q.r;
+    r.p.x = a.st.x[i];
+    r.p.y = a.st.y[i];
+    r.p.th = a.st.angle[i];
+    r.v = a.st.v[i];
+    r.w = a.st.w[i];
+    const bool tri = P.model == BCP_MODEL_TRICYCLE;
+    r.steer = tri ? a.st.steer[i] : 0.0;
+    r.wheel = tri ? a.st.wheel[i] : 0.0;
+    q.min_dist = a.st.min_dist[i];
+    q.target = a.st.target_idx[i];
+    q.iter = a.st.cur_iter[i];
+    q.collided = a.st.collided[i] != 0;
+
+    double cmd0, cmd1;
+    if (a.flags & BCP_STEP_ACTIONS_F32) {
+        const float2 c = reinterpret_cast<const float2*>(a.actions)[i];
+        cmd0 = (double)c.x;
+        cmd1 = (double)c.y;
+    } else {
+        const double2 c = reinterpret_cast<const double2*>(a.actions)[i];
+        cmd0 = c.x;
+        cmd1 = c.y;
+    }
+    q.z[0] = q.z[1] = q.z[2] = 0.0;
+    if (P.noise_on) {
+        if (a.noise_z) {
+            q.z[0] = a.noise_z[3 * i + 0];
+            q.z[1] = a.noise_z[3 * i + 1];
+            q.z[2] = a.noise_z[3 * i + 2];
+        } else {
+            device_normals(a.seed, (uint64_t)(a.env_id_base + i), a.step_counter, q.z);
+        }
+    }
+
+    // ---- _env_step (envs/base/env.py:442-461)
+    q.old = r.p;
+    q.drawn = 0;
+    q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
+
+    bool hit = false;
+    if (a.flags & (1u << 16)) {
+        // collision test disabled (timing experiments only)
+    } else if (defer) {
+        double ox = a.map.ox, oy = a.map.oy;
+        if (a.map.origins) {
+            ox = a.map.origins[2 * i + 0];
+            oy = a.map.origins[2 * i + 1];
+        }
+        const int px = (int)rint((r.p.x - ox) * a.map.inv_res);  // world_to_pixel
+        const int py = (int)rint((r.p.y - oy) * a.map.inv_res);
+        const int cls = classify(a.cull, a.map.rows, a.map.cols, px, py, cos(r.p.th), sin(r.p.th));
+        if (cls == kAmbiguous) {
+            if (active) {
+                const int slot = atomicAdd(a.pending_count, 1);
+                q.env_lo = (int32_t)(uint32_t)i;
+                q.env_hi = (int32_t)(i >> 32);
+                a.pending[slot] = q;
+            }
+            return;  // kernel 2 finishes this env
+        }
+        hit = cls == kHit;
+    } else {
+        hit = collides_wave(P, a.map, a.cull, L, a.exact_mode, a.dense_threshold, a.wide != 0, active, i, r.p.x, r.p.y,
+                            r.p.th);
+    }
+    if (!active) return;
+    finalize_env(a, i, q, hit);
+}
+
+// Kernel 2 of a step: one wavefront per undecided env.  All 64 lanes rasterise the footprint together
+// (coop_collides); lane 0 then finishes the env exactly as kernel 1 would have.
+__global__ void __launch_bounds__(kBlock) step_pending_kernel(const StepArgs a)
+{
+    const DevParams& P = a.P;
+    __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
+    for (int k = threadIdx.x; k < 2 * P.n_verts; k += kBlock) qv[k] = P.qverts[k >> 1][k & 1];
+    __syncthreads();
+    const int count = *a.pending_count;
+    for (int idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        Pending q = a.pending[idx];
+        const int64_t i = ((int64_t)q.env_hi << 32) | (uint32_t)q.env_lo;
+        double ox = a.map.ox, oy = a.map.oy;
+        if (a.map.origins) {
+            ox = a.map.origins[2 * i + 0];
+            oy = a.map.origins[2 * i + 1];
+        }
+        const int px = (int)rint((q.r.p.x - ox) * a.map.inv_res);
+        const int py = (int)rint((q.r.p.y - oy) * a.map.inv_res);
+        const uint32_t* words = a.map.bits + (a.map.shared ? 0 : i * a.map.env_stride);
+        const bool hit = coop_collides(P, qv, cos(q.r.p.th), sin(q.r.p.th), px, py, words, a.map.rows, a.map.cols,
+                                       a.map.wpr, a.wide != 0);
+        if (threadIdx.x == 0) finalize_env(a, i, q, hit);
+    }
 }
 
 __global__ void reset_kernel(DevState st, DevState init, const uint8_t* __restrict__ mask, int64_t n, int tri)
@@ -730,7 +845,9 @@ static void build_cull_geometry(const bcp_params& p, double res, CullDesc* C)
     C->reach = (int)std::ceil(rmax / res) + 2;
     C->pad = 2 * C->reach + 4;
     const double ay = 0.5 * (ymin + ymax), half_w = 0.5 * (ymax - ymin);
-    double a0 = xmin + half_w, a1 = xmax - half_w;
+    // axis segment: pulled in from the ends by a quarter of the half width, so that the round caps of the capsule
+    // still cover the corners of a box-like footprint without inflating the radius (corner distance hypot(w/4, w))
+    double a0 = xmin + 0.25 * half_w, a1 = xmax - 0.25 * half_w;
     if (a0 > a1) a0 = a1 = 0.5 * (xmin + xmax);
     // OUTER: capsule around the axis segment [a0,a1] x {ay} that contains every vertex (hence the polygon), covered
     // by n_out discs: a disc row of spacing h covers the capsule of radius rho when its radius is sqrt(rho^2+(h/2)^2)
@@ -847,6 +964,7 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->exact_mode = 0;
     h->dense_threshold = 12;
     h->cull_enabled = 1;
+    h->defer = 1;
     fill_dev_params(h);
     *out = h;
     return BCP_OK;
@@ -859,8 +977,11 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->bitmap) (void)hipFree(h->bitmap);
     if (h->path5) (void)hipFree(h->path5);
     if (h->path_bbox) (void)hipFree(h->path_bbox);
+    if (h->path_index) (void)hipFree(h->path_index);
     if (h->edt) (void)hipFree(h->edt);
     if (h->edt_col) (void)hipFree(h->edt_col);
+    if (h->pending) (void)hipFree(h->pending);
+    if (h->pending_count) (void)hipFree(h->pending_count);
     delete h;
     return BCP_OK;
 }
@@ -883,6 +1004,9 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
             return BCP_OK;
         case BCP_TUNE_DENSE_THRESHOLD:
             h->dense_threshold = value;
+            return BCP_OK;
+        case BCP_TUNE_DEFER:
+            h->defer = value ? 1 : 0;
             return BCP_OK;
         case BCP_TUNE_CULL:
             h->cull_enabled = value ? 1 : 0;
@@ -969,6 +1093,11 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
         C.edt = h->edt;
         C.width = W;
         C.on = 1;
+        if (!h->pending) {
+            HIP_TRY(hipMalloc(&h->pending, (size_t)h->n * sizeof(Pending)));
+            HIP_TRY(hipMalloc((void**)&h->pending_count, 2 * sizeof(int32_t)));
+            HIP_TRY(hipMemsetAsync(h->pending_count, 0, 2 * sizeof(int32_t), s));
+        }
     }
     h->have_map = true;
     return BCP_OK;
@@ -996,7 +1125,7 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
     hipLaunchKernelGGL(path_trig_kernel, dim3(blocks), dim3(threads), 0, s, xytheta, h->path5, total);
     HIP_TRY(hipGetLastError());
     const int64_t n_paths = shared ? 1 : h->n;
-    const size_t bb_bytes = (size_t)n_paths * 4 * sizeof(double);
+    const size_t bb_bytes = (size_t)n_paths * 8 * sizeof(double);
     if (bb_bytes > h->path_bbox_bytes) {
         if (h->path_bbox) HIP_TRY(hipFree(h->path_bbox));
         h->path_bbox = nullptr;
@@ -1004,11 +1133,24 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
         HIP_TRY(hipMalloc((void**)&h->path_bbox, bb_bytes));
         h->path_bbox_bytes = bb_bytes;
     }
+    const size_t ix_bytes = (size_t)n_paths * 4 * kPathBuckets * sizeof(int16_t);
+    if (ix_bytes > h->path_index_bytes) {
+        if (h->path_index) HIP_TRY(hipFree(h->path_index));
+        h->path_index = nullptr;
+        h->path_index_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&h->path_index, ix_bytes));
+        h->path_index_bytes = ix_bytes;
+    }
+    if (max_len > 32766) return fail(BCP_E_INVALID, "bcp_set_paths: paths longer than 32766 way points are not supported");
     hipLaunchKernelGGL(path_bbox_kernel, dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, s, xytheta,
-                       shared ? nullptr : lens, max_len, n_paths, h->path_bbox);
+                       shared ? nullptr : lens, max_len, n_paths, h->dev.sp_prune, h->path_bbox);
+    const int64_t n_idx = n_paths * 2 * kPathBuckets;
+    hipLaunchKernelGGL(path_index_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, s, xytheta,
+                       shared ? nullptr : lens, max_len, n_paths, h->dev.sp_prune, h->path_bbox, h->path_index);
     HIP_TRY(hipGetLastError());
     h->path.pts = h->path5;
     h->path.bbox = h->path_bbox;
+    h->path.index = h->path_index;
     h->path.lens = shared ? nullptr : lens;
     h->path.max_len = max_len;
     h->path.shared = shared ? 1 : 0;
@@ -1073,9 +1215,21 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     a.seed = h->seed;
     a.step_counter = h->step_counter;
     a.env_id_base = h->env_id_base;
-    const size_t lds = collision_lds_bytes(h->params.n_verts, h->map.in_lds, h->map.rows, h->map.wpr);
+    const bool defer = h->defer && h->cull.on && h->exact_mode == 0 && h->pending != nullptr;
+    a.pending = defer ? (Pending*)h->pending : nullptr;
+    a.pending_count = h->pending_count + (h->step_counter & 1);
+    a.pending_next = h->pending_count + ((h->step_counter + 1) & 1);
     const int blocks = (int)((h->n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(step_kernel, dim3(blocks), dim3(kBlock), lds, s, a);
+    if (defer) {
+        // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest, one wave each
+        hipLaunchKernelGGL(step_kernel, dim3(blocks), dim3(kBlock), 0, s, a);
+        const int waves = (int)std::min<int64_t>(blocks, 1024);
+        hipLaunchKernelGGL(step_pending_kernel, dim3(waves), dim3(kBlock), (size_t)h->params.n_verts * 2 * sizeof(double), s,
+                           a);
+    } else {
+        const size_t lds = collision_lds_bytes(h->params.n_verts, h->map.in_lds, h->map.rows, h->map.wpr);
+        hipLaunchKernelGGL(step_kernel, dim3(blocks), dim3(kBlock), lds, s, a);
+    }
     h->step_counter += 1;
     return BCP_OK;
 }

@@ -36,11 +36,11 @@ class NativeOps(object):
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None):
+    def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None, defer=None):
         """Execution knobs of libbcplan (bcp_set_tuning); results never depend on them.  `cull` must be chosen
         before set_costmap()."""
         for key, val in ((_lib.TUNE_EXACT_MODE, exact_mode), (_lib.TUNE_DENSE_THRESHOLD, dense_threshold),
-                         (_lib.TUNE_CULL, cull)):
+                         (_lib.TUNE_CULL, cull), (_lib.TUNE_DEFER, defer)):
             if val is not None:
                 _lib.check(self._lib.bcp_set_tuning(self._h, key, int(val)))
 

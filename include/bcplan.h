@@ -129,8 +129,10 @@ int bcp_seed(bcp_handle *h, uint64_t seed);
 /* Execution knobs; none of them changes any result (tests run every combination against the oracle).
  *   BCP_TUNE_EXACT_MODE       0 = auto, 1 = always the wave-cooperative exact rasteriser, 2 = always the per-thread one
  *   BCP_TUNE_DENSE_THRESHOLD  auto mode: more undecided poses than this in one wavefront -> per-thread rasteriser
- *   BCP_TUNE_CULL             0 = skip the distance-field pre-classification (every in-map pose is rasterised) */
-enum { BCP_TUNE_EXACT_MODE = 0, BCP_TUNE_DENSE_THRESHOLD = 1, BCP_TUNE_CULL = 2 };
+ *   BCP_TUNE_CULL             0 = skip the distance-field pre-classification (every in-map pose is rasterised)
+ *   BCP_TUNE_DEFER            0 = settle undecided poses inside the step kernel instead of the second, load-balanced
+ *                             kernel (only relevant with a distance field and exact mode auto) */
+enum { BCP_TUNE_EXACT_MODE = 0, BCP_TUNE_DENSE_THRESHOLD = 1, BCP_TUNE_CULL = 2, BCP_TUNE_DEFER = 3 };
 int bcp_set_tuning(bcp_handle *h, int32_t key, int32_t value);
 
 /* ---- static per-episode inputs ------------------------------------------------------------------------ */

@@ -240,15 +240,24 @@ def _random_batch(oracle, rng, n, g, name):
     return st, md, tgt, it
 
 
-@pytest.mark.parametrize("fixture", ["g8_traj_mini_00.npz", "g8_traj_mini_05.npz", "g8_traj_aisle_default.npz"])
-def test_batch_vs_oracle_multi_step(torch_cuda, oracle, fixture):
+STEP_MODES = [dict(), dict(defer=0), dict(exact_mode=1), dict(exact_mode=2), dict(cull=0, exact_mode=1),
+              dict(cull=0, exact_mode=2), dict(defer=0, dense_threshold=0)]
+
+
+@pytest.mark.parametrize("fixture,mode", [("g8_traj_mini_00.npz", m) for m in STEP_MODES] +
+                         [("g8_traj_mini_05.npz", dict()), ("g8_traj_aisle_default.npz", dict()),
+                          ("g8_traj_aisle_default.npz", dict(defer=0))],
+                         ids=lambda v: v[8:-4] if isinstance(v, str) else ("-".join("%s%d" % (k[:4], x) for k, x in sorted(v.items())) or "default"))
+def test_batch_vs_oracle_multi_step(torch_cuda, oracle, fixture, mode):
     """4096 envs, 40 steps, auto-reset, on-device Philox noise (its normals are read back and replayed through the
-    oracle): exact done / collided / target_idx, state within ATOL."""
+    oracle): exact done / collided / target_idx, state within ATOL -- through every execution path of the step
+    (two-kernel deferral, in-kernel cooperative / per-thread exact rasteriser, distance field on / off)."""
     torch = torch_cuda
     g = load(fixture)
     n, steps = 4096, 40
     rng = np.random.RandomState(7)
     env = env_from_traj(g, fixture, n_envs=n, auto_reset=True, seed=123)
+    env.set_tuning(**mode)
     p = oracle_params_for(oracle, fixture)
     ref = oracle.OracleBatch(p, n, g["costmap"], g["origin"], float(g["resolution"]), g["path"])
     ref.reset_from_paths()
