@@ -1,0 +1,123 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every symbol include/bcplan.h declares,
+the API mirror types behave like the reference's, reset-time host logic matches the oracle/golden data, and the
+product refuses to run without a GPU (no silent fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from bc_gym_planning_env_amd import _lib, build
+    build.build()  # hipcc cross-compiles gfx950 without a GPU
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "bcplan.h")).read()
+    declared = set(re.findall(r"\b(bcp_[a-z_0-9]+)\s*\(", header))
+    declared -= {"bcp_handle"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.bcp_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors must have the C layout (hipcc and ctypes agree on sizes through a tiny probe of offsets)."""
+    import ctypes as C
+    from bc_gym_planning_env_amd import _lib
+    assert C.sizeof(_lib.BcpParams) == 8 * 4 + 32 * 2 * 8 + 7 * 8 + 6 * 8 + 3 * 8
+    assert C.sizeof(_lib.BcpState) == 11 * 8
+    assert C.sizeof(_lib.BcpStepIO) == 7 * 8
+    assert _lib.BcpParams.verts.offset == 32 and _lib.BcpParams.dt.offset == 32 + 512
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a GPU the product must refuse to run: no CPU fallback, no oracle behind the scenes."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import ctypes as C
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams, _lib, robots
+    with pytest.raises(RuntimeError):
+        BatchedPlanEnv(CostMap2D(np.zeros((16, 16), np.uint8), 0.03, np.zeros(2)), np.array([[0., 0, 0], [1., 0, 0]]))
+    # and the C ABI itself reports BCP_E_NO_DEVICE
+    lib = _lib.load()
+    p = robots.make_bcp_params(EnvParams(), 'industrial_tricycle_v1', None)
+    h = C.c_void_p()
+    rc = lib.bcp_create(C.byref(p), 4, 0, 0, C.byref(h))
+    assert rc == _lib.E_NO_DEVICE
+    assert b"no CPU path" in lib.bcp_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "bc_gym_planning_env_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "bcp_oracle" not in text, f
+
+
+def test_refine_path_and_initial_state_match_reference_fixtures(oracle, golden_dir):
+    """host_init (reset-time numpy logic) against what the reference produced for the recorded envs."""
+    from bc_gym_planning_env_amd import host_init
+    from bc_gym_planning_env_amd.api import RewardParams
+    g = np.load(os.path.join(golden_dir, "g8_traj_mini_00.npz"))
+    path = g["path"]
+    # the recorded path is already refined: refining its two end points again must reproduce it
+    coarse = np.array([path[0], path[-1]])
+    np.testing.assert_array_equal(host_init.refine_path(coarse, 0.05), path)
+    md, ti = host_init.initial_reward_state(path, RewardParams(0.2, np.pi / 8))
+    assert (md, ti) == (float(g["init_min_dist"]), int(g["init_target_idx"]))
+    assert (md, ti) == oracle.initial_reward_state(path, 0.2, np.pi / 8)
+    ga = np.load(os.path.join(golden_dir, "g8_traj_aisle_default.npz"))
+    md, ti = host_init.initial_reward_state(ga["path"], RewardParams(1.0, np.pi / 2))
+    assert (md, ti) == (float(ga["init_min_dist"]), int(ga["init_target_idx"]))
+    with pytest.raises(ValueError):
+        host_init.initial_reward_state(path[:3], RewardParams(1.0, np.pi))
+
+
+def test_time_table_is_running_sum(golden_dir):
+    from bc_gym_planning_env_amd import host_init
+    g = np.load(os.path.join(golden_dir, "g8_traj_mini_nonoise_40.npz"))
+    t = host_init.time_table(0.05, 1300)
+    np.testing.assert_array_equal(t[1:1251], g["time"])
+
+
+def test_api_types_mirror_reference_semantics():
+    from bc_gym_planning_env_amd import (Action, ContinuousRewardProviderState, CostMap2D, EnvParams, RewardParams,
+                                         TricycleRobotState)
+    from bc_gym_planning_env_amd.api import Box, seed_action_space
+    p = EnvParams()
+    assert (p.dt, p.resolution, p.iteration_timeout, p.path_delta) == (0.05, 0.03, 1200, 0.05)
+    assert p.reward_provider_params == RewardParams(1.0, np.pi / 2, 0.0)
+    with pytest.raises(Exception):
+        p.dt = 1.0  # frozen, like the reference
+    a = Action.from_cmds(0.3, -0.2)
+    assert a == Action(command=np.array([0.3, -0.2])) and a != Action(command=np.array([0.3, 0.2]))
+    cm = CostMap2D(np.zeros((4, 5), np.uint8), 0.03, np.array([1., 2.]))
+    assert not cm.get_origin().flags.writeable and cm == cm.copy()
+    s = TricycleRobotState(x=1., y=2., angle=3., wheel_angle=0.5)
+    assert s.get_pose() == (1., 2., 3.) and list(s.to_numpy_array()) == [1., 2., 3., 0., 0., 0.5]
+    rps = ContinuousRewardProviderState(0.5, np.zeros((5, 3)), 5)
+    assert rps.done() and len(rps.current_path()) == 0
+    with pytest.raises(ValueError):
+        rps.current_goal_pose()
+    box = Box(np.array([np.pi / 30, -np.pi / 2]), np.array([np.pi / 6, np.pi / 2]))
+    seed_action_space(0)
+    act = box.sample()
+    assert act.command.dtype == np.float32 and box.contains(act.command)
+    # same stream as the reference's module RandomState(0): first uniform pair
+    r = np.random.RandomState(0).uniform(low=box.low, high=box.high, size=(2,)).astype(np.float32)
+    np.testing.assert_array_equal(act.command, r)
+
+
+def test_env_block_partition():
+    from bc_gym_planning_env_amd.distributed import env_block
+    for n, w in ((65536 * 8, 8), (10, 3), (7, 8)):
+        blocks = [env_block(n, r, w) for r in range(w)]
+        assert sum(c for _, c in blocks) == n
+        assert all(blocks[r][0] + blocks[r][1] == blocks[r + 1][0] for r in range(w - 1))
