@@ -392,9 +392,7 @@ class BatchedPlanEnv(object):
         if len(bad):
             raise Exception("Path has missing/corrupted angle data at env indices: %s" % bad.cpu().numpy())
 
-    def time_steps(self, actions, steps, noise_z=None):
-        """Average device time (ms) of one fused step launch over `steps` launches, measured with HIP events on the
-        launch stream (bench.py's roofline.achieved)."""
+    def _timing_io(self, actions, noise_z):
         a = _as_device_actions(actions, self.n_envs, self.device)
         io = _lib.BcpStepIO()
         io.actions = a.data_ptr()
@@ -404,9 +402,22 @@ class BatchedPlanEnv(object):
             io.noise_z = noise_z.data_ptr()
         io.reward, io.done = self.reward.data_ptr(), self.done.data_ptr()
         io.collided_now, io.err = self.collided_now.data_ptr(), self.err.data_ptr()
+        return a, io, flags
+
+    def time_steps(self, actions, steps, noise_z=None):
+        """Average device time (ms) of one step over `steps` back-to-back steps, measured with HIP events on the
+        launch stream."""
+        a, io, flags = self._timing_io(actions, noise_z)
         ms = C.c_float()
         _lib.check(self._lib.bcp_time_steps(self._h, C.byref(io), flags, int(steps), self._stream(), C.byref(ms)))
         return ms.value
+
+    def time_step_kernels(self, actions, steps, noise_z=None):
+        """(step_kernel ms, step_pending_kernel ms): average launch durations, HIP events around each launch."""
+        a, io, flags = self._timing_io(actions, noise_z)
+        ms = (C.c_float * 2)()
+        _lib.check(self._lib.bcp_time_step_kernels(self._h, C.byref(io), flags, int(steps), self._stream(), ms))
+        return ms[0], ms[1]
 
     def render(self, mode='human'):
         raise NotImplementedError("rendering is out of scope of the batched step path")

@@ -188,6 +188,11 @@ int bcp_world_to_pixel(bcp_handle *h, const double *xy, int64_t n, const double 
  * returns the average kernel-launch duration in milliseconds (synchronises).  Used by bench.py for
  * roofline.achieved. */
 int bcp_time_steps(bcp_handle *h, const bcp_step_io *io, uint32_t flags, int32_t steps, void *stream, float *avg_ms);
+/* Per-kernel split of a step: kernel_ms[0] = average duration of step_kernel (a loop of step_kernel-only launches
+ * between two events), kernel_ms[1] = average full step minus kernel_ms[0], i.e. step_pending_kernel plus the launch
+ * boundary (0 when the step runs as a single kernel).  Advances the envs by `steps` steps. */
+int bcp_time_step_kernels(bcp_handle *h, const bcp_step_io *io, uint32_t flags, int32_t steps, void *stream,
+                          float *kernel_ms);
 
 #ifdef __cplusplus
 }
