@@ -38,26 +38,41 @@ struct CullDesc {
 
 enum { kFree = 0, kHit = 1, kAmbiguous = 2 };
 
-__device__ __forceinline__ int classify(const CullDesc& C, int rows, int cols, int px, int py, double c, double s)
+// outer test: kFree, or kAmbiguous when a lethal cell may touch the footprint
+__device__ __forceinline__ int classify_outer(const CullDesc& C, int rows, int cols, int px, int py, double c, double s)
 {
     // the whole kernel image misses the map -> nothing to collide with (env.py:483-484 drops off-map cells)
     if (px + C.reach < 0 || px - C.reach >= cols || py + C.reach < 0 || py - C.reach >= rows) return kFree;
     if (!C.on) return kAmbiguous;
     const double ay_c = C.axis_y * c, ay_s = C.axis_y * s;
     const uint8_t* base = C.edt + (int64_t)(py + C.pad) * C.width + (px + C.pad);
-    // all lookups are issued back to back (no short-circuit), so their latencies overlap
-    int near_out = 0, hit_in = 0;
+    int near_out = 0;  // all lookups are issued back to back (no short-circuit), so their latencies overlap
     for (int i = 0; i < C.n_out; ++i) {
         const int du = (int)rint(C.out_x[i] * c - ay_s), dv = (int)rint(C.out_x[i] * s + ay_c);
         near_out |= (int)base[dv * C.width + du] < C.t_out;
     }
+    return near_out ? kAmbiguous : kFree;
+}
+
+// inner test for a pose the outer test could not clear: true => certainly colliding
+__device__ __forceinline__ bool classify_inner_hit(const CullDesc& C, int px, int py, double c, double s)
+{
+    if (!C.on) return false;
+    const double ay_c = C.axis_y * c, ay_s = C.axis_y * s;
+    const uint8_t* base = C.edt + (int64_t)(py + C.pad) * C.width + (px + C.pad);
+    int hit_in = 0;
     for (int j = 0; j < C.n_in; ++j) {
         const int du = (int)rint(C.in_x[j] * c - ay_s), dv = (int)rint(C.in_x[j] * s + ay_c);
         hit_in |= (int)base[dv * C.width + du] <= C.t_in[j];
     }
-    if (!near_out) return kFree;
-    const bool hit = hit_in != 0;
-    return hit ? kHit : kAmbiguous;
+    return hit_in != 0;
+}
+
+__device__ __forceinline__ int classify(const CullDesc& C, int rows, int cols, int px, int py, double c, double s)
+{
+    const int cls = classify_outer(C, rows, cols, px, py, c, s);
+    if (cls != kAmbiguous) return cls;
+    return classify_inner_hit(C, px, py, c, s) ? kHit : kAmbiguous;
 }
 
 // ---- wave helpers -------------------------------------------------------------------------------------
@@ -123,7 +138,8 @@ __device__ __forceinline__ bool coop_raster(const DevParams& P, LdsF64 qverts_ld
     const int up = __shfl(u, prev), vp = __shfl(v, prev);
     const bool owner = lane < K;
     const int vmin = wave_min_i(owner ? v : 0x7fffffff), vmax = wave_max_i(owner ? v : -0x7fffffff);
-    const int umin = wave_min_i(owner ? u : 0x7fffffff);
+    const int umin = wave_min_i(owner ? u : 0x7fffffff), umax = wave_max_i(owner ? u : -0x7fffffff);
+    sink.extent(umin, umax);
     EdgeRegs E;
     {
         // span edge (CollectPolyEdges): top = end with the smaller y
@@ -149,8 +165,10 @@ __device__ __forceinline__ bool coop_raster(const DevParams& P, LdsF64 qverts_ld
         E.sy = sy;
         E.dx = dx;
         E.dy = owner ? dy : -1;  // dy < 0: inert
+        // floor(2^32 / D) + 1 through an fp64 quotient: exact, because 2^32 / D is either an integer (D a power of
+        // two) or at least 1/D >= 2^-9 away from one, far more than the quotient's rounding error (2^-21)
         const uint32_t D = 2u * (uint32_t)(dy > 0 ? dy : 1);
-        E.inv = (uint32_t)(0x100000000ull / D) + 1u;
+        E.inv = (uint32_t)(4294967296.0 / (double)D) + 1u;
     }
     const int ubase = umin;  // bit 0 of the row masks <-> centred column umin
 
@@ -160,8 +178,11 @@ __device__ __forceinline__ bool coop_raster(const DevParams& P, LdsF64 qverts_ld
         uint32_t cov_or[NW], cov_xor[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) cov_or[w] = cov_xor[w] = 0;
+        if (!sink.chunk_matters(y, valid)) continue;  // no lethal cell on any row of this chunk
         for (int e = 0; e < K; ++e) {
             const int ey0 = bcast_i(E.y0, e), ey1 = bcast_i(E.y1, e);
+            // rows an edge can touch: [y0, y1] for the outline, [y0, y1) for the spans (horizontal: y0 == y1)
+            if (ey1 < ybase || ey0 > ybase + 63) continue;
             const int sy = bcast_i(E.sy, e), sx = bcast_i(E.sx, e);
             const int dx = bcast_i(E.dx, e), dy = bcast_i(E.dy, e), ystep = bcast_i(E.ystep, e);
             // SPANS: crossing of the active edge, parity mask starts one past floor(x_e)
@@ -229,6 +250,34 @@ struct CoopCollisionSink {
     {
         return __any(rows_hit(y, valid, cover, ubase));
     }
+    // does any row of the chunk hold a lethal cell in the columns the kernel image can cover?
+    int c_lo, c_hi;  // map columns of the image: px + umin .. px + umax
+    __device__ __forceinline__ void extent(int umin, int umax)
+    {
+        c_lo = px + umin;
+        c_hi = px + umax;
+    }
+    __device__ __forceinline__ bool chunk_matters(int y, bool valid) const
+    {
+        const int r = py + y;
+        bool any = false;
+        if (valid && (unsigned)r < (unsigned)n_rows) {
+            const int a = max(c_lo, 0), b = min(c_hi, n_cols - 1);
+            if (a <= b) {
+                const int w0 = a >> 5, w1 = b >> 5;
+                const uint32_t m0 = 0xFFFFFFFFu << (a & 31), m1 = 0xFFFFFFFFu >> (31 - (b & 31));
+                uint32_t acc = 0;
+                for (int w = w0; w <= w1; ++w) {
+                    uint32_t v = words[r * wpr + w];
+                    if (w == w0) v &= m0;
+                    if (w == w1) v &= m1;
+                    acc |= v;
+                }
+                any = acc != 0;
+            }
+        }
+        return __any(any);
+    }
 };
 
 // exact pose_collides for ONE pose, all 64 lanes cooperating; returns a wave-uniform verdict.
@@ -238,10 +287,10 @@ __device__ __forceinline__ bool coop_collides(const DevParams& P, LdsF64 qverts_
                               int py, WordPtr words, int rows, int cols, int wpr, bool wide)
 {
     if (!wide) {
-        CoopCollisionSink<3, WordPtr> sink{words, rows, cols, wpr, px, py};
+        CoopCollisionSink<3, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
         return coop_raster<3>(P, qverts_lds, c, s, sink);
     }
-    CoopCollisionSink<8, WordPtr> sink{words, rows, cols, wpr, px, py};
+    CoopCollisionSink<8, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
     return coop_raster<8>(P, qverts_lds, c, s, sink);
 }
 

@@ -481,8 +481,9 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
 }
 
 // Kernel 1 of a step: robot model + collision for every env.  With a distance field (shared map) a pose is
-// classified in O(1); the few undecided envs are parked in `pending` for kernel 2 and everything else is finished
-// here.  Without a distance field the exact rasterisers run in place (collides_wave).
+// cleared in O(1) by the outer test; the few envs it cannot clear are finished optimistically ("free") AND parked in
+// `pending`, and kernel 2 redoes those that really collide.  Without a distance field the exact rasterisers run in
+// place (collides_wave).
 __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
 {
     const DevParams& P = a.P;
@@ -549,17 +550,15 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
         }
         const int px = (int)rint((r.p.x - ox) * a.map.inv_res);  // world_to_pixel
         const int py = (int)rint((r.p.y - oy) * a.map.inv_res);
-        const int cls = classify(a.cull, a.map.rows, a.map.cols, px, py, cos(r.p.th), sin(r.p.th));
-        if (cls == kAmbiguous) {
-            if (active) {
-                const int slot = atomicAdd(a.pending_count, 1);
-                q.env_lo = (int32_t)(uint32_t)i;
-                q.env_hi = (int32_t)(i >> 32);
-                a.pending[slot] = q;
-            }
-            return;  // kernel 2 finishes this env
+        const int cls = classify_outer(a.cull, a.map.rows, a.map.cols, px, py, cos(r.p.th), sin(r.p.th));
+        if (cls == kAmbiguous && active) {
+            // Undecided: park the pre-verdict state for kernel 2 and carry on as if the pose were free, which it is
+            // for nearly every parked env; kernel 2 redoes the finalisation of the few that do collide.
+            const int slot = atomicAdd(a.pending_count, 1);
+            q.env_lo = (int32_t)(uint32_t)i;
+            q.env_hi = (int32_t)(i >> 32);
+            a.pending[slot] = q;
         }
-        hit = cls == kHit;
     } else {
         hit = collides_wave(P, a.map, a.cull, L, a.exact_mode, a.dense_threshold, a.wide != 0, active, i, r.p.x, r.p.y,
                             r.p.th);
@@ -568,8 +567,8 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     finalize_env(a, i, q, hit);
 }
 
-// Kernel 2 of a step: one wavefront per undecided env.  All 64 lanes rasterise the footprint together
-// (coop_collides); lane 0 then finishes the env exactly as kernel 1 would have.
+// Kernel 2 of a step: one wavefront per parked env.  Inner distance-field test, then all 64 lanes rasterise the
+// footprint together (coop_collides); on a collision lane 0 redoes the env's finalisation from the parked state.
 __global__ void __launch_bounds__(kBlock) step_pending_kernel(const StepArgs a)
 {
     const DevParams& P = a.P;
@@ -588,9 +587,11 @@ __global__ void __launch_bounds__(kBlock) step_pending_kernel(const StepArgs a)
         const int px = (int)rint((q.r.p.x - ox) * a.map.inv_res);
         const int py = (int)rint((q.r.p.y - oy) * a.map.inv_res);
         const uint32_t* words = a.map.bits + (a.map.shared ? 0 : i * a.map.env_stride);
-        const bool hit = coop_collides(P, qv, cos(q.r.p.th), sin(q.r.p.th), px, py, words, a.map.rows, a.map.cols,
-                                       a.map.wpr, a.wide != 0);
-        if (threadIdx.x == 0) finalize_env(a, i, q, hit);
+        const double c = cos(q.r.p.th), s = sin(q.r.p.th);
+        bool hit = classify_inner_hit(a.cull, px, py, c, s);  // wave-uniform: every lane holds the same pose
+        if (!hit) hit = coop_collides(P, qv, c, s, px, py, words, a.map.rows, a.map.cols, a.map.wpr, a.wide != 0);
+        // kernel 1 already finished this env as "free"; only a collision changes anything
+        if (hit && threadIdx.x == 0) finalize_env(a, i, q, true);
     }
 }
 
@@ -666,6 +667,8 @@ __global__ void __launch_bounds__(kBlock) pose_collides_kernel(DevParams P, MapD
 struct MaskRowSink {
     uint8_t* img;
     int side, hx, hy;
+    __device__ __forceinline__ void extent(int, int) {}
+    __device__ __forceinline__ bool chunk_matters(int, bool) const { return true; }
     __device__ __forceinline__ bool rows(int y, bool valid, const uint32_t cover[8], int ubase) const
     {
         const int ky = y + hy;
