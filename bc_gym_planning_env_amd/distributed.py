@@ -24,12 +24,14 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("BCP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kwargs = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             kwargs["device_id"] = torch.device("cuda", local_rank)
+            # the host driver of this pool only supports dmabuf IPC (RCCL / CUDA-tensor sharing across processes)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local_rank
 
@@ -49,5 +51,52 @@ class DoneGather(object):
         if self.world == 1:
             self.out.copy_(done_local)
             return None if async_op else self.out
+        if self.out.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal path (several ranks sharing one GPU): gloo gathers on the host
+            host = torch.empty(self.out.shape, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, done_local.cpu(), group=self.group)
+            self.out.copy_(host)
+            return None if async_op else self.out
         work = dist.all_gather_into_tensor(self.out, done_local, group=self.group, async_op=async_op)
         return work if async_op else self.out
+
+    # ---- pipelined form: the gather of step t overlaps the kernels of step t+1 -------------------------------
+    def launch(self, done_local):
+        """Start gathering this step's done mask without stalling the compute stream.  The mask is first copied to
+        one of two staging buffers (the step kernel overwrites `done_local` next step), then all-gathered
+        asynchronously; the result of THIS call is what `result()` returns after the next `launch()` / `flush()`."""
+        if not hasattr(self, "_stage"):
+            self._stage = [torch.empty_like(done_local) for _ in range(2)]
+            self._outs = [self.out, torch.empty_like(self.out)]
+            self._work = [None, None]
+            self._k = 0
+        k = self._k
+        if self._work[k] is not None:  # buffer k was used two launches ago: its gather must have completed
+            self._work[k].wait()
+            self._work[k] = None
+        self._stage[k].copy_(done_local)
+        if self.world == 1:
+            self._outs[k].copy_(self._stage[k])
+        elif self.out.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = torch.empty(self.out.shape, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, self._stage[k].cpu(), group=self.group)
+            self._outs[k].copy_(host)
+        else:
+            self._work[k] = dist.all_gather_into_tensor(self._outs[k], self._stage[k], group=self.group, async_op=True)
+        self._last = k
+        self._k = 1 - k
+        return k
+
+    def result(self):
+        """Global done mask of the most recent launch() (waits for its gather)."""
+        k = self._last
+        if self._work[k] is not None:
+            self._work[k].wait()
+            self._work[k] = None
+        return self._outs[k]
+
+    def flush(self):
+        for k in range(2):
+            if getattr(self, "_work", [None, None])[k] is not None:
+                self._work[k].wait()
+                self._work[k] = None

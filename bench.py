@@ -87,7 +87,7 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
                              % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    device = local_rank
+    device = local_rank % max(1, torch.cuda.device_count())  # (rehearsals may put several ranks on one GPU)
     torch.cuda.set_device(device)
     n = args.envs_per_gpu
     env, g = make_env(n, device, env_id_base=rank * n, seed=2024)
@@ -100,10 +100,11 @@ def main():
     def one_step(k):
         env.step(pool[k % 16])
         if gather is not None:
-            gather(env.done)
+            gather.launch(env.done)  # ONE all-gather per step, pipelined: it overlaps the next step's kernels
 
     def barrier():
         if world > 1:
+            gather.flush()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -130,7 +131,7 @@ def main():
     elapsed = time.perf_counter() - t0
     stream_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=env.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=env.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     env.check_errors()

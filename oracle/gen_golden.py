@@ -394,6 +394,62 @@ def gen_trajectories():
         save("g8_traj_aisle_%s.npz" % tag, **rec)
 
 
+def gen_diffdrive_trajectories():
+    """C2 shape: PlanEnv hard-codes the tricycle, so the diff-drive robot is driven the way SURVEY 8(a9) says:
+    _env_step(costmap, DiffDriveRobot, dt, action) (envs/base/env.py:442-461) + the reward provider, by hand, with
+    the bookkeeping of PlanEnv._resolve_state_transition / step (env.py:334-398)."""
+    from bc_gym_planning_env.envs.base.env import _env_step
+    from bc_gym_planning_env.envs.base.action import Action
+    from bc_gym_planning_env.envs.base.reward import ContinuousRewardProvider, RewardParams
+    from bc_gym_planning_env.robot_models.differential_drive import DiffDriveRobot
+    from bc_gym_planning_env.robot_models.robot_dimensions_examples import get_dimensions_example
+    from bc_gym_planning_env.utilities.path_tools import refine_path
+    for seed, toward_wall in ((0, False), (5, False), (3, True), (9, True)):
+        env = make_mini_env(seed, resolution=5.5 / 64)
+        costmap = env._env._state.costmap
+        path = np.array(env._env._state.original_path)
+        rng = np.random.RandomState(900 + seed)
+        robot = DiffDriveRobot(dimensions=get_dimensions_example('industrial_diffdrive_v1'), noise_parameters=None)
+        rp = RewardParams(spatial_precision=0.2, angular_precision=np.pi / 8)
+        prov = ContinuousRewardProvider(params=rp)
+        prov.set_state(ContinuousRewardProvider.generate_initial_state(path, rp))
+        init = prov.get_state()
+        robot.set_pose(*path[0])
+        if toward_wall:  # start 1.4 m in front of a lethal cell, heading at it: collisions and rollbacks for sure
+            ly, lx = np.nonzero(costmap.get_data() == 254)
+            k = len(ly) // 2
+            wx = costmap.get_origin()[0] + lx[k] * costmap.get_resolution()
+            wy = costmap.get_origin()[1] + ly[k] * costmap.get_resolution()
+            th0 = 0.3 + seed
+            robot.set_pose(wx - 1.4 * np.cos(th0), wy - 1.4 * np.sin(th0), np.arctan2(np.sin(th0), np.cos(th0)))
+        start_state = dd_state_vec(robot.get_state())
+
+        class S(object):
+            pass
+        T = 500
+        act = np.zeros((T, 2)); st = np.zeros((T, 7)); rew = np.zeros(T); done = np.zeros(T, np.uint8)
+        coll = np.zeros(T, np.uint8); tidx = np.zeros(T, np.int32); mind = np.zeros(T)
+        collided = False
+        for t in range(T):
+            # (v, w): mostly forward, float32-representable values handed over as float64 (see gen_robot_steps)
+            a = np.array([rng.uniform(0.1, 0.6), rng.uniform(-1.2, 1.2) * (0.15 if toward_wall else 1.0)])
+            a = a.astype(np.float32).astype(np.float64)
+            act[t] = a
+            hit = _env_step(costmap, robot, 0.05, Action(command=a))
+            collided = collided or hit
+            s = S(); s.pose = robot.get_pose()
+            rew[t] = prov.reward(s)
+            ps = prov.get_state()
+            st[t] = dd_state_vec(robot.get_state())
+            done[t] = ps.done() or (t + 1 >= 1200) or collided
+            coll[t], tidx[t], mind[t] = collided, ps.target_idx, ps.min_spat_dist_so_far
+        save("g8dd_traj_mini64_%02d.npz" % seed, costmap=costmap.get_data().copy(), origin=np.array(costmap.get_origin()),
+             resolution=np.float64(costmap.get_resolution()), path=path, init_target_idx=np.int32(init.target_idx),
+             init_min_dist=np.float64(init.min_spat_dist_so_far), start_state=start_state, actions=act, states=st, reward=rew, done=done,
+             collided=coll, target_idx=tidx, min_dist=mind)
+        print("   dd traj seed %d: collided at %s, final target %d/%d" % (seed, np.nonzero(coll)[0][:1], tidx[-1], len(path)))
+
+
 def gen_kat_collision_table():
     """Inputs of the reference KAT test_costmap_utils.py:251-314 (its 20 expected verdicts are written in the
     test itself and restated in tests/test_oracle_kat.py); here we only store the costmap the reference's own
@@ -418,6 +474,7 @@ def main():
     gen_pose_collides()
     gen_reward()
     gen_kat_collision_table()
+    gen_diffdrive_trajectories()
     gen_trajectories()
 
 

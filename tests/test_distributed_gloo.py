@@ -39,6 +39,14 @@ def _worker(rank, world, port, n_total, out_dir):
     work = gather(done_local, async_op=True)
     work.wait()
     assert torch.equal(gather.out, ((torch.arange(n_total) * 2654435761) % 7 == 0).to(torch.uint8))
+    # pipelined form: results come back one launch late, in order
+    base = ((torch.arange(n_total) * 2654435761) % 7 == 0).to(torch.uint8)
+    for step in range(5):
+        buf = done_local ^ (step & 1)
+        gather.launch(buf)
+        buf.zero_()  # the caller may overwrite its mask right away (the step kernel does)
+        assert torch.equal(gather.result(), base ^ (step & 1)), (rank, step)
+    gather.flush()
     np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([first, count]))
     dist.barrier()
     dist.destroy_process_group()

@@ -213,6 +213,40 @@ def test_full_step_trajectories_vs_reference(torch_cuda, path):
     assert s.current_iter == T and s.robot_collided == bool(g["collided"][-1])
 
 
+import glob as _glob
+DD_TRAJ = sorted(_glob.glob(os.path.join(GOLDEN, "g8dd_traj_*.npz")))
+
+
+@pytest.mark.parametrize("path", DD_TRAJ, ids=[os.path.basename(p)[5:-4] for p in DD_TRAJ])
+def test_diffdrive_trajectories_vs_reference(torch_cuda, path):
+    """C2 shape from the reference itself: DiffDriveRobot through _env_step + reward, 64x64 costmap, noise off."""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    g = np.load(path)
+    res = float(g["resolution"])
+    params = EnvParams(goal_spat_dist=0.2, goal_ang_dist=np.pi / 8, resolution=res, refine_path=False,
+                       robot_name='industrial_diffdrive_v1')
+    env = BatchedPlanEnv(CostMap2D(g["costmap"], res, g["origin"]), g["path"], params, n_envs=1, noise_parameters=None)
+    assert int(env.state.target_idx[0]) == int(g["init_target_idx"])
+    env.state.robot[:, 0] = torch.from_numpy(g["start_state"]).cuda()
+    T = len(g["actions"])
+    actions = torch.from_numpy(g["actions"]).cuda()
+    states = torch.zeros(T, 7, dtype=torch.float64, device="cuda")
+    rew = torch.zeros(T, dtype=torch.float64, device="cuda")
+    done = torch.zeros(T, dtype=torch.uint8, device="cuda")
+    coll = torch.zeros(T, dtype=torch.uint8, device="cuda")
+    tidx = torch.zeros(T, dtype=torch.int32, device="cuda")
+    for t in range(T):
+        _, r, d, _ = env.step(actions[t:t + 1])
+        states[t] = env.state.robot[:, 0]
+        rew[t], done[t], coll[t], tidx[t] = r[0], d[0], env.state.robot_collided[0], env.state.target_idx[0]
+    np.testing.assert_array_equal(done.cpu().numpy(), g["done"])
+    np.testing.assert_array_equal(coll.cpu().numpy(), g["collided"])
+    np.testing.assert_array_equal(tidx.cpu().numpy(), g["target_idx"])
+    np.testing.assert_allclose(states.cpu().numpy()[:, :5], g["states"][:, :5], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(rew.cpu().numpy(), g["reward"], rtol=0, atol=ATOL)
+
+
 def _random_batch(oracle, rng, n, g, name):
     """n envs on the recorded map/path, started from random poses near the path (many collide or progress)."""
     path = g["path"]

@@ -136,3 +136,23 @@ def test_g8_trajectories(oracle, path):
         assert len(g["path"]) - env.target_idx[0] == g["obs_path_len"][t] or env.target_idx[0] >= len(g["path"])
         n_coll += int(env.collided_now[0])
     assert env.err[0] == 0
+
+
+DD_TRAJ = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "g8dd_traj_*.npz")))
+
+
+@pytest.mark.parametrize("path", DD_TRAJ, ids=[os.path.basename(p)[5:-4] for p in DD_TRAJ])
+def test_g8_diffdrive_trajectories(oracle, path):
+    """_env_step with the DiffDriveRobot + reward provider (C2 shape: 64x64 costmap, res 5.5/64, noise off)."""
+    g = np.load(path)
+    p = oracle.make_params("diffdrive", spatial_precision=0.2, angular_precision=np.pi / 8)
+    env = oracle.OracleBatch(p, 1, g["costmap"], g["origin"], float(g["resolution"]), g["path"])
+    env.reset_from_paths()
+    assert env.target_idx[0] == int(g["init_target_idx"]) and env.min_dist[0] == float(g["init_min_dist"])
+    for f in range(7):
+        env.st[f][0] = g["start_state"][f]
+    for t in range(len(g["actions"])):
+        env.step(g["actions"][t][None])
+        np.testing.assert_array_equal([env.st[f][0] for f in range(7)], g["states"][t], err_msg="step %d" % t)
+        assert (env.reward[0], env.done[0], env.collided[0], env.target_idx[0], env.min_dist[0]) == \
+            (g["reward"][t], g["done"][t], g["collided"][t], g["target_idx"][t], g["min_dist"][t]), t
