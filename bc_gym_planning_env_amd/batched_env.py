@@ -141,11 +141,13 @@ class BatchedPlanEnv(object):
         dict alpha1..alpha6
     :param auto_reset bool: restore an env's initial state right after the step that finished it
     :param env_id_base int: global index of env 0 (rank * n_envs when sharded over GPUs); keys the noise stream
+    :param template_of_env: optional int array [n_envs]; `costmap` and `path` are then lists of T templates and env i
+        gets a PRIVATE copy of costmap[template_of_env[i]] / path[template_of_env[i]] (built on the device)
     """
 
     def __init__(self, costmap, path, params=None, n_envs=1, device=0, robot_name=None, noise_parameters='planenv',
                  auto_reset=False, env_id_base=0, seed=0, footprint_scale=1.0, dynamic_model=True,
-                 model_front_column_pid=True):
+                 model_front_column_pid=True, template_of_env=None):
         params = EnvParams() if params is None else params
         if params.pose_delay or params.control_delay or params.state_delay:
             raise NotImplementedError("pose/control/state delays > 0 are not supported by the batched step")
@@ -188,8 +190,12 @@ class BatchedPlanEnv(object):
         self.envs = _EnvViews(self)
         self._keep = {}  # device buffers the library holds pointers to
 
-        self._set_costmaps(costmap)
-        self._set_paths(path)
+        self._template_of_env = None if template_of_env is None else np.asarray(template_of_env, dtype=np.int64)
+        if self._template_of_env is not None:
+            self._set_from_templates(list(costmap), list(path))
+        else:
+            self._set_costmaps(costmap)
+            self._set_paths(path)
         self._bind(self.state, self._lib.bcp_bind_state)
         self._initial_state = self._make_initial_state()
         self._bind(self._initial_state, self._lib.bcp_bind_initial_state)
@@ -246,6 +252,40 @@ class BatchedPlanEnv(object):
                                      res, torch.from_numpy(vr).to(self.device), torch.from_numpy(vc).to(self.device))
         self.resolution = res
 
+    def _set_from_templates(self, costmaps, paths):
+        """Private per-env costmaps / paths expanded on the device from a few templates."""
+        n, dev = self.n_envs, self.device
+        idx = torch.from_numpy(self._template_of_env).to(dev)
+        assert idx.numel() == n and int(idx.max()) < len(costmaps) == len(paths)
+        res = float(costmaps[0].get_resolution())
+        rows = max(c.get_data().shape[0] for c in costmaps)
+        cols = max(c.get_data().shape[1] for c in costmaps)
+        t_data = np.zeros((len(costmaps), rows, cols), dtype=np.uint8)
+        t_shape = np.zeros((len(costmaps), 2), dtype=np.int32)
+        t_org = np.zeros((len(costmaps), 2), dtype=np.float64)
+        for t, c in enumerate(costmaps):
+            d = c.get_data()
+            t_data[t, :d.shape[0], :d.shape[1]] = d
+            t_shape[t] = d.shape
+            t_org[t] = c.get_origin()
+        data = torch.from_numpy(t_data).to(dev)[idx].contiguous()
+        shape = torch.from_numpy(t_shape).to(dev)[idx]
+        self._costmaps, self._shared_map = costmaps, False
+        self.set_costmap_tensors(data, torch.from_numpy(t_org).to(dev)[idx].contiguous(), res,
+                                 shape[:, 0].contiguous(), shape[:, 1].contiguous())
+        refine = (lambda p: host_init.refine_path(p, self.params.path_delta)) if self.params.refine_path else (lambda p: p)
+        tp = [np.ascontiguousarray(refine(np.asarray(p)), dtype=np.float64) for p in paths]
+        max_len = max(len(p) for p in tp)
+        buf = np.zeros((len(tp), max_len, 3), dtype=np.float64)
+        for t, p in enumerate(tp):
+            buf[t, :len(p)] = p
+        self._paths, self._shared_path = tp, False
+        pdev = torch.from_numpy(buf).to(dev)[idx].contiguous()
+        lens = torch.from_numpy(np.array([len(p) for p in tp], dtype=np.int32)).to(dev)[idx].contiguous()
+        self._keep.update(path=pdev, lens=lens)
+        _lib.check(self._lib.bcp_set_paths(self._h, pdev.data_ptr(), lens.data_ptr(), max_len, 0, self._stream()))
+        torch.cuda.current_stream(dev).synchronize()
+
     def set_costmap_tensors(self, data, origins, resolution, valid_rows=None, valid_cols=None):
         """Private costmaps straight from device tensors: data uint8 [N, rows, cols], origins float64 [N, 2]."""
         n = self.n_envs
@@ -300,6 +340,12 @@ class BatchedPlanEnv(object):
             m0, t0 = host_init.initial_reward_state(p, rp)
             robot[0:3, :] = p[0][:, None]
             md[:], ti[:] = m0, t0
+        elif self._template_of_env is not None:
+            per = [host_init.initial_reward_state(p, rp) for p in self._paths]
+            tix = self._template_of_env
+            md[:] = np.array([m for m, _ in per])[tix]
+            ti[:] = np.array([t for _, t in per])[tix]
+            robot[0:3, :] = np.stack([p[0] for p in self._paths])[tix].T
         else:
             for i, p in enumerate(self._paths):
                 md[i], ti[i] = host_init.initial_reward_state(p, rp)
@@ -317,9 +363,13 @@ class BatchedPlanEnv(object):
 
     # ------------------------------------------------------------------ per-env lookups
     def path_of(self, i):
+        if self._template_of_env is not None:
+            return self._paths[self._template_of_env[i]]
         return self._paths[0] if self._shared_path else self._paths[i]
 
     def costmap_of(self, i):
+        if self._template_of_env is not None:
+            return self._costmaps[self._template_of_env[i]]
         if self._shared_map or len(self._costmaps) == 1:
             return self._costmaps[0]
         return self._costmaps[i]

@@ -4,8 +4,12 @@ backend is "nccl"; "gloo" on CPU for tests).  The reference has no counterpart: 
 """
 import os
 
-import torch
-import torch.distributed as dist
+# the host driver of this pool only supports dmabuf IPC (RCCL / CUDA-tensor sharing across processes); must be in
+# the environment before the HIP runtime initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def env_block(n_total, rank, world_size):
@@ -30,8 +34,6 @@ def init_from_env(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             kwargs["device_id"] = torch.device("cuda", local_rank)
-            # the host driver of this pool only supports dmabuf IPC (RCCL / CUDA-tensor sharing across processes)
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local_rank
 
