@@ -25,9 +25,10 @@ constexpr int kMaxSamples = 8;
 
 // distance-field description (kernel argument)
 struct CullDesc {
-    const uint8_t* edt;   // [(rows + 2 pad) * (cols + 2 pad)] floor(min(255, distance to nearest lethal cell))
-    int32_t on;           // 0: no distance field (per-env maps) -> every in-map pose is AMBIGUOUS
-    int32_t pad, width;   // padding on each side, padded row width
+    const uint8_t* edt;   // [(rows + 2 pad) * (cols + 2 pad)] floor(min(clamp, distance to nearest lethal cell))
+    int64_t env_stride;   // bytes per env (0: one field shared by all envs)
+    int32_t on;           // 0: no distance field -> every in-map pose is AMBIGUOUS
+    int32_t pad, width, height;  // padding on each side, padded row width / row count
     int32_t reach;        // any footprint pixel is within `reach` px of the robot pixel (off-map test)
     int32_t n_out, n_in;
     int32_t t_out;        // free  <=>  edt >= t_out at every outer sample
@@ -38,41 +39,71 @@ struct CullDesc {
 
 enum { kFree = 0, kHit = 1, kAmbiguous = 2 };
 
+// distance-field value at padded cell (x, y); `outside` when the cell is not stored (small padding of private maps)
+__device__ __forceinline__ int edt_at(const CullDesc& C, const uint8_t* field, int x, int y, int outside)
+{
+    if ((unsigned)x >= (unsigned)C.width || (unsigned)y >= (unsigned)C.height) return outside;
+    return (int)field[y * C.width + x];
+}
+
 // outer test: kFree, or kAmbiguous when a lethal cell may touch the footprint
-__device__ __forceinline__ int classify_outer(const CullDesc& C, int rows, int cols, int px, int py, double c, double s)
+__device__ __forceinline__ int classify_outer(const CullDesc& C, int64_t env, int rows, int cols, int px, int py, double c,
+                                              double s)
 {
     // the whole kernel image misses the map -> nothing to collide with (env.py:483-484 drops off-map cells)
     if (px + C.reach < 0 || px - C.reach >= cols || py + C.reach < 0 || py - C.reach >= rows) return kFree;
     if (!C.on) return kAmbiguous;
     const double ay_c = C.axis_y * c, ay_s = C.axis_y * s;
-    const uint8_t* base = C.edt + (int64_t)(py + C.pad) * C.width + (px + C.pad);
-    int near_out = 0;  // all lookups are issued back to back (no short-circuit), so their latencies overlap
-    for (int i = 0; i < C.n_out; ++i) {
+    const uint8_t* field = C.edt + env * C.env_stride;
+    // fully unrolled over the (at most kMaxSamples) samples: addresses first, then all loads, then the compares --
+    // so the byte loads are in flight together instead of one L2 round trip per sample
+    int idx[kMaxSamples];
+#pragma unroll
+    for (int i = 0; i < kMaxSamples; ++i) {
         const int du = (int)rint(C.out_x[i] * c - ay_s), dv = (int)rint(C.out_x[i] * s + ay_c);
-        near_out |= (int)base[dv * C.width + du] < C.t_out;
+        const int x = px + C.pad + du, y = py + C.pad + dv;
+        const bool stored = i < C.n_out && (unsigned)x < (unsigned)C.width && (unsigned)y < (unsigned)C.height;
+        idx[i] = stored ? y * C.width + x : -1;
     }
+    int val[kMaxSamples];
+#pragma unroll
+    for (int i = 0; i < kMaxSamples; ++i) val[i] = idx[i] >= 0 ? (int)field[idx[i]] : (i < C.n_out ? 0 : 255);
+    int near_out = 0;  // a sample that is not stored cannot clear the pose
+#pragma unroll
+    for (int i = 0; i < kMaxSamples; ++i) near_out |= val[i] < C.t_out;
     return near_out ? kAmbiguous : kFree;
 }
 
 // inner test for a pose the outer test could not clear: true => certainly colliding
-__device__ __forceinline__ bool classify_inner_hit(const CullDesc& C, int px, int py, double c, double s)
+__device__ __forceinline__ bool classify_inner_hit(const CullDesc& C, int64_t env, int px, int py, double c, double s)
 {
     if (!C.on) return false;
     const double ay_c = C.axis_y * c, ay_s = C.axis_y * s;
-    const uint8_t* base = C.edt + (int64_t)(py + C.pad) * C.width + (px + C.pad);
-    int hit_in = 0;
-    for (int j = 0; j < C.n_in; ++j) {
+    const uint8_t* field = C.edt + env * C.env_stride;
+    // unrolled like the outer test: all lookups in flight together
+    int idx[kMaxSamples];
+#pragma unroll
+    for (int j = 0; j < kMaxSamples; ++j) {
         const int du = (int)rint(C.in_x[j] * c - ay_s), dv = (int)rint(C.in_x[j] * s + ay_c);
-        hit_in |= (int)base[dv * C.width + du] <= C.t_in[j];
+        const int x = px + C.pad + du, y = py + C.pad + dv;
+        const bool stored = j < C.n_in && (unsigned)x < (unsigned)C.width && (unsigned)y < (unsigned)C.height;
+        idx[j] = stored ? y * C.width + x : -1;
     }
+    int val[kMaxSamples];
+#pragma unroll
+    for (int j = 0; j < kMaxSamples; ++j) val[j] = idx[j] >= 0 ? (int)field[idx[j]] : 255;  // not stored: no verdict
+    int hit_in = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxSamples; ++j) hit_in |= (j < C.n_in) & (val[j] <= C.t_in[j]);
     return hit_in != 0;
 }
 
-__device__ __forceinline__ int classify(const CullDesc& C, int rows, int cols, int px, int py, double c, double s)
+__device__ __forceinline__ int classify(const CullDesc& C, int64_t env, int rows, int cols, int px, int py, double c,
+                                        double s)
 {
-    const int cls = classify_outer(C, rows, cols, px, py, c, s);
+    const int cls = classify_outer(C, env, rows, cols, px, py, c, s);
     if (cls != kAmbiguous) return cls;
-    return classify_inner_hit(C, px, py, c, s) ? kHit : kAmbiguous;
+    return classify_inner_hit(C, env, px, py, c, s) ? kHit : kAmbiguous;
 }
 
 // ---- wave helpers -------------------------------------------------------------------------------------
@@ -123,7 +154,8 @@ struct EdgeRegs {
 //   bool rows(int y /*this lane's centred row*/, bool valid, const uint32_t cover[NW], int ubase /*centred u of bit 0*/)
 // returns a wave-uniform "stop".
 template <int NW, typename RowSink>
-__device__ __forceinline__ bool coop_raster(const DevParams& P, LdsF64 qverts_lds, double c, double s, RowSink& sink)
+__device__ __forceinline__ bool coop_raster(const DevParams& P, LdsF64 qverts_lds, double c, double s, RowSink& sink,
+                                            int first_chunk = 0, int chunk_stride = 1)
 {
     const int K = P.n_verts;
     const int lane = lane_id();
@@ -172,13 +204,14 @@ __device__ __forceinline__ bool coop_raster(const DevParams& P, LdsF64 qverts_ld
     }
     const int ubase = umin;  // bit 0 of the row masks <-> centred column umin
 
-    for (int ybase = vmin; ybase <= vmax; ybase += 64) {
+    // several waves may share one pose: wave w takes the 64-row chunks w, w + chunk_stride, ...
+    for (int ybase = vmin + 64 * first_chunk; ybase <= vmax; ybase += 64 * chunk_stride) {
         const int y = ybase + lane;
         const bool valid = y <= vmax;
         uint32_t cov_or[NW], cov_xor[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) cov_or[w] = cov_xor[w] = 0;
-        if (!sink.chunk_matters(y, valid)) continue;  // no lethal cell on any row of this chunk
+        if (!sink.chunk_matters(y, valid)) continue;  // no lethal cell under the image on any row of this chunk
         for (int e = 0; e < K; ++e) {
             const int ey0 = bcast_i(E.y0, e), ey1 = bcast_i(E.y1, e);
             // rows an edge can touch: [y0, y1] for the outline, [y0, y1) for the spans (horizontal: y0 == y1)
@@ -225,58 +258,45 @@ template <int NW, typename WordPtr>
 struct CoopCollisionSink {
     WordPtr words;
     int n_rows, n_cols, wpr, px, py;
-    __device__ __forceinline__ bool rows_hit(int y, bool valid, const uint32_t cover[NW], int ubase) const
-    {
-        const int r = py + y;
-        const int c0 = px + ubase;     // map column of mask bit 0
-        const int w0 = c0 >> 5;        // arithmetic shift: floor
-        const int sh = c0 & 31;
-        bool hit = false;
-        if (valid && (unsigned)r < (unsigned)n_rows) {
-            // lethal bits of columns c0 .. c0 + 32*NW - 1, re-aligned so that bit 0 <-> column c0
-            uint32_t lo = (unsigned)w0 < (unsigned)wpr ? words[r * wpr + w0] : 0u;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const int wi = w0 + w + 1;
-                const uint32_t hiw = (unsigned)wi < (unsigned)wpr ? words[r * wpr + wi] : 0u;
-                const uint32_t leth = sh ? (lo >> sh) | (hiw << (32 - sh)) : lo;
-                hit = hit || (leth & cover[w]) != 0;
-                lo = hiw;
-            }
-        }
-        return hit;
-    }
-    __device__ __forceinline__ bool rows(int y, bool valid, const uint32_t cover[NW], int ubase) const
-    {
-        return __any(rows_hit(y, valid, cover, ubase));
-    }
-    // does any row of the chunk hold a lethal cell in the columns the kernel image can cover?
-    int c_lo, c_hi;  // map columns of the image: px + umin .. px + umax
+    int c_lo, c_hi;        // map columns of the image: px + umin .. px + umax
+    uint32_t leth[NW];     // this lane's row: lethal bits of map columns c_lo .. c_lo + 32*NW - 1 (bit 0 <-> c_lo)
     __device__ __forceinline__ void extent(int umin, int umax)
     {
         c_lo = px + umin;
         c_hi = px + umax;
     }
-    __device__ __forceinline__ bool chunk_matters(int y, bool valid) const
+    // Loads the lane's row once per chunk; returns whether ANY row of the chunk holds a lethal cell under the image.
+    __device__ __forceinline__ bool chunk_matters(int y, bool valid)
     {
         const int r = py + y;
-        bool any = false;
-        if (valid && (unsigned)r < (unsigned)n_rows) {
-            const int a = max(c_lo, 0), b = min(c_hi, n_cols - 1);
-            if (a <= b) {
-                const int w0 = a >> 5, w1 = b >> 5;
-                const uint32_t m0 = 0xFFFFFFFFu << (a & 31), m1 = 0xFFFFFFFFu >> (31 - (b & 31));
-                uint32_t acc = 0;
-                for (int w = w0; w <= w1; ++w) {
-                    uint32_t v = words[r * wpr + w];
-                    if (w == w0) v &= m0;
-                    if (w == w1) v &= m1;
-                    acc |= v;
-                }
-                any = acc != 0;
-            }
+        const int w0 = c_lo >> 5;  // arithmetic shift: floor
+        const int sh = c_lo & 31;
+        const bool row_ok = valid && (unsigned)r < (unsigned)n_rows;
+        uint32_t raw[NW + 1];
+#pragma unroll
+        for (int w = 0; w <= NW; ++w) {
+            const int wi = w0 + w;
+            raw[w] = (row_ok && (unsigned)wi < (unsigned)wpr) ? words[r * wpr + wi] : 0u;
         }
-        return __any(any);
+        uint32_t any = 0;
+        const int width = c_hi - c_lo + 1;  // columns beyond the image never matter
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            uint32_t v = sh ? (raw[w] >> sh) | (raw[w + 1] << (32 - sh)) : raw[w];
+            const int rem = width - 32 * w;
+            if (rem <= 0) v = 0;
+            else if (rem < 32) v &= 0xFFFFFFFFu >> (32 - rem);
+            leth[w] = v;
+            any |= v;
+        }
+        return __any(any != 0);
+    }
+    __device__ __forceinline__ bool rows(int y, bool valid, const uint32_t cover[NW], int ubase) const
+    {
+        uint32_t acc = 0;  // bit 0 of cover <-> centred column ubase == umin <-> map column c_lo: same alignment
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc |= leth[w] & cover[w];
+        return __any(acc != 0);
     }
 };
 
@@ -284,14 +304,15 @@ struct CoopCollisionSink {
 // `wide`: the kernel image may be wider than 96 px (use the 8-word row masks).
 template <typename WordPtr>
 __device__ __forceinline__ bool coop_collides(const DevParams& P, LdsF64 qverts_lds, double c, double s, int px,
-                              int py, WordPtr words, int rows, int cols, int wpr, bool wide)
+                              int py, WordPtr words, int rows, int cols, int wpr, bool wide, int first_chunk = 0,
+                              int chunk_stride = 1)
 {
     if (!wide) {
         CoopCollisionSink<3, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
-        return coop_raster<3>(P, qverts_lds, c, s, sink);
+        return coop_raster<3>(P, qverts_lds, c, s, sink, first_chunk, chunk_stride);
     }
     CoopCollisionSink<8, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
-    return coop_raster<8>(P, qverts_lds, c, s, sink);
+    return coop_raster<8>(P, qverts_lds, c, s, sink, first_chunk, chunk_stride);
 }
 
 }  // namespace bcp

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -86,14 +87,15 @@ struct bcp_handle {
     size_t path_index_bytes;
     uint8_t* edt;          // owned: distance transform of the shared costmap (padded)
     size_t edt_bytes;
-    int32_t* edt_col;      // owned scratch of the transform
+    uint8_t* edt_col;      // owned scratch of the transform
     size_t edt_col_bytes;
     MapDesc map;
     CullDesc cull;
     PathDesc path;
     DevState st, init;
     void* pending;            // owned: Pending[n]
-    int32_t* pending_count;   // owned: two alternating counters
+    int32_t* pending_count;   // owned: two alternating sets of kShards counters
+    int32_t pending_cap;      // parking slots per shard
     int32_t defer;            // settle undecided envs in a second kernel (shared map with distance field)
     int32_t exact_mode;       // 0 auto, 1 cooperative only, 2 per-thread only
     int32_t dense_threshold;  // auto: more ambiguous lanes than this in a wave -> per-thread rasteriser
@@ -223,7 +225,8 @@ __global__ void path_index_kernel(const double* __restrict__ xyt, const int32_t*
 // LAST reached index is >= target_idx (envs/base/reward.py:234), so indices below target never matter.
 // A way point can only be reached when |x_j - x| and |y_j - y| are both below spatial_precision, so the scan is
 // confined to the index window the two bucket tables allow for this pose (usually a handful of way points).
-__device__ __forceinline__ int last_reached_from(const DevParams& P, const double* __restrict__ path,
+template <typename PathPtr>
+__device__ __forceinline__ int last_reached_from(const DevParams& P, PathPtr path,
                                                  const double* __restrict__ bbox, const int16_t* __restrict__ index,
                                                  int m, int target, double x, double y, double th)
 {
@@ -237,7 +240,7 @@ __device__ __forceinline__ int last_reached_from(const DevParams& P, const doubl
     const int lo = max(max((int)ix[0], (int)iy[0]), target);
     const int hi = min(min((int)ix[1], (int)iy[1]), m - 1);
     for (int j = hi; j >= lo; --j) {
-        const double* s = path + 5 * j;
+        const PathPtr s = path + 5 * j;
         const double dx = s[0] - x, dy = s[1] - y;
         // the three reach conditions are independent predicates; evaluate the cheap ones first
         if (fabs(dx) > P.sp_prune || fabs(dy) > P.sp_prune) continue;   // then hypot(dx,dy) >= sp
@@ -253,7 +256,8 @@ __device__ __forceinline__ int last_reached_from(const DevParams& P, const doubl
 }
 
 // ContinuousRewardProvider.reward (envs/base/reward.py:214-259)
-__device__ __forceinline__ double reward_step(const DevParams& P, const double* __restrict__ path,
+template <typename PathPtr>
+__device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path,
                                               const double* __restrict__ bbox, const int16_t* __restrict__ index, int m,
                                               double x, double y, double th, double& min_dist, int& target)
 {
@@ -262,14 +266,14 @@ __device__ __forceinline__ double reward_step(const DevParams& P, const double* 
     if (last >= 0) {
         target = last + 1;
         if (!(target > m - 1)) {
-            const double* g = path + 5 * target;
+            const PathPtr g = path + 5 * target;
             min_dist = hypot(g[0] - x, g[1] - y);
         } else {
             min_dist = 0.0;
         }
         return 1.0;
     }
-    const double* g = path + 5 * target;
+    const PathPtr g = path + 5 * target;
     const double d = hypot(g[0] - x, g[1] - y);
     if (d < min_dist) {
         const double r = min_dist - d;
@@ -299,10 +303,14 @@ struct StepArgs {
     int32_t exact_mode, dense_threshold, wide;
     uint64_t seed, step_counter;
     int64_t env_id_base;
-    struct Pending* pending;   // [n] parking slots for undecided envs (nullptr: settle everything in kernel 1)
-    int32_t* pending_count;    // this step's counter of parked envs
-    int32_t* pending_next;     // the next step's counter (the two alternate); kernel 1 zeroes it
+    struct Pending* pending;   // [kShards][pending_cap] parking slots for undecided envs (nullptr: no second kernel)
+    int32_t* pending_count;    // [kShards] this step's counters of parked envs (one per shard: no hot atomic)
+    int32_t* pending_next;     // [kShards] the next step's counters (the two sets alternate); kernel 1 zeroes them
+    int32_t pending_cap;       // slots per shard
+    int32_t lds_path_doubles;  // > 0: the shared path (max_len * 5 doubles) is staged in LDS by the step kernel
 };
+
+constexpr int kShards = 64;  // a wave parks into shard (block index % kShards)
 
 // dynamic LDS of the collision kernels:
 //   [lethal bitmap words (when the shared map is staged)] [qverts: n_verts * 2 doubles] [vertex scratch of the
@@ -357,7 +365,7 @@ __device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc&
     const int px = (int)rint((x - ox) * map.inv_res);   // world_to_pixel, coordinate_transformations.py:185-205
     const int py = (int)rint((y - oy) * map.inv_res);
     const double c = cos(th), s = sin(th);
-    int cls = active ? classify(cull, map.rows, map.cols, px, py, c, s) : kFree;
+    int cls = active ? classify(cull, map.shared ? 0 : env, map.rows, map.cols, px, py, c, s) : kFree;
     bool hit = cls == kHit;
     uint64_t amb = __ballot(cls == kAmbiguous);
     if (amb == 0) return hit;
@@ -397,6 +405,8 @@ __device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc&
 
 // One env's state after the robot model ran, before the collision verdict is known.
 struct Pending {
+    double c, s;        // cos / sin of the new heading (as used by the classification)
+    int32_t px, py;     // world_to_pixel of the new position
     Robot r;            // after robot.step()
     Pose old;           // pose before the step (rollback target)
     double min_dist;
@@ -408,7 +418,7 @@ struct Pending {
 
 // Everything of PlanEnv.step() that follows pose_collides(): rollback (env.py:458-459), bookkeeping (:382-396),
 // reward (:352), done (:407-419), outputs, optional reset, state write-back.  Runs on one lane for env i.
-__device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pending& q, bool hit)
+__device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr)
 {
     const DevParams& P = a.P;
     const bool tri = P.model == BCP_MODEL_TRICYCLE;
@@ -428,7 +438,10 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     int m;
     if (a.path.shared) {
         m = a.path.max_len;
-        if (!(a.flags & (1u << 17)))
+        if (a.flags & (1u << 17)) {
+        } else if (lds_path)  // way points staged in LDS by the step kernel: no global round trip per candidate
+            rew = reward_step(P, lds_path, a.path.bbox, a.path.index, m, r.p.x, r.p.y, r.p.th, min_dist, target);
+        else
             rew = reward_step(P, a.path.pts, a.path.bbox, a.path.index, m, r.p.x, r.p.y, r.p.th, min_dist, target);
     } else {
         m = a.path.lens[i];
@@ -494,8 +507,17 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     const bool defer = a.pending != nullptr;
 
     CollisionLds L;
-    if (!defer) L = collision_lds_setup(P, a.map, tid);
-    if (defer && gi == 0) *a.pending_next = 0;  // arm the counter of the NEXT step (the two slots alternate)
+    __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
+    if (!defer) {
+        L = collision_lds_setup(P, a.map, tid);
+    } else {  // the deferring kernel keeps the scaled footprint and (when it fits) the shared path in LDS
+        for (int k = tid; k < 2 * P.n_verts; k += kBlock) qv[k] = P.qverts[k >> 1][k & 1];
+        if (a.lds_path_doubles)
+            for (int k = tid; k < a.lds_path_doubles; k += kBlock) qv[2 * P.n_verts + k] = a.path.pts[k];
+        __syncthreads();
+    }
+    const LdsF64 lds_path = (defer && a.lds_path_doubles) ? (LdsF64)(qv + 2 * P.n_verts) : (LdsF64) nullptr;
+    if (defer && gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
 
     // ---- load state
     Pending q;
@@ -550,48 +572,75 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
         }
         const int px = (int)rint((r.p.x - ox) * a.map.inv_res);  // world_to_pixel
         const int py = (int)rint((r.p.y - oy) * a.map.inv_res);
-        const int cls = classify_outer(a.cull, a.map.rows, a.map.cols, px, py, cos(r.p.th), sin(r.p.th));
-        if (cls == kAmbiguous && active) {
-            // Undecided: park the pre-verdict state for kernel 2 and carry on as if the pose were free, which it is
-            // for nearly every parked env; kernel 2 redoes the finalisation of the few that do collide.
-            const int slot = atomicAdd(a.pending_count, 1);
+        const double c = cos(r.p.th), s = sin(r.p.th);
+        const int cls = (active && !(a.flags & (1u << 22))) ? classify_outer(a.cull, a.map.shared ? 0 : i, a.map.rows, a.map.cols, px, py, c, s) : kFree;
+        const uint64_t amb = __ballot(cls == kAmbiguous);
+        if (__popcll(amb) > a.dense_threshold) {
+            // Many undecided lanes in this wave (robots hugging walls): settle them in place, one pose at a time by
+            // the whole wave -- the per-wave load is balanced anyway and the pose is already in registers.
+            const bool inner = cls == kAmbiguous && classify_inner_hit(a.cull, a.map.shared ? 0 : i, px, py, c, s);
+            hit = inner;
+            uint64_t todo = __ballot(cls == kAmbiguous && !inner);
+            while (todo) {
+                const int src = __ffsll((unsigned long long)todo) - 1;
+                todo &= todo - 1;
+                const int64_t env_ = ((int64_t)bcast_i((int)(i >> 32), src) << 32) | (uint32_t)bcast_i((int)i, src);
+                const uint32_t* words = a.map.bits + (a.map.shared ? 0 : env_ * a.map.env_stride);
+                const bool h = coop_collides(P, (LdsF64)qv, bcast_d(c, src), bcast_d(s, src), bcast_i(px, src),
+                                             bcast_i(py, src), words, a.map.rows, a.map.cols, a.map.wpr, a.wide != 0);
+                if (lane_id() == src) hit = h;
+            }
+        } else if (cls == kAmbiguous && !(a.flags & (1u << 21))) {
+            // A few undecided lanes: park the pre-verdict state for kernel 2 (one wave per pose, load-balanced over
+            // the whole GPU) and carry on as if the pose were free, which it is for nearly every parked env;
+            // kernel 2 redoes the finalisation of the few that do collide.
+            const int shard = (int)(blockIdx.x % kShards);
+            const int slot = atomicAdd(a.pending_count + shard, 1);
+            q.c = c;
+            q.s = s;
+            q.px = px;
+            q.py = py;
             q.env_lo = (int32_t)(uint32_t)i;
             q.env_hi = (int32_t)(i >> 32);
-            a.pending[slot] = q;
+            a.pending[(int64_t)shard * a.pending_cap + slot] = q;
         }
     } else {
         hit = collides_wave(P, a.map, a.cull, L, a.exact_mode, a.dense_threshold, a.wide != 0, active, i, r.p.x, r.p.y,
                             r.p.th);
     }
     if (!active) return;
-    finalize_env(a, i, q, hit);
+    finalize_env(a, i, q, hit, lds_path);
 }
 
 // Kernel 2 of a step: one wavefront per parked env.  Inner distance-field test, then all 64 lanes rasterise the
 // footprint together (coop_collides); on a collision lane 0 redoes the env's finalisation from the parked state.
-__global__ void __launch_bounds__(kBlock) step_pending_kernel(const StepArgs a)
+constexpr int kPendingWaves = 2;  // wavefronts sharing one parked pose: wave w rasterises the row chunks w, w+2, ...
+
+__global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(const StepArgs a)
 {
     const DevParams& P = a.P;
     __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
-    for (int k = threadIdx.x; k < 2 * P.n_verts; k += kBlock) qv[k] = P.qverts[k >> 1][k & 1];
+    for (int k = threadIdx.x; k < 2 * P.n_verts; k += kBlock * kPendingWaves) qv[k] = P.qverts[k >> 1][k & 1];
     __syncthreads();
-    const int count = *a.pending_count;
-    for (int idx = blockIdx.x; idx < count; idx += gridDim.x) {
-        Pending q = a.pending[idx];
-        const int64_t i = ((int64_t)q.env_hi << 32) | (uint32_t)q.env_lo;
-        double ox = a.map.ox, oy = a.map.oy;
-        if (a.map.origins) {
-            ox = a.map.origins[2 * i + 0];
-            oy = a.map.origins[2 * i + 1];
-        }
-        const int px = (int)rint((q.r.p.x - ox) * a.map.inv_res);
-        const int py = (int)rint((q.r.p.y - oy) * a.map.inv_res);
+    const int wave = threadIdx.x / kBlock;
+    const int shard = (int)(blockIdx.x % kShards);
+    const int count = a.pending_count[shard];
+    for (int idx = blockIdx.x / kShards; idx < count; idx += gridDim.x / kShards) {
+        const Pending* e = a.pending + ((int64_t)shard * a.pending_cap + idx);
+        const double c = e->c, s = e->s;
+        const int px = e->px, py = e->py;
+        const int64_t i = ((int64_t)e->env_hi << 32) | (uint32_t)e->env_lo;
         const uint32_t* words = a.map.bits + (a.map.shared ? 0 : i * a.map.env_stride);
-        const double c = cos(q.r.p.th), s = sin(q.r.p.th);
-        bool hit = classify_inner_hit(a.cull, px, py, c, s);  // wave-uniform: every lane holds the same pose
-        if (!hit) hit = coop_collides(P, qv, c, s, px, py, words, a.map.rows, a.map.cols, a.map.wpr, a.wide != 0);
+        bool hit = (a.flags & (1u << 20)) ? false : classify_inner_hit(a.cull, a.map.shared ? 0 : i, px, py, c, s);
+        if (!hit && !(a.flags & (1u << 19)))
+            hit = coop_collides(P, qv, c, s, px, py, words, a.map.rows, a.map.cols, a.map.wpr, a.wide != 0, wave,
+                                kPendingWaves);
+        hit = __syncthreads_or(hit);  // wave-uniform verdicts of the block's waves
         // kernel 1 already finished this env as "free"; only a collision changes anything
-        if (hit && threadIdx.x == 0) finalize_env(a, i, q, true);
+        if (hit && threadIdx.x == 0) {
+            Pending q = *e;
+            finalize_env(a, i, q, true);
+        }
     }
 }
 
@@ -738,56 +787,56 @@ __global__ void __launch_bounds__(kBlock) pixel_footprint_thread_kernel(DevParam
     raster_runs(P, c, s, E, sink);
 }
 
-// ---- Euclidean distance transform of the lethal cells over the padded map (classify(), bcp_coop.h) -------------
-// pass 1: per padded column, vertical distance to the nearest lethal cell of that column (INF if none)
-__global__ void edt_columns_kernel(const uint32_t* __restrict__ bits, int rows, int cols, int wpr, int pad,
-                                   int32_t* __restrict__ g)
+// ---- Euclidean distance transform of the lethal cells over the padded map(s) (classify(), bcp_coop.h) ----------
+// Distances are only ever compared with thresholds <= `clamp`, so the transform is exact up to `clamp` and
+// saturates there.  pass 1: per padded column, vertical distance to the nearest lethal cell of that column.
+__global__ void edt_columns_kernel(const uint32_t* __restrict__ bits, int64_t n_maps, int rows, int cols, int wpr, int pad,
+                                   int clamp, uint8_t* __restrict__ g)
 {
     const int W = cols + 2 * pad, H = rows + 2 * pad;
-    const int cp = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cp >= W) return;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_maps * W) return;
+    const int cp = (int)(t % W);
+    const int64_t m = t / W;
     const int c = cp - pad;
-    const int INF = 1 << 20;
+    const uint32_t* mb = bits + m * (int64_t)rows * wpr;
+    uint8_t* mg = g + m * (int64_t)W * H;
     const bool in_cols = c >= 0 && c < cols;
-    int d = INF;
+    int d = clamp;
     for (int rp = 0; rp < H; ++rp) {  // downward sweep
         const int r = rp - pad;
-        const bool leth = in_cols && r >= 0 && r < rows && ((bits[r * wpr + (c >> 5)] >> (c & 31)) & 1u);
-        d = leth ? 0 : (d >= INF ? INF : d + 1);
-        g[rp * W + cp] = d;
+        const bool leth = in_cols && r >= 0 && r < rows && ((mb[r * wpr + (c >> 5)] >> (c & 31)) & 1u);
+        d = leth ? 0 : min(d + 1, clamp);
+        mg[rp * W + cp] = (uint8_t)d;
     }
-    d = INF;
+    d = clamp;
     for (int rp = H - 1; rp >= 0; --rp) {  // upward sweep
         const int r = rp - pad;
-        const bool leth = in_cols && r >= 0 && r < rows && ((bits[r * wpr + (c >> 5)] >> (c & 31)) & 1u);
-        d = leth ? 0 : (d >= INF ? INF : d + 1);
-        g[rp * W + cp] = min(g[rp * W + cp], d);
+        const bool leth = in_cols && r >= 0 && r < rows && ((mb[r * wpr + (c >> 5)] >> (c & 31)) & 1u);
+        d = leth ? 0 : min(d + 1, clamp);
+        mg[rp * W + cp] = (uint8_t)min((int)mg[rp * W + cp], d);
     }
 }
 
-// pass 2: d^2(r,c) = min over c' of (c - c')^2 + g(r,c')^2, stored as floor(min(255, d)).  Only |c - c'| <= 255 can
-// yield a distance below the clamp.
-__global__ void edt_rows_kernel(const int32_t* __restrict__ g, int W, int H, uint8_t* __restrict__ out)
+// pass 2: d^2(r,c) = min over |c - c'| < clamp of (c - c')^2 + g(r,c')^2, stored as floor(min(clamp, d)).
+__global__ void edt_rows_kernel(const uint8_t* __restrict__ g, int64_t n_maps, int W, int H, int clamp,
+                                uint8_t* __restrict__ out)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)W * H) return;
-    const int cp = (int)(idx % W), rp = (int)(idx / W);
-    const int32_t* row = g + (int64_t)rp * W;
-    int64_t best = (int64_t)255 * 255 + 1;
-    const int lo = max(0, cp - 255), hi = min(W - 1, cp + 255);
+    if (idx >= n_maps * (int64_t)W * H) return;
+    const int cp = (int)(idx % W);
+    const uint8_t* row = g + (idx - cp);
+    int best = clamp * clamp;
+    const int lo = max(0, cp - clamp + 1), hi = min(W - 1, cp + clamp - 1);
     for (int k = lo; k <= hi; ++k) {
-        const int64_t gv = row[k];
-        if (gv > 255) continue;
-        const int64_t dd = (int64_t)(cp - k) * (cp - k) + gv * gv;
+        const int gv = row[k];
+        const int dd = (cp - k) * (cp - k) + gv * gv;
         best = dd < best ? dd : best;
     }
-    int sq = 255;
-    if (best <= (int64_t)255 * 255) {
-        sq = (int)sqrt((double)best);
-        while ((int64_t)sq * sq > best) --sq;
-        while ((int64_t)(sq + 1) * (sq + 1) <= best) ++sq;
-    }
-    out[idx] = (uint8_t)sq;
+    int sq = (int)sqrt((double)best);
+    while (sq * sq > best) --sq;
+    while ((sq + 1) * (sq + 1) <= best) ++sq;
+    out[idx] = (uint8_t)min(sq, clamp);
 }
 
 __global__ void normalize_angle_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n)
@@ -965,7 +1014,7 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->env_id_base = env_id_base;
     h->seed = 0;
     h->exact_mode = 0;
-    h->dense_threshold = 12;
+    h->dense_threshold = 6;
     h->cull_enabled = 1;
     h->defer = 1;
     fill_dev_params(h);
@@ -1071,9 +1120,14 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
     CullDesc& C = h->cull;
     memset(&C, 0, sizeof(C));
     build_cull_geometry(h->params, resolution, &C);
-    if (shared && h->cull_enabled) {
+    if (const char* dbg = getenv("BCP_DEBUG_MAX_OUT")) C.n_out = std::min(C.n_out, atoi(dbg));  // timing experiments
+    if (h->cull_enabled) {
+        // shared map: padding wide enough that every sample of a pose whose image touches the map is stored;
+        // private maps: a thin margin (samples outside it just cannot clear / convict a pose)
+        if (!shared) C.pad = 8;
+        const int clamp = std::min(255, std::max(C.t_out + 1, 2));
         const int W = cols + 2 * C.pad, H = rows + 2 * C.pad;
-        const size_t cells = (size_t)W * H;
+        const size_t cells = (size_t)n_maps * W * H;
         if (cells > h->edt_bytes) {
             if (h->edt) HIP_TRY(hipFree(h->edt));
             h->edt = nullptr;
@@ -1081,25 +1135,30 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
             HIP_TRY(hipMalloc((void**)&h->edt, cells));
             h->edt_bytes = cells;
         }
-        if (cells * sizeof(int32_t) > h->edt_col_bytes) {
+        if (cells > h->edt_col_bytes) {
             if (h->edt_col) HIP_TRY(hipFree(h->edt_col));
             h->edt_col = nullptr;
             h->edt_col_bytes = 0;
-            HIP_TRY(hipMalloc((void**)&h->edt_col, cells * sizeof(int32_t)));
-            h->edt_col_bytes = cells * sizeof(int32_t);
+            HIP_TRY(hipMalloc((void**)&h->edt_col, cells));
+            h->edt_col_bytes = cells;
         }
-        hipLaunchKernelGGL(edt_columns_kernel, dim3((W + 63) / 64), dim3(64), 0, s, h->bitmap, rows, cols, wpr, C.pad,
-                           h->edt_col);
-        hipLaunchKernelGGL(edt_rows_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, h->edt_col, W, H,
-                           h->edt);
+        const int64_t n_cols_total = n_maps * W;
+        hipLaunchKernelGGL(edt_columns_kernel, dim3((unsigned)((n_cols_total + 63) / 64)), dim3(64), 0, s, h->bitmap, n_maps,
+                           rows, cols, wpr, C.pad, clamp, h->edt_col);
+        hipLaunchKernelGGL(edt_rows_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, h->edt_col, n_maps, W, H,
+                           clamp, h->edt);
         HIP_TRY(hipGetLastError());
         C.edt = h->edt;
         C.width = W;
-        C.on = 1;
+        C.height = H;
+        C.env_stride = shared ? 0 : (int64_t)W * H;
+        C.on = C.t_out <= clamp ? 1 : 0;
         if (!h->pending) {
-            HIP_TRY(hipMalloc(&h->pending, (size_t)h->n * sizeof(Pending)));
-            HIP_TRY(hipMalloc((void**)&h->pending_count, 2 * sizeof(int32_t)));
-            HIP_TRY(hipMemsetAsync(h->pending_count, 0, 2 * sizeof(int32_t), s));
+            const int64_t blocks = (h->n + kBlock - 1) / kBlock;
+            h->pending_cap = (int32_t)(((blocks + kShards - 1) / kShards) * kBlock);  // every env of a shard's blocks
+            HIP_TRY(hipMalloc(&h->pending, (size_t)kShards * h->pending_cap * sizeof(Pending)));
+            HIP_TRY(hipMalloc((void**)&h->pending_count, 2 * kShards * sizeof(int32_t)));
+            HIP_TRY(hipMemsetAsync(h->pending_count, 0, 2 * kShards * sizeof(int32_t), s));
         }
     }
     h->have_map = true;
@@ -1201,7 +1260,8 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     a.map = h->map;
     a.cull = h->cull;
     a.exact_mode = h->exact_mode;
-    a.dense_threshold = h->dense_threshold;
+    // fewer waves than SIMDs: nothing to balance, settle every undecided pose inside the step kernel
+    a.dense_threshold = (h->n + kBlock - 1) / kBlock < 1024 && h->exact_mode == 0 ? -1 : h->dense_threshold;
     a.wide = h->wide;
     a.path = h->path;
     a.st = h->st;
@@ -1220,15 +1280,19 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     a.env_id_base = h->env_id_base;
     const bool defer = h->defer && h->cull.on && h->exact_mode == 0 && h->pending != nullptr;
     a.pending = defer ? (Pending*)h->pending : nullptr;
-    a.pending_count = h->pending_count + (h->step_counter & 1);
-    a.pending_next = h->pending_count + ((h->step_counter + 1) & 1);
+    a.pending_count = h->pending_count + (h->step_counter & 1) * kShards;
+    a.pending_next = h->pending_count + ((h->step_counter + 1) & 1) * kShards;
+    a.pending_cap = h->pending_cap;
+    a.lds_path_doubles = 0;
     const int blocks = (int)((h->n + kBlock - 1) / kBlock);
     if (defer) {
         // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest, one wave each
-        hipLaunchKernelGGL(step_kernel, dim3(blocks), dim3(kBlock), 0, s, a);
-        const int waves = (int)std::min<int64_t>(blocks, 1024);
+        a.lds_path_doubles = (h->path.shared && h->path.max_len * 5 * sizeof(double) <= 24 * 1024) ? h->path.max_len * 5 : 0;
+        hipLaunchKernelGGL(step_kernel, dim3(blocks), dim3(kBlock),
+                           ((size_t)h->params.n_verts * 2 + a.lds_path_doubles) * sizeof(double), s, a);
+        const int waves = 1024;  // a multiple of kShards: 16 waves per shard
         if (!first_only)
-            hipLaunchKernelGGL(step_pending_kernel, dim3(waves), dim3(kBlock),
+            hipLaunchKernelGGL(step_pending_kernel, dim3(waves), dim3(kBlock * kPendingWaves),
                                (size_t)h->params.n_verts * 2 * sizeof(double), s, a);
     } else {
         const size_t lds = collision_lds_bytes(h->params.n_verts, h->map.in_lds, h->map.rows, h->map.wpr);

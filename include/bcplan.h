@@ -128,7 +128,8 @@ int bcp_seed(bcp_handle *h, uint64_t seed);
 
 /* Execution knobs; none of them changes any result (tests run every combination against the oracle).
  *   BCP_TUNE_EXACT_MODE       0 = auto, 1 = always the wave-cooperative exact rasteriser, 2 = always the per-thread one
- *   BCP_TUNE_DENSE_THRESHOLD  auto mode: more undecided poses than this in one wavefront -> per-thread rasteriser
+ *   BCP_TUNE_DENSE_THRESHOLD  auto mode: more undecided poses than this in one wavefront -> settle them inside the
+ *                             step kernel (cooperatively with a distance field, per thread without one)
  *   BCP_TUNE_CULL             0 = skip the distance-field pre-classification (every in-map pose is rasterised)
  *   BCP_TUNE_DEFER            0 = settle undecided poses inside the step kernel instead of the second, load-balanced
  *                             kernel (only relevant with a distance field and exact mode auto) */

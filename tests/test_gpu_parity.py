@@ -275,7 +275,8 @@ def _random_batch(oracle, rng, n, g, name):
 
 
 STEP_MODES = [dict(), dict(defer=0), dict(exact_mode=1), dict(exact_mode=2), dict(cull=0, exact_mode=1),
-              dict(cull=0, exact_mode=2), dict(defer=0, dense_threshold=0)]
+              dict(cull=0, exact_mode=2), dict(defer=0, dense_threshold=0), dict(dense_threshold=0),
+              dict(dense_threshold=64)]
 
 
 @pytest.mark.parametrize("fixture,mode", [("g8_traj_mini_00.npz", m) for m in STEP_MODES] +
@@ -366,8 +367,12 @@ def test_diffdrive_shared_64x64_vs_oracle(torch_cuda, oracle):
     assert tot > 100
 
 
-def test_private_maps_and_paths_vs_oracle(torch_cuda, oracle):
-    """C4 shape at reduced N: per-env costmaps (different shapes, padded) and per-env paths of different length."""
+@pytest.mark.parametrize("mode", [dict(), dict(defer=0), dict(cull=0, exact_mode=1), dict(cull=0, exact_mode=2),
+                                  dict(dense_threshold=0), dict(dense_threshold=64)],
+                         ids=lambda m: "-".join("%s%d" % (k[:4], v) for k, v in sorted(m.items())) or "default")
+def test_private_maps_and_paths_vs_oracle(torch_cuda, oracle, mode):
+    """C4 shape at reduced N: per-env costmaps (different shapes, padded) and per-env paths of different length,
+    with and without the per-env distance field."""
     torch = torch_cuda
     from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
     names = ["g8_traj_aisle_c4_00.npz", "g8_traj_aisle_c4_10.npz", "g8_traj_aisle_c4_01.npz", "g8_traj_aisle_c4_11.npz"]
@@ -397,6 +402,7 @@ def test_private_maps_and_paths_vs_oracle(torch_cuda, oracle):
     # give the HIP path the poisoned maps as well
     env.set_costmap_tensors(torch.from_numpy(maps).cuda(), torch.from_numpy(origins).cuda(), res,
                             torch.from_numpy(vr).cuda(), torch.from_numpy(vc).cuda())
+    env.set_tuning(**mode)
     p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE)
     ref = oracle.OracleBatch(p, n, maps, origins, res, pbuf, lens=[len(p_) for p_ in paths], rows=vr, cols=vc)
     ref.reset_from_paths()

@@ -8,7 +8,8 @@ env.state.current_iter.copy_(torch.from_numpy(rng.randint(0,1200,65536).astype(n
 for k in range(1200): env.step(pool[k%16])
 torch.cuda.synchronize()
 st=env.get_state()
-for name,fl in [('full',0),('no_park',1<<21),('no_classify',1<<22),('no_raster',1<<16),('no_reward',1<<17),('neither',3<<16)]:
+for name,fl in [('full',0),('k2_no_coop',1<<19),('k2_no_coop_no_inner',(1<<19)|(1<<20))]:
     env.set_state(st); env._debug_flags=fl
-    ms=[env.time_steps(pool[i%16],20) for i in range(5)]
-    print(name, ['%.3f'%m for m in ms])
+    for rep in range(2):
+        k1,k2=env.time_step_kernels(pool[rep],100)
+        print(name,'k1 %.4f  k2+gap %.4f'%(k1,k2), flush=True)

@@ -8,7 +8,7 @@ env.state.current_iter.copy_(torch.from_numpy(rng.randint(0,1200,65536).astype(n
 for k in range(1200): env.step(pool[k%16])
 torch.cuda.synchronize()
 st=env.get_state()
-for name,fl in [('full',0),('no_park',1<<21),('no_classify',1<<22),('no_raster',1<<16),('no_reward',1<<17),('neither',3<<16)]:
-    env.set_state(st); env._debug_flags=fl
-    ms=[env.time_steps(pool[i%16],20) for i in range(5)]
-    print(name, ['%.3f'%m for m in ms])
+for thr in (64, 16, 6, 2, 0):
+    env.set_state(st); env.set_tuning(dense_threshold=thr)
+    ms=[env.time_steps(pool[i%16],50) for i in range(3)]
+    print('dense_threshold',thr, ['%.4f'%m for m in ms], flush=True)
