@@ -74,6 +74,38 @@ __device__ __forceinline__ int classify_outer(const CullDesc& C, int64_t env, in
     return near_out ? kAmbiguous : kFree;
 }
 
+// The outer test in two halves, so that a caller can put other loads between issuing the lookups and using them.
+struct OuterLookups {
+    int val[kMaxSamples];
+    bool off_map;
+};
+
+__device__ __forceinline__ OuterLookups outer_lookups_issue(const CullDesc& C, int64_t env, int rows, int cols, int px,
+                                                            int py, double c, double s)
+{
+    OuterLookups L;
+    L.off_map = px + C.reach < 0 || px - C.reach >= cols || py + C.reach < 0 || py - C.reach >= rows;
+    const double ay_c = C.axis_y * c, ay_s = C.axis_y * s;
+    const uint8_t* field = C.edt + env * C.env_stride;
+#pragma unroll
+    for (int i = 0; i < kMaxSamples; ++i) {
+        const int du = (int)rint(C.out_x[i] * c - ay_s), dv = (int)rint(C.out_x[i] * s + ay_c);
+        const int x = px + C.pad + du, y = py + C.pad + dv;
+        const bool stored = !L.off_map && i < C.n_out && (unsigned)x < (unsigned)C.width && (unsigned)y < (unsigned)C.height;
+        L.val[i] = stored ? (int)field[y * C.width + x] : (i < C.n_out ? 0 : 255);  // not stored: cannot clear
+    }
+    return L;
+}
+
+__device__ __forceinline__ int outer_lookups_verdict(const CullDesc& C, const OuterLookups& L)
+{
+    if (L.off_map) return kFree;
+    int near_out = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxSamples; ++i) near_out |= L.val[i] < C.t_out;
+    return near_out ? kAmbiguous : kFree;
+}
+
 // inner test for a pose the outer test could not clear: true => certainly colliding
 __device__ __forceinline__ bool classify_inner_hit(const CullDesc& C, int64_t env, int px, int py, double c, double s)
 {
@@ -153,24 +185,38 @@ struct EdgeRegs {
 // Row coverage sink of the cooperative rasteriser: called once per 64-row chunk with each lane's row masks.
 //   bool rows(int y /*this lane's centred row*/, bool valid, const uint32_t cover[NW], int ubase /*centred u of bit 0*/)
 // returns a wave-uniform "stop".
-template <int NW, typename RowSink>
-__device__ __forceinline__ bool coop_raster(const DevParams& P, LdsF64 qverts_lds, double c, double s, RowSink& sink,
-                                            int first_chunk = 0, int chunk_stride = 1)
+//
+// Work split between the waves of one workgroup (all on the same pose): wave = (chunk slot, edge slot).
+//   chunks: a wave takes the 64-row chunks first_chunk, first_chunk + chunk_stride, ...
+//   edges : with ESPLIT == 2, two waves share a chunk, one taking the even and one the odd edges; outline runs just
+//           OR together, but the span parity needs every edge, so the partners exchange their partial XOR masks
+//           through LDS (`xch`, double-buffered, one workgroup barrier per round -- every wave of the workgroup
+//           runs the same number of rounds).
+template <int NW, int ESPLIT, typename RowSink>
+__device__ __forceinline__ bool coop_raster(const DevParams& P, double qx, double qy, double c, double s, RowSink& sink,
+                                            int first_chunk = 0, int chunk_stride = 1, int first_edge = 0,
+                                            LdsU32 xch = nullptr, int wave = 0)
 {
     const int K = P.n_verts;
     const int lane = lane_id();
     // ---- lane k < K owns vertex k and edge k
     int u = 0, v = 0;
-    if (lane < K) {
-        const double qx = qverts_lds[2 * lane], qy = qverts_lds[2 * lane + 1];
+    if (lane < K) {  // (qx, qy) = footprint vertex `lane` divided by the resolution, supplied by the caller
         u = (int)rint(fma(qy, -s, qx * c));   // path_tools.py:142-150
         v = (int)rint(fma(qy, c, qx * s));
     }
     const int prev = lane == 0 ? K - 1 : lane - 1;
     const int up = __shfl(u, prev), vp = __shfl(v, prev);
     const bool owner = lane < K;
-    const int vmin = wave_min_i(owner ? v : 0x7fffffff), vmax = wave_max_i(owner ? v : -0x7fffffff);
-    const int umin = wave_min_i(owner ? u : 0x7fffffff), umax = wave_max_i(owner ? u : -0x7fffffff);
+    // extents of the integer polygon: a scalar loop over the K owner lanes (v_readlane + s_min / s_max)
+    int vmin = 0x7fffffff, vmax = -0x7fffffff, umin = 0x7fffffff, umax = -0x7fffffff;
+    for (int k = 0; k < K; ++k) {
+        const int uk = bcast_i(u, k), vk = bcast_i(v, k);
+        vmin = min(vmin, vk);
+        vmax = max(vmax, vk);
+        umin = min(umin, uk);
+        umax = max(umax, uk);
+    }
     sink.extent(umin, umax);
     EdgeRegs E;
     {
@@ -204,53 +250,72 @@ __device__ __forceinline__ bool coop_raster(const DevParams& P, LdsF64 qverts_ld
     }
     const int ubase = umin;  // bit 0 of the row masks <-> centred column umin
 
-    // several waves may share one pose: wave w takes the 64-row chunks w, w + chunk_stride, ...
-    for (int ybase = vmin + 64 * first_chunk; ybase <= vmax; ybase += 64 * chunk_stride) {
+    const int n_chunks = (vmax - vmin) / 64 + 1;
+    const int n_rounds = (n_chunks + chunk_stride - 1) / chunk_stride;  // the same for every wave of the workgroup
+    bool stop = false;
+    for (int round = 0; round < n_rounds; ++round) {
+        const int ybase = vmin + 64 * (first_chunk + round * chunk_stride);
         const int y = ybase + lane;
-        const bool valid = y <= vmax;
+        const bool valid = ybase <= vmax && y <= vmax;
         uint32_t cov_or[NW], cov_xor[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) cov_or[w] = cov_xor[w] = 0;
-        if (!sink.chunk_matters(y, valid)) continue;  // no lethal cell under the image on any row of this chunk
-        for (int e = 0; e < K; ++e) {
-            const int ey0 = bcast_i(E.y0, e), ey1 = bcast_i(E.y1, e);
-            // rows an edge can touch: [y0, y1] for the outline, [y0, y1) for the spans (horizontal: y0 == y1)
-            if (ey1 < ybase || ey0 > ybase + 63) continue;
-            const int sy = bcast_i(E.sy, e), sx = bcast_i(E.sx, e);
-            const int dx = bcast_i(E.dx, e), dy = bcast_i(E.dy, e), ystep = bcast_i(E.ystep, e);
-            // SPANS: crossing of the active edge, parity mask starts one past floor(x_e)
-            if (y >= ey0 && y < ey1) {
-                const int xe = bcast_i(E.x0fp, e) + (y - ey0) * bcast_i(E.dxfp, e);
-                const int pos = (xe >> 16) + 1 - ubase;
+        // no lethal cell under the image on any row of this chunk: nothing to rasterise
+        const bool matters = !stop && ybase <= vmax && sink.chunk_matters(y, valid);
+        if (matters) {
+            for (int e = first_edge; e < K; e += ESPLIT) {
+                const int ey0 = bcast_i(E.y0, e), ey1 = bcast_i(E.y1, e);
+                // rows an edge can touch: [y0, y1] for the outline, [y0, y1) for the spans (horizontal: y0 == y1)
+                if (ey1 < ybase || ey0 > ybase + 63) continue;
+                const int sy = bcast_i(E.sy, e), sx = bcast_i(E.sx, e);
+                const int dx = bcast_i(E.dx, e), dy = bcast_i(E.dy, e), ystep = bcast_i(E.ystep, e);
+                // SPANS: crossing of the active edge, parity mask starts one past floor(x_e)
+                if (y >= ey0 && y < ey1) {
+                    const int xe = bcast_i(E.x0fp, e) + (y - ey0) * bcast_i(E.dxfp, e);
+                    const int pos = (xe >> 16) + 1 - ubase;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) cov_xor[w] ^= suffix_word(pos, w);
-            }
-            // OUTLINE: the run of this edge on row y (i = |y - sy| steps along the minor / major axis)
-            const int i = (y - sy) * ystep;
-            if (i >= 0 && i <= dy) {
-                int lo, hi;
-                if (dy > dx) {         // y-major: x = sx + floor((2*dx*i + dy - 1) / (2*dy))
-                    lo = hi = sx + (int)__umulhi((uint32_t)(2 * dx * i + dy - 1), bcast_i((int)E.inv, e));
-                } else if (dy == 0) {  // horizontal edge / single point
-                    lo = sx;
-                    hi = sx + dx;
-                } else {               // x-major: steps floor((2*dx*(i-1)+dx)/(2*dy)) + 1 .. min(dx, floor((2*dx*i+dx)/(2*dy)))
-                    const uint32_t inv = (uint32_t)bcast_i((int)E.inv, e);
-                    const int qhi = (int)__umulhi((uint32_t)(2 * dx * i + dx), inv);
-                    const int qlo = i == 0 ? -1 : (int)__umulhi((uint32_t)(2 * dx * (i - 1) + dx), inv);
-                    lo = sx + qlo + 1;
-                    hi = sx + (qhi > dx ? dx : qhi);
+                    for (int w = 0; w < NW; ++w) cov_xor[w] ^= suffix_word(pos, w);
                 }
-                const int p0 = lo - ubase, p1 = hi + 1 - ubase;
+                // OUTLINE: the run of this edge on row y (i = |y - sy| steps along the minor / major axis)
+                const int i = (y - sy) * ystep;
+                if (i >= 0 && i <= dy) {
+                    int lo, hi;
+                    if (dy > dx) {         // y-major: x = sx + floor((2*dx*i + dy - 1) / (2*dy))
+                        lo = hi = sx + (int)__umulhi((uint32_t)(2 * dx * i + dy - 1), bcast_i((int)E.inv, e));
+                    } else if (dy == 0) {  // horizontal edge / single point
+                        lo = sx;
+                        hi = sx + dx;
+                    } else {  // x-major: steps floor((2*dx*(i-1)+dx)/(2*dy)) + 1 .. min(dx, floor((2*dx*i+dx)/(2*dy)))
+                        const uint32_t inv = (uint32_t)bcast_i((int)E.inv, e);
+                        const int qhi = (int)__umulhi((uint32_t)(2 * dx * i + dx), inv);
+                        const int qlo = i == 0 ? -1 : (int)__umulhi((uint32_t)(2 * dx * (i - 1) + dx), inv);
+                        lo = sx + qlo + 1;
+                        hi = sx + (qhi > dx ? dx : qhi);
+                    }
+                    const int p0 = lo - ubase, p1 = hi + 1 - ubase;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) cov_or[w] |= suffix_word(p0, w) & ~suffix_word(p1, w);
+                    for (int w = 0; w < NW; ++w) cov_or[w] |= suffix_word(p0, w) & ~suffix_word(p1, w);
+                }
             }
+        }
+        if (ESPLIT == 2) {
+            // partner = the wave with the other edge slot of the same chunk slot (wave ^ 1)
+            const LdsU32 mine = xch + ((round & 1) * 4 + wave) * (NW * 64) + lane;
+            const LdsU32 theirs = xch + ((round & 1) * 4 + (wave ^ 1)) * (NW * 64) + lane;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) mine[w * 64] = cov_xor[w];
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NW; ++w) cov_xor[w] ^= theirs[w * 64];
         }
 #pragma unroll
         for (int w = 0; w < NW; ++w) cov_or[w] |= cov_xor[w];
-        if (sink.rows(y, valid, cov_or, ubase)) return true;
+        if (matters && sink.rows(y, valid, cov_or, ubase)) {
+            if (ESPLIT == 1) return true;
+            stop = true;  // keep taking part in the remaining barriers
+        }
     }
-    return false;
+    return stop;
 }
 
 // Row sink testing coverage against the lethal bitmap (pose_collides, env.py:464-489)
@@ -303,16 +368,30 @@ struct CoopCollisionSink {
 // exact pose_collides for ONE pose, all 64 lanes cooperating; returns a wave-uniform verdict.
 // `wide`: the kernel image may be wider than 96 px (use the 8-word row masks).
 template <typename WordPtr>
-__device__ __forceinline__ bool coop_collides(const DevParams& P, LdsF64 qverts_lds, double c, double s, int px,
-                              int py, WordPtr words, int rows, int cols, int wpr, bool wide, int first_chunk = 0,
-                              int chunk_stride = 1)
+__device__ __forceinline__ bool coop_collides(const DevParams& P, double qx, double qy, double c, double s, int px,
+                              int py, WordPtr words, int rows, int cols, int wpr, bool wide)
 {
     if (!wide) {
         CoopCollisionSink<3, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
-        return coop_raster<3>(P, qverts_lds, c, s, sink, first_chunk, chunk_stride);
+        return coop_raster<3, 1>(P, qx, qy, c, s, sink);
     }
     CoopCollisionSink<8, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
-    return coop_raster<8>(P, qverts_lds, c, s, sink, first_chunk, chunk_stride);
+    return coop_raster<8, 1>(P, qx, qy, c, s, sink);
+}
+
+// the same for a workgroup of 4 waves on one pose: wave = 2 * chunk slot + edge slot.  `xch`: 2 * 4 * NW * 64 words
+// of LDS.  Returns this wave's partial verdict (OR them over the workgroup).
+template <typename WordPtr>
+__device__ __forceinline__ bool coop_collides_quad(const DevParams& P, double qx, double qy, double c, double s, int px,
+                                                   int py, WordPtr words, int rows, int cols, int wpr, bool wide, int wave,
+                                                   LdsU32 xch)
+{
+    if (!wide) {
+        CoopCollisionSink<3, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
+        return coop_raster<3, 2>(P, qx, qy, c, s, sink, wave >> 1, 2, wave & 1, xch, wave);
+    }
+    CoopCollisionSink<8, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
+    return coop_raster<8, 2>(P, qx, qy, c, s, sink, wave >> 1, 2, wave & 1, xch, wave);
 }
 
 }  // namespace bcp

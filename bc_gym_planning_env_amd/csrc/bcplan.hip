@@ -67,6 +67,41 @@ struct PathDesc {
     int32_t max_len, shared;
 };
 
+struct Pending;
+
+// Everything a step needs that only changes when the caller re-binds something.  It lives in DEVICE memory (uploaded
+// when dirty) and the kernels get a pointer: kernel arguments sit in host memory on this platform, and a kernel that
+// takes kilobytes of arguments by value pays a PCIe-latency scalar load every time it touches a new field.
+struct StepStatic {
+    DevParams P;
+    MapDesc map;
+    CullDesc cull;
+    PathDesc path;
+    DevState st, init;
+    int64_t n;
+    int64_t env_id_base;
+    int32_t exact_mode, dense_threshold, wide;
+    int32_t pending_cap;       // slots per shard
+    int32_t lds_path_doubles;  // > 0: the shared path (max_len * 5 doubles) is staged in LDS by the fast step kernel
+    struct Pending* pending;   // [kShards][pending_cap] parking slots for undecided envs (nullptr: no second kernel)
+};
+
+// Per-launch kernel arguments (small).
+struct StepArgs {
+    const StepStatic* S;
+    const void* actions;
+    const double* noise_z;
+    double* noise_z_out;
+    double* reward;
+    uint8_t* done;
+    uint8_t* collided_now;
+    int32_t* err;
+    int32_t* pending_count;    // [kShards] this step's counters of parked envs (one per shard: no hot atomic)
+    int32_t* pending_next;     // [kShards] the next step's counters (the two sets alternate); kernel 1 zeroes them
+    uint64_t seed, step_counter;
+    uint32_t flags;
+};
+
 struct bcp_handle {
     bcp_params params;
     DevParams dev;
@@ -93,6 +128,9 @@ struct bcp_handle {
     CullDesc cull;
     PathDesc path;
     DevState st, init;
+    StepStatic host_static;   // host image of the device-resident step parameters
+    StepStatic* dev_static;   // owned
+    bool static_dirty;        // host_static must be rebuilt and uploaded before the next step
     void* pending;            // owned: Pending[n]
     int32_t* pending_count;   // owned: two alternating sets of kShards counters
     int32_t pending_cap;      // parking slots per shard
@@ -225,20 +263,35 @@ __global__ void path_index_kernel(const double* __restrict__ xyt, const int32_t*
 // LAST reached index is >= target_idx (envs/base/reward.py:234), so indices below target never matter.
 // A way point can only be reached when |x_j - x| and |y_j - y| are both below spatial_precision, so the scan is
 // confined to the index window the two bucket tables allow for this pose (usually a handful of way points).
-template <typename PathPtr>
-__device__ __forceinline__ int last_reached_from(const DevParams& P, PathPtr path,
-                                                 const double* __restrict__ bbox, const int16_t* __restrict__ index,
-                                                 int m, int target, double x, double y, double th)
+// index window [lo, hi] of the way points that can be within spatial_precision of (x, y); empty when lo > hi
+struct PathWindow {
+    int lo, hi;
+};
+
+__device__ __forceinline__ PathWindow path_window(const DevParams& P, const double* __restrict__ bbox,
+                                                  const int16_t* __restrict__ index, double x, double y)
 {
-    if (target > m - 1) return -1;
+    PathWindow w;
+    w.lo = 0;
+    w.hi = -1;
     if (x < bbox[0] - P.sp_prune || x > bbox[1] + P.sp_prune || y < bbox[2] - P.sp_prune || y > bbox[3] + P.sp_prune)
-        return -1;  // farther than spatial_precision from the bounding box of the whole path
+        return w;  // farther than spatial_precision from the bounding box of the whole path
     const int bx = min(max((int)floor((x - bbox[4]) * bbox[5]), 0), kPathBuckets - 1);
     const int by = min(max((int)floor((y - bbox[6]) * bbox[7]), 0), kPathBuckets - 1);
     const int16_t* ix = index + 2 * bx;
     const int16_t* iy = index + 2 * (kPathBuckets + by);
-    const int lo = max(max((int)ix[0], (int)iy[0]), target);
-    const int hi = min(min((int)ix[1], (int)iy[1]), m - 1);
+    w.lo = max((int)ix[0], (int)iy[0]);
+    w.hi = min((int)ix[1], (int)iy[1]);
+    return w;
+}
+
+template <typename PathPtr>
+__device__ __forceinline__ int last_reached_from(const DevParams& P, PathPtr path, PathWindow w, int m, int target,
+                                                 double x, double y, double th)
+{
+    if (target > m - 1) return -1;
+    const int lo = max(w.lo, target);
+    const int hi = min(w.hi, m - 1);
     for (int j = hi; j >= lo; --j) {
         const PathPtr s = path + 5 * j;
         const double dx = s[0] - x, dy = s[1] - y;
@@ -257,12 +310,11 @@ __device__ __forceinline__ int last_reached_from(const DevParams& P, PathPtr pat
 
 // ContinuousRewardProvider.reward (envs/base/reward.py:214-259)
 template <typename PathPtr>
-__device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path,
-                                              const double* __restrict__ bbox, const int16_t* __restrict__ index, int m,
-                                              double x, double y, double th, double& min_dist, int& target)
+__device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path, PathWindow w, int m, double x, double y,
+                                              double th, double& min_dist, int& target)
 {
     if (target > m - 1) return 0.0;
-    const int last = last_reached_from(P, path, bbox, index, m, target, x, y, th);
+    const int last = last_reached_from(P, path, w, m, target, x, y, th);
     if (last >= 0) {
         target = last + 1;
         if (!(target > m - 1)) {
@@ -282,33 +334,6 @@ __device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path,
     }
     return 0.0;
 }
-
-struct Pending;
-
-struct StepArgs {
-    DevParams P;
-    MapDesc map;
-    CullDesc cull;
-    PathDesc path;
-    DevState st, init;
-    int64_t n;
-    const void* actions;
-    const double* noise_z;
-    double* noise_z_out;
-    double* reward;
-    uint8_t* done;
-    uint8_t* collided_now;
-    int32_t* err;
-    uint32_t flags;
-    int32_t exact_mode, dense_threshold, wide;
-    uint64_t seed, step_counter;
-    int64_t env_id_base;
-    struct Pending* pending;   // [kShards][pending_cap] parking slots for undecided envs (nullptr: no second kernel)
-    int32_t* pending_count;    // [kShards] this step's counters of parked envs (one per shard: no hot atomic)
-    int32_t* pending_next;     // [kShards] the next step's counters (the two sets alternate); kernel 1 zeroes them
-    int32_t pending_cap;       // slots per shard
-    int32_t lds_path_doubles;  // > 0: the shared path (max_len * 5 doubles) is staged in LDS by the step kernel
-};
 
 constexpr int kShards = 64;  // a wave parks into shard (block index % kShards)
 
@@ -369,7 +394,7 @@ __device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc&
     bool hit = cls == kHit;
     uint64_t amb = __ballot(cls == kAmbiguous);
     if (amb == 0) return hit;
-    const bool dense = exact_mode == 2 || (exact_mode == 0 && __popcll(amb) > dense_threshold);
+    const bool dense = exact_mode == 2 || (exact_mode == 0 && (int)__popcll(amb) > dense_threshold);
     if (dense) {
         // many undecided lanes: one per-thread rasteriser pass settles them all at once
         if (cls == kAmbiguous) {
@@ -385,6 +410,8 @@ __device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc&
         return hit;
     }
     // few undecided lanes: the wave rasterises them cooperatively, one pose at a time
+    const int ln = lane_id();
+    const double vqx = ln < P.n_verts ? L.qverts[2 * ln] : 0.0, vqy = ln < P.n_verts ? L.qverts[2 * ln + 1] : 0.0;
     while (amb) {
         const int src = __ffsll((unsigned long long)amb) - 1;
         amb &= amb - 1;
@@ -392,11 +419,11 @@ __device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc&
         const int px_ = bcast_i(px, src), py_ = bcast_i(py, src);
         bool h;
         if (L.staged) {
-            h = coop_collides(P, L.qverts, c_, s_, px_, py_, L.bits, map.rows, map.cols, map.wpr, wide);
+            h = coop_collides(P, vqx, vqy, c_, s_, px_, py_, L.bits, map.rows, map.cols, map.wpr, wide);
         } else {
             const int64_t env_ = ((int64_t)bcast_i((int)(env >> 32), src) << 32) | (uint32_t)bcast_i((int)env, src);
             const uint32_t* words = map.bits + (map.shared ? 0 : env_ * map.env_stride);
-            h = coop_collides(P, L.qverts, c_, s_, px_, py_, words, map.rows, map.cols, map.wpr, wide);
+            h = coop_collides(P, vqx, vqy, c_, s_, px_, py_, words, map.rows, map.cols, map.wpr, wide);
         }
         if (lane_id() == src) hit = h;
     }
@@ -418,9 +445,10 @@ struct Pending {
 
 // Everything of PlanEnv.step() that follows pose_collides(): rollback (env.py:458-459), bookkeeping (:382-396),
 // reward (:352), done (:407-419), outputs, optional reset, state write-back.  Runs on one lane for env i.
-__device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr)
+__device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
+                                             const PathWindow* free_window = nullptr)
 {
-    const DevParams& P = a.P;
+    const DevParams& P = a.S->P;
     const bool tri = P.model == BCP_MODEL_TRICYCLE;
     Robot& r = q.r;
     if (hit) {  // robot.set_pose(*old_position): pose restored, v = w = 0 (tricycle_model.py:471-476)
@@ -436,18 +464,25 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     // shared path: uniform pointers (scalar cache); private paths: per-lane pointers
     double rew = 0.0;
     int m;
-    if (a.path.shared) {
-        m = a.path.max_len;
+    // way-point window of the final pose: the caller may have looked it up already for the un-rolled-back pose
+    const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : i * 8);
+    const int16_t* index = a.S->path.index + (a.S->path.shared ? 0 : i * (int64_t)(4 * kPathBuckets));
+    if (a.S->path.shared) {
+        m = a.S->path.max_len;
         if (a.flags & (1u << 17)) {
-        } else if (lds_path)  // way points staged in LDS by the step kernel: no global round trip per candidate
-            rew = reward_step(P, lds_path, a.path.bbox, a.path.index, m, r.p.x, r.p.y, r.p.th, min_dist, target);
-        else
-            rew = reward_step(P, a.path.pts, a.path.bbox, a.path.index, m, r.p.x, r.p.y, r.p.th, min_dist, target);
+        } else {
+            const PathWindow w = (free_window && !hit) ? *free_window : path_window(P, bbox, index, r.p.x, r.p.y);
+            if (lds_path)  // way points staged in LDS by the step kernel: no global round trip per candidate
+                rew = reward_step(P, lds_path, w, m, r.p.x, r.p.y, r.p.th, min_dist, target);
+            else
+                rew = reward_step(P, a.S->path.pts, w, m, r.p.x, r.p.y, r.p.th, min_dist, target);
+        }
     } else {
-        m = a.path.lens[i];
-        if (!(a.flags & (1u << 17)))
-            rew = reward_step(P, a.path.pts + i * (int64_t)a.path.max_len * 5, a.path.bbox + i * 8,
-                              a.path.index + i * (int64_t)(4 * kPathBuckets), m, r.p.x, r.p.y, r.p.th, min_dist, target);
+        m = a.S->path.lens[i];
+        if (!(a.flags & (1u << 17))) {
+            const PathWindow w = (free_window && !hit) ? *free_window : path_window(P, bbox, index, r.p.x, r.p.y);
+            rew = reward_step(P, a.S->path.pts + i * (int64_t)a.S->path.max_len * 5, w, m, r.p.x, r.p.y, r.p.th, min_dist, target);
+        }
     }
     const bool done = (target > m - 1) || (iter >= P.iteration_timeout) || collided;
 
@@ -463,79 +498,53 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     }
 
     if (done && (a.flags & BCP_STEP_AUTO_RESET)) {  // PlanEnv.reset(): set_state(initial_state) (env.py:293-303)
-        r.p.x = a.init.x[i];
-        r.p.y = a.init.y[i];
-        r.p.th = a.init.angle[i];
-        r.v = a.init.v[i];
-        r.w = a.init.w[i];
+        r.p.x = a.S->init.x[i];
+        r.p.y = a.S->init.y[i];
+        r.p.th = a.S->init.angle[i];
+        r.v = a.S->init.v[i];
+        r.w = a.S->init.w[i];
         if (tri) {
-            r.steer = a.init.steer[i];
-            r.wheel = a.init.wheel[i];
+            r.steer = a.S->init.steer[i];
+            r.wheel = a.S->init.wheel[i];
         }
-        min_dist = a.init.min_dist[i];
-        target = a.init.target_idx[i];
-        iter = a.init.cur_iter[i];
-        collided = a.init.collided[i] != 0;
+        min_dist = a.S->init.min_dist[i];
+        target = a.S->init.target_idx[i];
+        iter = a.S->init.cur_iter[i];
+        collided = a.S->init.collided[i] != 0;
     }
 
-    a.st.x[i] = r.p.x;
-    a.st.y[i] = r.p.y;
-    a.st.angle[i] = r.p.th;
-    a.st.v[i] = r.v;
-    a.st.w[i] = r.w;
+    a.S->st.x[i] = r.p.x;
+    a.S->st.y[i] = r.p.y;
+    a.S->st.angle[i] = r.p.th;
+    a.S->st.v[i] = r.v;
+    a.S->st.w[i] = r.w;
     if (tri) {
-        a.st.steer[i] = r.steer;
-        a.st.wheel[i] = r.wheel;
+        a.S->st.steer[i] = r.steer;
+        a.S->st.wheel[i] = r.wheel;
     }
-    a.st.min_dist[i] = min_dist;
-    a.st.target_idx[i] = target;
-    a.st.cur_iter[i] = iter;
-    a.st.collided[i] = (uint8_t)collided;
+    a.S->st.min_dist[i] = min_dist;
+    a.S->st.target_idx[i] = target;
+    a.S->st.cur_iter[i] = iter;
+    a.S->st.collided[i] = (uint8_t)collided;
 }
 
-// Kernel 1 of a step: robot model + collision for every env.  With a distance field (shared map) a pose is
-// cleared in O(1) by the outer test; the few envs it cannot clear are finished optimistically ("free") AND parked in
-// `pending`, and kernel 2 redoes those that really collide.  Without a distance field the exact rasterisers run in
-// place (collides_wave).
-__global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
+// ---- loads shared by the step kernels ------------------------------------------------------------------------
+__device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, Pending& q, double& cmd0, double& cmd1)
 {
-    const DevParams& P = a.P;
-    const int tid = threadIdx.x;
-    const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
-    const bool active = gi < a.n;
-    const int64_t i = active ? gi : a.n - 1;  // inactive lanes of the last wave shadow env n-1 and never store
-    const bool defer = a.pending != nullptr;
-
-    CollisionLds L;
-    __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
-    if (!defer) {
-        L = collision_lds_setup(P, a.map, tid);
-    } else {  // the deferring kernel keeps the scaled footprint and (when it fits) the shared path in LDS
-        for (int k = tid; k < 2 * P.n_verts; k += kBlock) qv[k] = P.qverts[k >> 1][k & 1];
-        if (a.lds_path_doubles)
-            for (int k = tid; k < a.lds_path_doubles; k += kBlock) qv[2 * P.n_verts + k] = a.path.pts[k];
-        __syncthreads();
-    }
-    const LdsF64 lds_path = (defer && a.lds_path_doubles) ? (LdsF64)(qv + 2 * P.n_verts) : (LdsF64) nullptr;
-    if (defer && gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
-
-    // ---- load state
-    Pending q;
+    const DevParams& P = a.S->P;
     Robot& r = q.r;
-    r.p.x = a.st.x[i];
-    r.p.y = a.st.y[i];
-    r.p.th = a.st.angle[i];
-    r.v = a.st.v[i];
-    r.w = a.st.w[i];
+    r.p.x = a.S->st.x[i];
+    r.p.y = a.S->st.y[i];
+    r.p.th = a.S->st.angle[i];
+    r.v = a.S->st.v[i];
+    r.w = a.S->st.w[i];
     const bool tri = P.model == BCP_MODEL_TRICYCLE;
-    r.steer = tri ? a.st.steer[i] : 0.0;
-    r.wheel = tri ? a.st.wheel[i] : 0.0;
-    q.min_dist = a.st.min_dist[i];
-    q.target = a.st.target_idx[i];
-    q.iter = a.st.cur_iter[i];
-    q.collided = a.st.collided[i] != 0;
-
-    double cmd0, cmd1;
+    r.steer = tri ? a.S->st.steer[i] : 0.0;
+    r.wheel = tri ? a.S->st.wheel[i] : 0.0;
+    q.min_dist = a.S->st.min_dist[i];
+    q.target = a.S->st.target_idx[i];
+    q.iter = a.S->st.cur_iter[i];
+    q.collided = a.S->st.collided[i] != 0;
     if (a.flags & BCP_STEP_ACTIONS_F32) {
         const float2 c = reinterpret_cast<const float2*>(a.actions)[i];
         cmd0 = (double)c.x;
@@ -552,90 +561,180 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
             q.z[1] = a.noise_z[3 * i + 1];
             q.z[2] = a.noise_z[3 * i + 2];
         } else {
-            device_normals(a.seed, (uint64_t)(a.env_id_base + i), a.step_counter, q.z);
+            device_normals(a.seed, (uint64_t)(a.S->env_id_base + i), a.step_counter, q.z);
         }
     }
+}
+
+// General step kernel: robot model, collision settled in place by collides_wave (distance-field classification when
+// there is one, then the cooperative / per-thread exact rasterisers), reward, done, write-back.  Used when there
+// is no distance field, when the batch is too small to need load balancing, or when a mode is forced.
+__global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
+{
+    const DevParams& P = a.S->P;
+    const int tid = threadIdx.x;
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
+    const bool active = gi < a.S->n;
+    const int64_t i = active ? gi : a.S->n - 1;  // inactive lanes of the last wave shadow env n-1 and never store
+
+    const CollisionLds L = collision_lds_setup(P, a.S->map, tid);
+    Pending q;
+    double cmd0, cmd1;
+    load_env(a, i, q, cmd0, cmd1);
 
     // ---- _env_step (envs/base/env.py:442-461)
+    q.old = q.r.p;
+    q.drawn = 0;
+    q.err = robot_step(P, q.r, cmd0, cmd1, q.z, q.drawn);
+    bool hit = false;
+    if (!(a.flags & (1u << 16)))
+        hit = collides_wave(P, a.S->map, a.S->cull, L, a.S->exact_mode, a.S->dense_threshold, a.S->wide != 0, active, i, q.r.p.x,
+                            q.r.p.y, q.r.p.th);
+    if (!active) return;
+    finalize_env(a, i, q, hit);
+}
+
+// Fast step kernel (kernel 1 of the two-kernel step; needs a distance field).  A pose is cleared in O(1) by the
+// outer test; the few envs it cannot clear are finished optimistically ("free") AND parked in `pending`, and kernel 2
+// redoes those that really collide.  Waves with many undecided lanes (robots hugging walls) settle them in place.
+// Memory operations are grouped so that independent round trips overlap: every wave runs alone on its SIMD, so an
+// exposed L2 / HBM latency is pure stall.
+__global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
+{
+    const DevParams& P = a.S->P;
+    const int tid = threadIdx.x;
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
+    const bool active = gi < a.S->n;
+    const int64_t i = active ? gi : a.S->n - 1;
+
+    // (1) loads for the LDS staging of the scaled footprint and of the shared path (up to 8 doubles per lane per
+    //     round), issued first ...
+    __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
+    const int nq = 2 * P.n_verts;
+    const double my_q = tid < nq ? P.qverts[tid >> 1][tid & 1] : 0.0;
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = u * kBlock + tid;
+        t[u] = k < a.S->lds_path_doubles ? a.S->path.pts[k] : 0.0;
+    }
+    // (2) ... then state, action, noise (the first-touch lines of this step): all of it is in flight together
+    Pending q;
+    double cmd0, cmd1;
+    load_env(a, i, q, cmd0, cmd1);
+    if (gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
+    // (3) LDS writes (the staging loads return first, in issue order)
+    if (tid < nq) qv[tid] = my_q;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = u * kBlock + tid;
+        if (k < a.S->lds_path_doubles) qv[nq + k] = t[u];
+    }
+    for (int k = 8 * kBlock + tid; k < a.S->lds_path_doubles; k += kBlock) qv[nq + k] = a.S->path.pts[k];  // long paths
+    __syncthreads();
+    const LdsF64 lds_path = a.S->lds_path_doubles ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
+
+    // ---- _env_step (envs/base/env.py:442-461)
+    Robot& r = q.r;
     q.old = r.p;
     q.drawn = 0;
     q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
 
+    // (3) everything that depends only on the new pose is looked up together: distance-field samples and the
+    //     way-point window of the reward
+    double ox = a.S->map.ox, oy = a.S->map.oy;
+    if (a.S->map.origins) {
+        ox = a.S->map.origins[2 * i + 0];
+        oy = a.S->map.origins[2 * i + 1];
+    }
+    const int px = (int)rint((r.p.x - ox) * a.S->map.inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
+    const int py = (int)rint((r.p.y - oy) * a.S->map.inv_res);
+    const double c = cos(r.p.th), s = sin(r.p.th);
+    const int64_t map_env = a.S->map.shared ? 0 : i;
+    OuterLookups look;
+    look.off_map = true;
+    if (!(a.flags & ((1u << 16) | (1u << 22)))) look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
+    const PathWindow win = path_window(P, a.S->path.bbox + (a.S->path.shared ? 0 : i * 8),
+                                       a.S->path.index + (a.S->path.shared ? 0 : i * (int64_t)(4 * kPathBuckets)), r.p.x, r.p.y);
+    const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
+
     bool hit = false;
-    if (a.flags & (1u << 16)) {
-        // collision test disabled (timing experiments only)
-    } else if (defer) {
-        double ox = a.map.ox, oy = a.map.oy;
-        if (a.map.origins) {
-            ox = a.map.origins[2 * i + 0];
-            oy = a.map.origins[2 * i + 1];
+    const uint64_t amb = __ballot(cls == kAmbiguous);
+    if ((int)__popcll(amb) > a.S->dense_threshold) {
+        // many undecided lanes in this wave: settle them in place, one pose at a time by the whole wave
+        const bool inner = cls == kAmbiguous && classify_inner_hit(a.S->cull, map_env, px, py, c, s);
+        hit = inner;
+        uint64_t todo = __ballot(cls == kAmbiguous && !inner);
+        const double vqx = tid < P.n_verts ? qv[2 * tid] : 0.0, vqy = tid < P.n_verts ? qv[2 * tid + 1] : 0.0;
+        while (todo) {
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const int64_t env_ = ((int64_t)bcast_i((int)(i >> 32), src) << 32) | (uint32_t)bcast_i((int)i, src);
+            const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : env_ * a.S->map.env_stride);
+            const bool h = coop_collides(P, vqx, vqy, bcast_d(c, src), bcast_d(s, src), bcast_i(px, src), bcast_i(py, src),
+                                         words, a.S->map.rows, a.S->map.cols, a.S->map.wpr, a.S->wide != 0);
+            if (tid == src) hit = h;
         }
-        const int px = (int)rint((r.p.x - ox) * a.map.inv_res);  // world_to_pixel
-        const int py = (int)rint((r.p.y - oy) * a.map.inv_res);
-        const double c = cos(r.p.th), s = sin(r.p.th);
-        const int cls = (active && !(a.flags & (1u << 22))) ? classify_outer(a.cull, a.map.shared ? 0 : i, a.map.rows, a.map.cols, px, py, c, s) : kFree;
-        const uint64_t amb = __ballot(cls == kAmbiguous);
-        if (__popcll(amb) > a.dense_threshold) {
-            // Many undecided lanes in this wave (robots hugging walls): settle them in place, one pose at a time by
-            // the whole wave -- the per-wave load is balanced anyway and the pose is already in registers.
-            const bool inner = cls == kAmbiguous && classify_inner_hit(a.cull, a.map.shared ? 0 : i, px, py, c, s);
-            hit = inner;
-            uint64_t todo = __ballot(cls == kAmbiguous && !inner);
-            while (todo) {
-                const int src = __ffsll((unsigned long long)todo) - 1;
-                todo &= todo - 1;
-                const int64_t env_ = ((int64_t)bcast_i((int)(i >> 32), src) << 32) | (uint32_t)bcast_i((int)i, src);
-                const uint32_t* words = a.map.bits + (a.map.shared ? 0 : env_ * a.map.env_stride);
-                const bool h = coop_collides(P, (LdsF64)qv, bcast_d(c, src), bcast_d(s, src), bcast_i(px, src),
-                                             bcast_i(py, src), words, a.map.rows, a.map.cols, a.map.wpr, a.wide != 0);
-                if (lane_id() == src) hit = h;
-            }
-        } else if (cls == kAmbiguous && !(a.flags & (1u << 21))) {
-            // A few undecided lanes: park the pre-verdict state for kernel 2 (one wave per pose, load-balanced over
-            // the whole GPU) and carry on as if the pose were free, which it is for nearly every parked env;
-            // kernel 2 redoes the finalisation of the few that do collide.
-            const int shard = (int)(blockIdx.x % kShards);
-            const int slot = atomicAdd(a.pending_count + shard, 1);
-            q.c = c;
-            q.s = s;
-            q.px = px;
-            q.py = py;
-            q.env_lo = (int32_t)(uint32_t)i;
-            q.env_hi = (int32_t)(i >> 32);
-            a.pending[(int64_t)shard * a.pending_cap + slot] = q;
-        }
-    } else {
-        hit = collides_wave(P, a.map, a.cull, L, a.exact_mode, a.dense_threshold, a.wide != 0, active, i, r.p.x, r.p.y,
-                            r.p.th);
+    } else if (cls == kAmbiguous && !(a.flags & (1u << 21))) {
+        // a few undecided lanes: park the pre-verdict state for kernel 2 (load-balanced over the whole GPU) and carry
+        // on as if the pose were free, which it is for nearly every parked env
+        const int shard = (int)(blockIdx.x % kShards);
+        const int slot = atomicAdd(a.pending_count + shard, 1);
+        q.c = c;
+        q.s = s;
+        q.px = px;
+        q.py = py;
+        q.env_lo = (int32_t)(uint32_t)i;
+        q.env_hi = (int32_t)(i >> 32);
+        a.S->pending[(int64_t)slot * kShards + shard] = q;  // interleaved: the used slots stay in a few pages
     }
     if (!active) return;
-    finalize_env(a, i, q, hit, lds_path);
+    finalize_env(a, i, q, hit, lds_path, &win);
 }
 
-// Kernel 2 of a step: one wavefront per parked env.  Inner distance-field test, then all 64 lanes rasterise the
-// footprint together (coop_collides); on a collision lane 0 redoes the env's finalisation from the parked state.
-constexpr int kPendingWaves = 2;  // wavefronts sharing one parked pose: wave w rasterises the row chunks w, w+2, ...
+// Kernel 2 of a step: kPendingWaves wavefronts per parked env.  Inner distance-field test, then the lanes rasterise
+// the footprint together (coop_collides, wave w takes the row chunks w, w+2, ...); on a collision thread 0 redoes
+// the env's finalisation from the parked state.  The first entry is fetched speculatively, together with the
+// counter that says whether it exists, so the two round trips overlap.
+constexpr int kPendingWaves = 4;  // wave = 2 * (row-chunk slot) + (edge slot)
+
+#ifdef BCP_DIAG
+__device__ unsigned long long g_diag[1024 * 8];
+#define DIAG_STAMP(k) do { if (threadIdx.x == 0) g_diag[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int bcp_diag_read(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(g_diag));
+}
+#else
+#define DIAG_STAMP(k) do { } while (0)
+#endif
 
 __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(const StepArgs a)
 {
-    const DevParams& P = a.P;
-    __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
-    for (int k = threadIdx.x; k < 2 * P.n_verts; k += kBlock * kPendingWaves) qv[k] = P.qverts[k >> 1][k & 1];
-    __syncthreads();
-    const int wave = threadIdx.x / kBlock;
+    DIAG_STAMP(0);
+    const DevParams& P = a.S->P;
+    const int lane = threadIdx.x % kBlock, wave = threadIdx.x / kBlock;
     const int shard = (int)(blockIdx.x % kShards);
+    const int stride = gridDim.x / kShards;
+    const Pending* slots = a.S->pending + shard;
+    const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
     const int count = a.pending_count[shard];
-    for (int idx = blockIdx.x / kShards; idx < count; idx += gridDim.x / kShards) {
-        const Pending* e = a.pending + ((int64_t)shard * a.pending_cap + idx);
+    for (int idx = blockIdx.x / kShards; idx < a.S->pending_cap; idx += stride) {
+        const Pending* e = slots + (int64_t)idx * kShards;   // in bounds whatever `count` says
         const double c = e->c, s = e->s;
         const int px = e->px, py = e->py;
         const int64_t i = ((int64_t)e->env_hi << 32) | (uint32_t)e->env_lo;
-        const uint32_t* words = a.map.bits + (a.map.shared ? 0 : i * a.map.env_stride);
-        bool hit = (a.flags & (1u << 20)) ? false : classify_inner_hit(a.cull, a.map.shared ? 0 : i, px, py, c, s);
-        if (!hit && !(a.flags & (1u << 19)))
-            hit = coop_collides(P, qv, c, s, px, py, words, a.map.rows, a.map.cols, a.map.wpr, a.wide != 0, wave,
-                                kPendingWaves);
+        if (idx >= count) break;
+        DIAG_STAMP(1);
+        const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : i * a.S->map.env_stride);
+        bool hit = (a.flags & (1u << 20)) ? false : classify_inner_hit(a.S->cull, a.S->map.shared ? 0 : i, px, py, c, s);
+        DIAG_STAMP(2);
+        if (!hit && !(a.flags & (1u << 19)))  // (the inner verdict is uniform over the workgroup: no barrier mismatch)
+            hit = coop_collides_quad(P, vqx, vqy, c, s, px, py, words, a.S->map.rows, a.S->map.cols, a.S->map.wpr,
+                                     a.S->wide != 0, wave, (LdsU32)lds_dyn);
+        DIAG_STAMP(3);
         hit = __syncthreads_or(hit);  // wave-uniform verdicts of the block's waves
+        DIAG_STAMP(4);
         // kernel 1 already finished this env as "free"; only a collision changes anything
         if (hit && threadIdx.x == 0) {
             Pending q = *e;
@@ -750,7 +849,7 @@ __global__ void __launch_bounds__(kBlock) pixel_footprint_kernel(DevParams P, co
         shape_hw[2 * i] = 2 * sink.hy + 1;
         shape_hw[2 * i + 1] = 2 * sink.hx + 1;
     }
-    coop_raster<8>(P, q, c, s, sink);
+    coop_raster<8, 1>(P, tid < P.n_verts ? q[2 * tid] : 0.0, tid < P.n_verts ? q[2 * tid + 1] : 0.0, c, s, sink);
 }
 
 // same image through the per-thread rasteriser (one thread per angle): cross-checks the two exact paths
@@ -1017,6 +1116,7 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->dense_threshold = 6;
     h->cull_enabled = 1;
     h->defer = 1;
+    h->static_dirty = true;
     fill_dev_params(h);
     *out = h;
     return BCP_OK;
@@ -1034,6 +1134,7 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->edt_col) (void)hipFree(h->edt_col);
     if (h->pending) (void)hipFree(h->pending);
     if (h->pending_count) (void)hipFree(h->pending_count);
+    if (h->dev_static) (void)hipFree(h->dev_static);
     delete h;
     return BCP_OK;
 }
@@ -1049,6 +1150,7 @@ extern "C" int bcp_seed(bcp_handle* h, uint64_t seed)
 extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
 {
     if (!h) return fail(BCP_E_INVALID, "bcp_set_tuning: null handle");
+    h->static_dirty = true;
     switch (key) {
         case BCP_TUNE_EXACT_MODE:
             if (value < 0 || value > 2) return fail(BCP_E_INVALID, "bcp_set_tuning: exact mode must be 0, 1 or 2");
@@ -1162,6 +1264,7 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
         }
     }
     h->have_map = true;
+    h->static_dirty = true;
     return BCP_OK;
 }
 
@@ -1217,6 +1320,7 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
     h->path.max_len = max_len;
     h->path.shared = shared ? 1 : 0;
     h->have_path = true;
+    h->static_dirty = true;
     return BCP_OK;
 }
 
@@ -1227,6 +1331,7 @@ extern "C" int bcp_bind_state(bcp_handle* h, const bcp_state* state)
         return fail(BCP_E_INVALID, "bcp_bind_state: missing state array");
     h->st = to_dev_state(state);
     h->have_state = true;
+    h->static_dirty = true;
     return BCP_OK;
 }
 
@@ -1237,6 +1342,7 @@ extern "C" int bcp_bind_initial_state(bcp_handle* h, const bcp_state* initial)
         return fail(BCP_E_INVALID, "bcp_bind_initial_state: missing state array");
     h->init = to_dev_state(initial);
     h->have_init = true;
+    h->static_dirty = true;
     return BCP_OK;
 }
 
@@ -1253,20 +1359,49 @@ extern "C" int bcp_reset_masked(bcp_handle* h, const uint8_t* mask, void* stream
     return BCP_OK;
 }
 
+// (re)builds the device-resident StepStatic block; returns whether the two-kernel (deferring) step is in effect
+static bool step_uses_deferral(const bcp_handle* h)
+{
+    return h->defer && h->cull.on && h->exact_mode == 0 && h->pending != nullptr;
+}
+
+static int upload_step_static(bcp_handle* h, hipStream_t s)
+{
+    StepStatic& S = h->host_static;
+    S.P = h->dev;
+    S.map = h->map;
+    S.cull = h->cull;
+    S.path = h->path;
+    S.st = h->st;
+    S.init = h->init;
+    S.n = h->n;
+    S.env_id_base = h->env_id_base;
+    S.exact_mode = h->exact_mode;
+    // fewer waves than SIMDs: nothing to balance, settle every undecided pose inside the step kernel
+    S.dense_threshold = (h->n + kBlock - 1) / kBlock < 1024 && h->exact_mode == 0 ? -1 : h->dense_threshold;
+    S.wide = h->wide;
+    S.pending_cap = h->pending_cap;
+    const bool defer = step_uses_deferral(h);
+    S.pending = defer ? (Pending*)h->pending : nullptr;
+    S.lds_path_doubles =
+        (defer && h->path.shared && h->path.max_len * 5 * sizeof(double) <= 24 * 1024) ? h->path.max_len * 5 : 0;
+    if (getenv("BCP_DEBUG_NO_LDS_PATH")) S.lds_path_doubles = 0;  // timing experiments
+    if (!h->dev_static) HIP_TRY(hipMalloc((void**)&h->dev_static, sizeof(StepStatic)));
+    // pageable source: the copy is staged before the call returns, so host_static may change afterwards
+    HIP_TRY(hipMemcpyAsync(h->dev_static, &S, sizeof(StepStatic), hipMemcpyHostToDevice, s));
+    h->static_dirty = false;
+    return BCP_OK;
+}
+
 static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hipStream_t s, bool first_only = false)
 {
+    if (h->static_dirty) {
+        const int rc = upload_step_static(h, s);
+        if (rc != BCP_OK) return rc;
+    }
+    const StepStatic& S = h->host_static;
     StepArgs a;
-    a.P = h->dev;
-    a.map = h->map;
-    a.cull = h->cull;
-    a.exact_mode = h->exact_mode;
-    // fewer waves than SIMDs: nothing to balance, settle every undecided pose inside the step kernel
-    a.dense_threshold = (h->n + kBlock - 1) / kBlock < 1024 && h->exact_mode == 0 ? -1 : h->dense_threshold;
-    a.wide = h->wide;
-    a.path = h->path;
-    a.st = h->st;
-    a.init = h->init;
-    a.n = h->n;
+    a.S = h->dev_static;
     a.actions = io->actions;
     a.noise_z = io->noise_z;
     a.noise_z_out = io->noise_z_out;
@@ -1277,23 +1412,17 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     a.flags = flags;
     a.seed = h->seed;
     a.step_counter = h->step_counter;
-    a.env_id_base = h->env_id_base;
-    const bool defer = h->defer && h->cull.on && h->exact_mode == 0 && h->pending != nullptr;
-    a.pending = defer ? (Pending*)h->pending : nullptr;
     a.pending_count = h->pending_count + (h->step_counter & 1) * kShards;
     a.pending_next = h->pending_count + ((h->step_counter + 1) & 1) * kShards;
-    a.pending_cap = h->pending_cap;
-    a.lds_path_doubles = 0;
     const int blocks = (int)((h->n + kBlock - 1) / kBlock);
-    if (defer) {
-        // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest, one wave each
-        a.lds_path_doubles = (h->path.shared && h->path.max_len * 5 * sizeof(double) <= 24 * 1024) ? h->path.max_len * 5 : 0;
-        hipLaunchKernelGGL(step_kernel, dim3(blocks), dim3(kBlock),
-                           ((size_t)h->params.n_verts * 2 + a.lds_path_doubles) * sizeof(double), s, a);
-        const int waves = 1024;  // a multiple of kShards: 16 waves per shard
-        if (!first_only)
+    if (S.pending) {
+        // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest
+        hipLaunchKernelGGL(step_fast_kernel, dim3(blocks), dim3(kBlock),
+                           ((size_t)h->params.n_verts * 2 + S.lds_path_doubles) * sizeof(double), s, a);
+        const int waves = 1024;  // a multiple of kShards: 16 blocks per shard
+        if (!first_only && S.dense_threshold >= 0)  // (threshold < 0: everything was settled in place)
             hipLaunchKernelGGL(step_pending_kernel, dim3(waves), dim3(kBlock * kPendingWaves),
-                               (size_t)h->params.n_verts * 2 * sizeof(double), s, a);
+                               (size_t)2 * 4 * (S.wide ? 8 : 3) * 64 * sizeof(uint32_t), s, a);
     } else {
         const size_t lds = collision_lds_bytes(h->params.n_verts, h->map.in_lds, h->map.rows, h->map.wpr);
         hipLaunchKernelGGL(step_kernel, dim3(blocks), dim3(kBlock), lds, s, a);
