@@ -366,32 +366,35 @@ struct CoopCollisionSink {
 };
 
 // exact pose_collides for ONE pose, all 64 lanes cooperating; returns a wave-uniform verdict.
-// `wide`: the kernel image may be wider than 96 px (use the 8-word row masks).
+// WIDE: the kernel image may be wider than 96 px (8-word row masks instead of 3).  It is a template parameter so that
+// a kernel carries only the variant it needs (the rasteriser is the bulk of the code).
+template <bool WIDE, typename WordPtr>
+__device__ __forceinline__ bool coop_collides(const DevParams& P, double qx, double qy, double c, double s, int px,
+                                              int py, WordPtr words, int rows, int cols, int wpr)
+{
+    constexpr int NW = WIDE ? 8 : 3;
+    CoopCollisionSink<NW, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
+    return coop_raster<NW, 1>(P, qx, qy, c, s, sink);
+}
+
+// runtime-selected width (operator kernels, where code size does not matter)
 template <typename WordPtr>
 __device__ __forceinline__ bool coop_collides(const DevParams& P, double qx, double qy, double c, double s, int px,
-                              int py, WordPtr words, int rows, int cols, int wpr, bool wide)
+                                              int py, WordPtr words, int rows, int cols, int wpr, bool wide)
 {
-    if (!wide) {
-        CoopCollisionSink<3, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
-        return coop_raster<3, 1>(P, qx, qy, c, s, sink);
-    }
-    CoopCollisionSink<8, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
-    return coop_raster<8, 1>(P, qx, qy, c, s, sink);
+    return wide ? coop_collides<true>(P, qx, qy, c, s, px, py, words, rows, cols, wpr)
+                : coop_collides<false>(P, qx, qy, c, s, px, py, words, rows, cols, wpr);
 }
 
 // the same for a workgroup of 4 waves on one pose: wave = 2 * chunk slot + edge slot.  `xch`: 2 * 4 * NW * 64 words
 // of LDS.  Returns this wave's partial verdict (OR them over the workgroup).
-template <typename WordPtr>
+template <bool WIDE, typename WordPtr>
 __device__ __forceinline__ bool coop_collides_quad(const DevParams& P, double qx, double qy, double c, double s, int px,
-                                                   int py, WordPtr words, int rows, int cols, int wpr, bool wide, int wave,
-                                                   LdsU32 xch)
+                                                   int py, WordPtr words, int rows, int cols, int wpr, int wave, LdsU32 xch)
 {
-    if (!wide) {
-        CoopCollisionSink<3, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
-        return coop_raster<3, 2>(P, qx, qy, c, s, sink, wave >> 1, 2, wave & 1, xch, wave);
-    }
-    CoopCollisionSink<8, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
-    return coop_raster<8, 2>(P, qx, qy, c, s, sink, wave >> 1, 2, wave & 1, xch, wave);
+    constexpr int NW = WIDE ? 8 : 3;
+    CoopCollisionSink<NW, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
+    return coop_raster<NW, 2>(P, qx, qy, c, s, sink, wave >> 1, 2, wave & 1, xch, wave);
 }
 
 }  // namespace bcp

@@ -294,16 +294,18 @@ __device__ __forceinline__ int last_reached_from(const DevParams& P, PathPtr pat
     const int hi = min(w.hi, m - 1);
     for (int j = hi; j >= lo; --j) {
         const PathPtr s = path + 5 * j;
-        const double dx = s[0] - x, dy = s[1] - y;
+        // all five values of the way point are fetched up front (one latency instead of three dependent ones)
+        const double sx = s[0], sy = s[1], sth = s[2], sc = s[3], ss = s[4];
+        const double dx = sx - x, dy = sy - y;
         // the three reach conditions are independent predicates; evaluate the cheap ones first
         if (fabs(dx) > P.sp_prune || fabs(dy) > P.sp_prune) continue;   // then hypot(dx,dy) >= sp
-        const double par = s[3] * (x - s[0]) + s[4] * (y - s[1]);       // path_tools.py:405
+        const double par = sc * (x - sx) + ss * (y - sy);               // path_tools.py:405
         if (!(par >= P.par_thr)) continue;
         const double q = dx * dx + dy * dy;
         bool near = q < P.sp2_lo;
         if (!near && q <= P.sp2_hi) near = hypot(dx, dy) < P.sp;        // too close to call from q
         if (!near) continue;
-        if (fabs(normalize_angle(th - s[2])) < P.ap) return j;
+        if (fabs(normalize_angle(th - sth)) < P.ap) return j;
     }
     return -1;
 }
@@ -314,7 +316,14 @@ __device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path, 
                                               double th, double& min_dist, int& target)
 {
     if (target > m - 1) return 0.0;
+#if defined(BCP_EXP_NOLOOP)
+    const int last = -1;
+#else
     const int last = last_reached_from(P, path, w, m, target, x, y, th);
+#endif
+#if defined(BCP_EXP_NOHYPOT)
+#define hypot(a, b) sqrt((a) * (a) + (b) * (b))
+#endif
     if (last >= 0) {
         target = last + 1;
         if (!(target > m - 1)) {
@@ -334,6 +343,24 @@ __device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path, 
     }
     return 0.0;
 }
+
+#ifdef BCP_DIAG
+__device__ unsigned long long g_diag[1024 * 8];
+__device__ unsigned long long g_diag1[1024 * 8];
+#define DIAG1_STAMP(k) do { if (threadIdx.x == 0) g_diag1[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DIAG_STAMP(k) do { if (threadIdx.x == 0) g_diag[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int bcp_diag_read(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(g_diag));
+}
+extern "C" int bcp_diag1_read(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag1), sizeof(g_diag1));
+}
+#else
+#define DIAG_STAMP(k) do { } while (0)
+#define DIAG1_STAMP(k) do { } while (0)
+#endif
 
 constexpr int kShards = 64;  // a wave parks into shard (block index % kShards)
 
@@ -485,6 +512,7 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
         }
     }
     const bool done = (target > m - 1) || (iter >= P.iteration_timeout) || collided;
+    if (free_window) DIAG1_STAMP(5);
 
     a.reward[i] = rew;
     a.done[i] = (uint8_t)done;
@@ -513,6 +541,7 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
         collided = a.S->init.collided[i] != 0;
     }
 
+    if (free_window) DIAG1_STAMP(6);
     a.S->st.x[i] = r.p.x;
     a.S->st.y[i] = r.p.y;
     a.S->st.angle[i] = r.p.th;
@@ -527,6 +556,10 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     a.S->st.cur_iter[i] = iter;
     a.S->st.collided[i] = (uint8_t)collided;
 }
+
+#if defined(BCP_EXP_NOHYPOT)
+#undef hypot
+#endif
 
 // ---- loads shared by the step kernels ------------------------------------------------------------------------
 __device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, Pending& q, double& cmd0, double& cmd1)
@@ -594,11 +627,13 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     finalize_env(a, i, q, hit);
 }
 
+
 // Fast step kernel (kernel 1 of the two-kernel step; needs a distance field).  A pose is cleared in O(1) by the
 // outer test; the few envs it cannot clear are finished optimistically ("free") AND parked in `pending`, and kernel 2
 // redoes those that really collide.  Waves with many undecided lanes (robots hugging walls) settle them in place.
 // Memory operations are grouped so that independent round trips overlap: every wave runs alone on its SIMD, so an
 // exposed L2 / HBM latency is pure stall.
+template <bool WIDE>
 __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
 {
     const DevParams& P = a.S->P;
@@ -606,6 +641,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
     const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
     const bool active = gi < a.S->n;
     const int64_t i = active ? gi : a.S->n - 1;
+    DIAG1_STAMP(0);
 
     // (1) loads for the LDS staging of the scaled footprint and of the shared path (up to 8 doubles per lane per
     //     round), issued first ...
@@ -632,6 +668,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
     }
     for (int k = 8 * kBlock + tid; k < a.S->lds_path_doubles; k += kBlock) qv[nq + k] = a.S->path.pts[k];  // long paths
     __syncthreads();
+    DIAG1_STAMP(1);
     const LdsF64 lds_path = a.S->lds_path_doubles ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
 
     // ---- _env_step (envs/base/env.py:442-461)
@@ -639,6 +676,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
     q.old = r.p;
     q.drawn = 0;
     q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
+    DIAG1_STAMP(2);
 
     // (3) everything that depends only on the new pose is looked up together: distance-field samples and the
     //     way-point window of the reward
@@ -657,6 +695,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
     const PathWindow win = path_window(P, a.S->path.bbox + (a.S->path.shared ? 0 : i * 8),
                                        a.S->path.index + (a.S->path.shared ? 0 : i * (int64_t)(4 * kPathBuckets)), r.p.x, r.p.y);
     const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
+    DIAG1_STAMP(3);
 
     bool hit = false;
     const uint64_t amb = __ballot(cls == kAmbiguous);
@@ -671,8 +710,8 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
             todo &= todo - 1;
             const int64_t env_ = ((int64_t)bcast_i((int)(i >> 32), src) << 32) | (uint32_t)bcast_i((int)i, src);
             const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : env_ * a.S->map.env_stride);
-            const bool h = coop_collides(P, vqx, vqy, bcast_d(c, src), bcast_d(s, src), bcast_i(px, src), bcast_i(py, src),
-                                         words, a.S->map.rows, a.S->map.cols, a.S->map.wpr, a.S->wide != 0);
+            const bool h = coop_collides<WIDE>(P, vqx, vqy, bcast_d(c, src), bcast_d(s, src), bcast_i(px, src),
+                                               bcast_i(py, src), words, a.S->map.rows, a.S->map.cols, a.S->map.wpr);
             if (tid == src) hit = h;
         }
     } else if (cls == kAmbiguous && !(a.flags & (1u << 21))) {
@@ -688,8 +727,10 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
         q.env_hi = (int32_t)(i >> 32);
         a.S->pending[(int64_t)slot * kShards + shard] = q;  // interleaved: the used slots stay in a few pages
     }
+    DIAG1_STAMP(4);
     if (!active) return;
     finalize_env(a, i, q, hit, lds_path, &win);
+    DIAG1_STAMP(7);
 }
 
 // Kernel 2 of a step: kPendingWaves wavefronts per parked env.  Inner distance-field test, then the lanes rasterise
@@ -698,17 +739,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
 // counter that says whether it exists, so the two round trips overlap.
 constexpr int kPendingWaves = 4;  // wave = 2 * (row-chunk slot) + (edge slot)
 
-#ifdef BCP_DIAG
-__device__ unsigned long long g_diag[1024 * 8];
-#define DIAG_STAMP(k) do { if (threadIdx.x == 0) g_diag[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int bcp_diag_read(unsigned long long* out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(g_diag));
-}
-#else
-#define DIAG_STAMP(k) do { } while (0)
-#endif
-
+template <bool WIDE>
 __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(const StepArgs a)
 {
     DIAG_STAMP(0);
@@ -730,8 +761,8 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
         bool hit = (a.flags & (1u << 20)) ? false : classify_inner_hit(a.S->cull, a.S->map.shared ? 0 : i, px, py, c, s);
         DIAG_STAMP(2);
         if (!hit && !(a.flags & (1u << 19)))  // (the inner verdict is uniform over the workgroup: no barrier mismatch)
-            hit = coop_collides_quad(P, vqx, vqy, c, s, px, py, words, a.S->map.rows, a.S->map.cols, a.S->map.wpr,
-                                     a.S->wide != 0, wave, (LdsU32)lds_dyn);
+            hit = coop_collides_quad<WIDE>(P, vqx, vqy, c, s, px, py, words, a.S->map.rows, a.S->map.cols, a.S->map.wpr, wave,
+                                           (LdsU32)lds_dyn);
         DIAG_STAMP(3);
         hit = __syncthreads_or(hit);  // wave-uniform verdicts of the block's waves
         DIAG_STAMP(4);
@@ -1417,12 +1448,17 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     const int blocks = (int)((h->n + kBlock - 1) / kBlock);
     if (S.pending) {
         // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest
-        hipLaunchKernelGGL(step_fast_kernel, dim3(blocks), dim3(kBlock),
-                           ((size_t)h->params.n_verts * 2 + S.lds_path_doubles) * sizeof(double), s, a);
+        const size_t lds1 = ((size_t)h->params.n_verts * 2 + S.lds_path_doubles) * sizeof(double);
+        const size_t lds2 = (size_t)2 * 4 * (S.wide ? 8 : 3) * 64 * sizeof(uint32_t);
         const int waves = 1024;  // a multiple of kShards: 16 blocks per shard
-        if (!first_only && S.dense_threshold >= 0)  // (threshold < 0: everything was settled in place)
-            hipLaunchKernelGGL(step_pending_kernel, dim3(waves), dim3(kBlock * kPendingWaves),
-                               (size_t)2 * 4 * (S.wide ? 8 : 3) * 64 * sizeof(uint32_t), s, a);
+        const bool second = !first_only && S.dense_threshold >= 0;  // (threshold < 0: everything settled in place)
+        if (S.wide) {
+            hipLaunchKernelGGL(step_fast_kernel<true>, dim3(blocks), dim3(kBlock), lds1, s, a);
+            if (second) hipLaunchKernelGGL(step_pending_kernel<true>, dim3(waves), dim3(kBlock * kPendingWaves), lds2, s, a);
+        } else {
+            hipLaunchKernelGGL(step_fast_kernel<false>, dim3(blocks), dim3(kBlock), lds1, s, a);
+            if (second) hipLaunchKernelGGL(step_pending_kernel<false>, dim3(waves), dim3(kBlock * kPendingWaves), lds2, s, a);
+        }
     } else {
         const size_t lds = collision_lds_bytes(h->params.n_verts, h->map.in_lds, h->map.rows, h->map.wpr);
         hipLaunchKernelGGL(step_kernel, dim3(blocks), dim3(kBlock), lds, s, a);
