@@ -199,6 +199,18 @@ class BatchedPlanEnv(object):
         self._bind(self.state, self._lib.bcp_bind_state)
         self._initial_state = self._make_initial_state()
         self._bind(self._initial_state, self._lib.bcp_bind_initial_state)
+        # per-step call state, built once (the step path itself should cost microseconds of host time)
+        self._io = _lib.BcpStepIO()
+        self._io.reward = self.reward.data_ptr()
+        self._io.done = self.done.data_ptr()
+        self._io.collided_now = self.collided_now.data_ptr()
+        self._io.err = self.err.data_ptr()
+        self._io_ref = C.byref(self._io)
+        self._bcp_step = self._lib.bcp_step
+        self._flags_f64 = _lib.STEP_AUTO_RESET if self.auto_reset else 0
+        self._flags_f32 = self._flags_f64 | _lib.STEP_ACTIONS_F32
+        self._obs = BatchedObservation(self)
+        self._info = {}
         self.seed(seed)
         self.reset()
 
@@ -396,7 +408,7 @@ class BatchedPlanEnv(object):
             mask = mask.to(self.device).to(torch.uint8).contiguous()
             ptr = mask.data_ptr()
         _lib.check(self._lib.bcp_reset_masked(self._h, ptr, self._stream()))
-        return BatchedObservation(self)
+        return self._obs
 
     def get_state(self):
         return self.state.copy()
@@ -413,28 +425,31 @@ class BatchedPlanEnv(object):
         """One tick for every env.  actions: [N,2] (float32 or float64) tensor / array, or a list of Action.
         noise_z: optional [N,3] float64 standard normals (slot order) replacing the on-device RNG.
         Returns (BatchedObservation, reward float64[N], done uint8[N], {}) -- device tensors, no sync."""
-        a = _as_device_actions(actions, self.n_envs, self.device)
-        io = _lib.BcpStepIO()
-        io.actions = a.data_ptr()
-        flags = _lib.STEP_ACTIONS_F32 if a.dtype == torch.float32 else 0
-        if self.auto_reset:
-            flags |= _lib.STEP_AUTO_RESET
+        # fast path: a device tensor of the right shape and dtype goes straight to the library
+        if not (isinstance(actions, torch.Tensor) and actions.device == self.device and actions.is_contiguous()
+                and actions.dtype in (torch.float32, torch.float64) and tuple(actions.shape) == (self.n_envs, 2)):
+            actions = _as_device_actions(actions, self.n_envs, self.device)
+        io = self._io
+        io.actions = actions.data_ptr()
+        flags = self._flags_f32 if actions.dtype == torch.float32 else self._flags_f64
         z = None
         if noise_z is not None:
             z = noise_z if isinstance(noise_z, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(noise_z))
             z = z.to(self.device, torch.float64).contiguous()
             assert tuple(z.shape) == (self.n_envs, 3)
             io.noise_z = z.data_ptr()
+        else:
+            io.noise_z = None
         if noise_z_out is not None:
             assert noise_z_out.dtype == torch.float64 and tuple(noise_z_out.shape) == (self.n_envs, 3)
             io.noise_z_out = noise_z_out.data_ptr()
-        io.reward = self.reward.data_ptr()
-        io.done = self.done.data_ptr()
-        io.collided_now = self.collided_now.data_ptr()
-        io.err = self.err.data_ptr()
-        _lib.check(self._lib.bcp_step(self._h, C.byref(io), flags, self._stream()))
-        self._last_inputs = (a, z)  # keep inputs alive until the stream has consumed them
-        return BatchedObservation(self), self.reward, self.done, {}
+        else:
+            io.noise_z_out = None
+        rc = self._bcp_step(self._h, self._io_ref, flags, torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            _lib.check(rc)
+        self._last_inputs = (actions, z)  # keep inputs alive until the stream has consumed them
+        return self._obs, self.reward, self.done, self._info
 
     def check_errors(self):
         """Raise what the reference would have raised during the last step (synchronises)."""

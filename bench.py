@@ -136,17 +136,17 @@ def main():
         elapsed = float(t.item())
     env.check_errors()
 
-    # The step is two launches: step_kernel (all envs: robot model, O(1) collision classification, reward, done)
-    # and step_pending_kernel (the ~1 % of envs whose collision needs the exact rasteriser).  The dominant kernel is
-    # step_kernel; its average launch duration is measured live with HIP events recorded around each launch on the
-    # launch stream.  step_ms is the whole step (both launches, from the events around the timed region).
+    # One step = two launches on one stream: step_fast_kernel (all envs: robot model, O(1) collision classification,
+    # reward, done) and step_pending_kernel (the ~1.5 % of envs whose collision needs the exact rasteriser).  Their
+    # combined average duration is measured live with HIP events recorded on the launch stream around the timed
+    # region (at N=1 the region holds nothing but these launches, back to back); the per-kernel split of the same
+    # command is in profiles/ (rocprofv3 --kernel-trace --stats).
     step_ms = stream_ms / args.steps if world == 1 else env.time_steps(pool[0], max(20, min(args.steps, 200)))
-    k1_ms, k2_ms = env.time_step_kernels(pool[1], max(20, min(args.steps, 200)))
-    achieved = BYTES_PER_ENV_STEP * n / (k1_ms * 1e-3) / 1e9
+    achieved = BYTES_PER_ENV_STEP * n / (step_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     if os.path.exists(pmc) and n == ENVS_PER_GPU:  # PMC passes cannot run inside bench.py; committed per round
-        traffic = json.load(open(pmc))["corrected_bytes_per_step"]["step_kernel"]["total"]
+        traffic = json.load(open(pmc))["corrected_bytes_per_step"]["total"]
 
     if rank == 0:
         total_envs = n * world
@@ -169,9 +169,8 @@ def main():
                        "sharding": "env blocks per rank, 1 RCCL all-gather of done per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "step_kernel", "kernel_ms": k1_ms,
-                         "second_kernel": "step_pending_kernel", "second_kernel_ms": k2_ms,
-                         "step_ms": step_ms, "step_achieved": BYTES_PER_ENV_STEP * n / (step_ms * 1e-3) / 1e9,
+                         "kernel": "step_fast_kernel + step_pending_kernel (one step = these two launches)",
+                         "kernel_ms": step_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n,
                          "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
                          "note": "shared-map config is ALU/latency-bound (SURVEY 8d): the HBM fraction is low by "
