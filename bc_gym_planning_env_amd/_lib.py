@@ -58,6 +58,7 @@ SYMBOLS = {
     "bcp_destroy": (C.c_int, [_H]),
     "bcp_seed": (C.c_int, [_H, C.c_uint64]),
     "bcp_set_tuning": (C.c_int, [_H, C.c_int32, C.c_int32]),
+    "bcp_set_geometry_pool": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p]),
     "bcp_set_costmaps": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
     "bcp_set_paths": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -143,11 +143,16 @@ class BatchedPlanEnv(object):
     :param env_id_base int: global index of env 0 (rank * n_envs when sharded over GPUs); keys the noise stream
     :param template_of_env: optional int array [n_envs]; `costmap` and `path` are then lists of T templates and env i
         gets a PRIVATE copy of costmap[template_of_env[i]] / path[template_of_env[i]] (built on the device)
+    :param geom_of_env: optional int array [n_envs] -> GEOMETRY POOL mode: `costmap` and `path` are lists of G pool
+        entries, env i runs on entry geom_of_env[i], and every reset (reset(), auto-reset) moves an env to
+        next_geom[entry] (RandomMiniEnv.reset with draw_new_turn_on_reset, envs/mini_env.py:469-481).  Note that the
+        constructor ends with reset(), like the reference's usage `env = RandomMiniEnv(); env.reset()`.
+    :param next_geom: optional int array [G], successor of every pool entry; None = stay on the same entry
     """
 
     def __init__(self, costmap, path, params=None, n_envs=1, device=0, robot_name=None, noise_parameters='planenv',
                  auto_reset=False, env_id_base=0, seed=0, footprint_scale=1.0, dynamic_model=True,
-                 model_front_column_pid=True, template_of_env=None):
+                 model_front_column_pid=True, template_of_env=None, geom_of_env=None, next_geom=None):
         params = EnvParams() if params is None else params
         if params.pose_delay or params.control_delay or params.state_delay:
             raise NotImplementedError("pose/control/state delays > 0 are not supported by the batched step")
@@ -191,7 +196,23 @@ class BatchedPlanEnv(object):
         self._keep = {}  # device buffers the library holds pointers to
 
         self._template_of_env = None if template_of_env is None else np.asarray(template_of_env, dtype=np.int64)
-        if self._template_of_env is not None:
+        self.geom_of_env = None
+        if geom_of_env is not None:
+            assert template_of_env is None
+            costmap, path = list(costmap), list(path)
+            g0 = np.asarray(geom_of_env, dtype=np.int32)
+            assert g0.shape == (n,) and len(costmap) == len(path) and 0 <= g0.min() and g0.max() < len(costmap)
+            self.geom_of_env = torch.from_numpy(g0.copy()).to(dev)
+            nxt = None
+            if next_geom is not None:
+                nx = np.asarray(next_geom, dtype=np.int32)
+                assert nx.shape == (len(costmap),) and 0 <= nx.min() and nx.max() < len(costmap)
+                nxt = torch.from_numpy(nx.copy()).to(dev)
+            self._keep.update(next_geom=nxt)
+            _lib.check(self._lib.bcp_set_geometry_pool(self._h, len(costmap), self.geom_of_env.data_ptr(),
+                                                       nxt.data_ptr() if nxt is not None else None))
+            self._set_from_templates(costmap, path)
+        elif self._template_of_env is not None:
             self._set_from_templates(list(costmap), list(path))
         else:
             self._set_costmaps(costmap)
@@ -267,8 +288,11 @@ class BatchedPlanEnv(object):
     def _set_from_templates(self, costmaps, paths):
         """Private per-env costmaps / paths expanded on the device from a few templates."""
         n, dev = self.n_envs, self.device
-        idx = torch.from_numpy(self._template_of_env).to(dev)
-        assert idx.numel() == n and int(idx.max()) < len(costmaps) == len(paths)
+        if self.geom_of_env is not None:   # geometry pool: the library indexes the entries itself
+            idx = torch.arange(len(costmaps), device=dev)
+        else:
+            idx = torch.from_numpy(self._template_of_env).to(dev)
+            assert idx.numel() == n and int(idx.max()) < len(costmaps) == len(paths)
         res = float(costmaps[0].get_resolution())
         rows = max(c.get_data().shape[0] for c in costmaps)
         cols = max(c.get_data().shape[1] for c in costmaps)
@@ -299,8 +323,9 @@ class BatchedPlanEnv(object):
         torch.cuda.current_stream(dev).synchronize()
 
     def set_costmap_tensors(self, data, origins, resolution, valid_rows=None, valid_cols=None):
-        """Private costmaps straight from device tensors: data uint8 [N, rows, cols], origins float64 [N, 2]."""
-        n = self.n_envs
+        """Private costmaps straight from device tensors: data uint8 [N, rows, cols], origins float64 [N, 2]
+        (N = pool entries in geometry-pool mode)."""
+        n = self.n_envs if self.geom_of_env is None else data.shape[0]
         assert data.dtype == torch.uint8 and data.dim() == 3 and data.shape[0] == n and data.is_contiguous()
         assert origins.dtype == torch.float64 and tuple(origins.shape) == (n, 2) and origins.is_contiguous()
         self._keep.update(map=data, origins=origins, vr=valid_rows, vc=valid_cols)
@@ -342,12 +367,16 @@ class BatchedPlanEnv(object):
         """make_initial_state (env.py:179-214): pose = path[0], v = w = 0, wheel at initial_wheel_angle... the
         reference's TricycleRobotState() default wheel angle is 0.0 and PlanEnv never applies
         params.initial_wheel_angle to it, so neither do we."""
-        n = self.n_envs
+        n = self.n_envs if self.geom_of_env is None else len(self._paths)
         robot = np.zeros((7, n), dtype=np.float64)
         md = np.zeros(n, dtype=np.float64)
         ti = np.zeros(n, dtype=np.int32)
         rp = self.params.reward_provider_params
-        if self._shared_path:
+        if self.geom_of_env is not None:   # one initial state per pool entry
+            for g, p in enumerate(self._paths):
+                md[g], ti[g] = host_init.initial_reward_state(p, rp)
+                robot[0:3, g] = p[0]
+        elif self._shared_path:
             p = self._paths[0]
             m0, t0 = host_init.initial_reward_state(p, rp)
             robot[0:3, :] = p[0][:, None]
@@ -375,11 +404,15 @@ class BatchedPlanEnv(object):
 
     # ------------------------------------------------------------------ per-env lookups
     def path_of(self, i):
+        if self.geom_of_env is not None:
+            return self._paths[int(self.geom_of_env[i])]
         if self._template_of_env is not None:
             return self._paths[self._template_of_env[i]]
         return self._paths[0] if self._shared_path else self._paths[i]
 
     def costmap_of(self, i):
+        if self.geom_of_env is not None:
+            return self._costmaps[int(self.geom_of_env[i])]
         if self._template_of_env is not None:
             return self._costmaps[self._template_of_env[i]]
         if self._shared_map or len(self._costmaps) == 1:

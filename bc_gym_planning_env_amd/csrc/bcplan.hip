@@ -84,6 +84,10 @@ struct StepStatic {
     int32_t pending_cap;       // slots per shard
     int32_t lds_path_doubles;  // > 0: the shared path (max_len * 5 doubles) is staged in LDS by the fast step kernel
     struct Pending* pending;   // [kShards][pending_cap] parking slots for undecided envs (nullptr: no second kernel)
+    // geometry pool (bcp_set_geometry_pool): env i uses entry geom_of_env[i] of the non-shared map / path / initial
+    // state arrays; a reset moves it to next_geom[entry].  nullptr: env i uses entry i.
+    int32_t* geom_of_env;
+    const int32_t* next_geom;
 };
 
 // Per-launch kernel arguments (small).
@@ -139,7 +143,13 @@ struct bcp_handle {
     int32_t dense_threshold;  // auto: more ambiguous lanes than this in a wave -> per-thread rasteriser
     int32_t cull_enabled;
     int32_t wide;             // kernel image may exceed 96 px: 8-word row masks in the cooperative path
+    int32_t n_geoms;          // > 0: geometry pool of that many entries
+    int32_t* geom_of_env;     // caller-owned device int32 [n]
+    const int32_t* next_geom; // caller-owned device int32 [n_geoms] or nullptr
 };
+
+// number of entries of a non-shared map / path / initial-state array
+static int64_t n_slots(const bcp_handle* h) { return h->n_geoms > 0 ? h->n_geoms : h->n; }
 
 static DevState to_dev_state(const bcp_state* s)
 {
@@ -468,7 +478,14 @@ struct Pending {
     int32_t target, iter, err, drawn;
     int32_t collided;   // sticky flag before this step
     int32_t env_lo, env_hi;
+    int32_t geom;       // geometry-pool entry of the env during this step (pool mode only)
 };
+
+// entry of the non-shared map / path arrays that env i uses
+__device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const Pending& q)
+{
+    return S->geom_of_env ? (int64_t)q.geom : i;
+}
 
 // Everything of PlanEnv.step() that follows pose_collides(): rollback (env.py:458-459), bookkeeping (:382-396),
 // reward (:352), done (:407-419), outputs, optional reset, state write-back.  Runs on one lane for env i.
@@ -492,8 +509,9 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     double rew = 0.0;
     int m;
     // way-point window of the final pose: the caller may have looked it up already for the un-rolled-back pose
-    const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : i * 8);
-    const int16_t* index = a.S->path.index + (a.S->path.shared ? 0 : i * (int64_t)(4 * kPathBuckets));
+    const int64_t g = slot_of(a.S, i, q);
+    const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : g * 8);
+    const int16_t* index = a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
     if (a.S->path.shared) {
         m = a.S->path.max_len;
         if (a.flags & (1u << 17)) {
@@ -505,10 +523,10 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
                 rew = reward_step(P, a.S->path.pts, w, m, r.p.x, r.p.y, r.p.th, min_dist, target);
         }
     } else {
-        m = a.S->path.lens[i];
+        m = a.S->path.lens[g];
         if (!(a.flags & (1u << 17))) {
             const PathWindow w = (free_window && !hit) ? *free_window : path_window(P, bbox, index, r.p.x, r.p.y);
-            rew = reward_step(P, a.S->path.pts + i * (int64_t)a.S->path.max_len * 5, w, m, r.p.x, r.p.y, r.p.th, min_dist, target);
+            rew = reward_step(P, a.S->path.pts + g * (int64_t)a.S->path.max_len * 5, w, m, r.p.x, r.p.y, r.p.th, min_dist, target);
         }
     }
     const bool done = (target > m - 1) || (iter >= P.iteration_timeout) || collided;
@@ -526,19 +544,26 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     }
 
     if (done && (a.flags & BCP_STEP_AUTO_RESET)) {  // PlanEnv.reset(): set_state(initial_state) (env.py:293-303)
-        r.p.x = a.S->init.x[i];
-        r.p.y = a.S->init.y[i];
-        r.p.th = a.S->init.angle[i];
-        r.v = a.S->init.v[i];
-        r.w = a.S->init.w[i];
-        if (tri) {
-            r.steer = a.S->init.steer[i];
-            r.wheel = a.S->init.wheel[i];
+        int64_t k = i;
+        if (a.S->geom_of_env) {  // RandomMiniEnv.reset(): the env moves on to its next geometry (mini_env.py:469-481).
+            // Computed from the entry the step started with, so kernel 2 redoing an env that kernel 1 already reset
+            // lands on the same geometry (a hit always ends the episode, so both reset or neither does).
+            k = a.S->next_geom ? a.S->next_geom[g] : g;
+            a.S->geom_of_env[i] = (int32_t)k;
         }
-        min_dist = a.S->init.min_dist[i];
-        target = a.S->init.target_idx[i];
-        iter = a.S->init.cur_iter[i];
-        collided = a.S->init.collided[i] != 0;
+        r.p.x = a.S->init.x[k];
+        r.p.y = a.S->init.y[k];
+        r.p.th = a.S->init.angle[k];
+        r.v = a.S->init.v[k];
+        r.w = a.S->init.w[k];
+        if (tri) {
+            r.steer = a.S->init.steer[k];
+            r.wheel = a.S->init.wheel[k];
+        }
+        min_dist = a.S->init.min_dist[k];
+        target = a.S->init.target_idx[k];
+        iter = a.S->init.cur_iter[k];
+        collided = a.S->init.collided[k] != 0;
     }
 
     if (free_window) DIAG1_STAMP(6);
@@ -578,6 +603,7 @@ __device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, Pending& 
     q.target = a.S->st.target_idx[i];
     q.iter = a.S->st.cur_iter[i];
     q.collided = a.S->st.collided[i] != 0;
+    q.geom = a.S->geom_of_env ? a.S->geom_of_env[i] : 0;
     if (a.flags & BCP_STEP_ACTIONS_F32) {
         const float2 c = reinterpret_cast<const float2*>(a.actions)[i];
         cmd0 = (double)c.x;
@@ -621,8 +647,8 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     q.err = robot_step(P, q.r, cmd0, cmd1, q.z, q.drawn);
     bool hit = false;
     if (!(a.flags & (1u << 16)))
-        hit = collides_wave(P, a.S->map, a.S->cull, L, a.S->exact_mode, a.S->dense_threshold, a.S->wide != 0, active, i, q.r.p.x,
-                            q.r.p.y, q.r.p.th);
+        hit = collides_wave(P, a.S->map, a.S->cull, L, a.S->exact_mode, a.S->dense_threshold, a.S->wide != 0, active,
+                            slot_of(a.S, i, q), q.r.p.x, q.r.p.y, q.r.p.th);
     if (!active) return;
     finalize_env(a, i, q, hit);
 }
@@ -680,20 +706,21 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
 
     // (3) everything that depends only on the new pose is looked up together: distance-field samples and the
     //     way-point window of the reward
+    const int64_t g = slot_of(a.S, i, q);
     double ox = a.S->map.ox, oy = a.S->map.oy;
     if (a.S->map.origins) {
-        ox = a.S->map.origins[2 * i + 0];
-        oy = a.S->map.origins[2 * i + 1];
+        ox = a.S->map.origins[2 * g + 0];
+        oy = a.S->map.origins[2 * g + 1];
     }
     const int px = (int)rint((r.p.x - ox) * a.S->map.inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
     const int py = (int)rint((r.p.y - oy) * a.S->map.inv_res);
     const double c = cos(r.p.th), s = sin(r.p.th);
-    const int64_t map_env = a.S->map.shared ? 0 : i;
+    const int64_t map_env = a.S->map.shared ? 0 : g;
     OuterLookups look;
     look.off_map = true;
     if (!(a.flags & ((1u << 16) | (1u << 22)))) look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
-    const PathWindow win = path_window(P, a.S->path.bbox + (a.S->path.shared ? 0 : i * 8),
-                                       a.S->path.index + (a.S->path.shared ? 0 : i * (int64_t)(4 * kPathBuckets)), r.p.x, r.p.y);
+    const PathWindow win = path_window(P, a.S->path.bbox + (a.S->path.shared ? 0 : g * 8),
+                                       a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets)), r.p.x, r.p.y);
     const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
     DIAG1_STAMP(3);
 
@@ -708,7 +735,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
         while (todo) {
             const int src = __ffsll((unsigned long long)todo) - 1;
             todo &= todo - 1;
-            const int64_t env_ = ((int64_t)bcast_i((int)(i >> 32), src) << 32) | (uint32_t)bcast_i((int)i, src);
+            const int64_t env_ = ((int64_t)bcast_i((int)(g >> 32), src) << 32) | (uint32_t)bcast_i((int)g, src);
             const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : env_ * a.S->map.env_stride);
             const bool h = coop_collides<WIDE>(P, vqx, vqy, bcast_d(c, src), bcast_d(s, src), bcast_i(px, src),
                                                bcast_i(py, src), words, a.S->map.rows, a.S->map.cols, a.S->map.wpr);
@@ -755,10 +782,11 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
         const double c = e->c, s = e->s;
         const int px = e->px, py = e->py;
         const int64_t i = ((int64_t)e->env_hi << 32) | (uint32_t)e->env_lo;
+        const int64_t g = a.S->geom_of_env ? (int64_t)e->geom : i;
         if (idx >= count) break;
         DIAG_STAMP(1);
-        const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : i * a.S->map.env_stride);
-        bool hit = (a.flags & (1u << 20)) ? false : classify_inner_hit(a.S->cull, a.S->map.shared ? 0 : i, px, py, c, s);
+        const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : g * a.S->map.env_stride);
+        bool hit = (a.flags & (1u << 20)) ? false : classify_inner_hit(a.S->cull, a.S->map.shared ? 0 : g, px, py, c, s);
         DIAG_STAMP(2);
         if (!hit && !(a.flags & (1u << 19)))  // (the inner verdict is uniform over the workgroup: no barrier mismatch)
             hit = coop_collides_quad<WIDE>(P, vqx, vqy, c, s, px, py, words, a.S->map.rows, a.S->map.cols, a.S->map.wpr, wave,
@@ -774,24 +802,31 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
     }
 }
 
-__global__ void reset_kernel(DevState st, DevState init, const uint8_t* __restrict__ mask, int64_t n, int tri)
+__global__ void reset_kernel(DevState st, DevState init, const uint8_t* __restrict__ mask, int64_t n, int tri,
+                             int32_t* __restrict__ geom_of_env, const int32_t* __restrict__ next_geom)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (mask && !mask[i]) return;
-    st.x[i] = init.x[i];
-    st.y[i] = init.y[i];
-    st.angle[i] = init.angle[i];
-    st.v[i] = init.v[i];
-    st.w[i] = init.w[i];
-    if (tri) {
-        st.steer[i] = init.steer[i];
-        st.wheel[i] = init.wheel[i];
+    int64_t k = i;
+    if (geom_of_env) {  // geometry pool: a reset draws the env's next geometry (mini_env.py:469-481)
+        k = geom_of_env[i];
+        if (next_geom) k = next_geom[k];
+        geom_of_env[i] = (int32_t)k;
     }
-    st.min_dist[i] = init.min_dist[i];
-    st.target_idx[i] = init.target_idx[i];
-    st.cur_iter[i] = init.cur_iter[i];
-    st.collided[i] = init.collided[i];
+    st.x[i] = init.x[k];
+    st.y[i] = init.y[k];
+    st.angle[i] = init.angle[k];
+    st.v[i] = init.v[k];
+    st.w[i] = init.w[k];
+    if (tri) {
+        st.steer[i] = init.steer[k];
+        st.wheel[i] = init.wheel[k];
+    }
+    st.min_dist[i] = init.min_dist[k];
+    st.target_idx[i] = init.target_idx[k];
+    st.cur_iter[i] = init.cur_iter[k];
+    st.collided[i] = init.collided[k];
 }
 
 __global__ void __launch_bounds__(kBlock) robot_step_kernel(DevParams P, double* __restrict__ st7, int64_t n,
@@ -829,6 +864,7 @@ __global__ void __launch_bounds__(kBlock) robot_step_kernel(DevParams P, double*
 __global__ void __launch_bounds__(kBlock) pose_collides_kernel(DevParams P, MapDesc map, CullDesc cull, int exact_mode,
                                                                int dense_threshold, int wide,
                                                                const double* __restrict__ poses, int64_t n, int64_t n_envs,
+                                                               const int32_t* __restrict__ geom_of_env,
                                                                uint8_t* __restrict__ out)
 {
     const int tid = threadIdx.x;
@@ -836,7 +872,7 @@ __global__ void __launch_bounds__(kBlock) pose_collides_kernel(DevParams P, MapD
     const bool active = gi < n;
     const int64_t i = active ? gi : n - 1;
     const CollisionLds L = collision_lds_setup(P, map, tid);
-    const int64_t env = i % n_envs;
+    const int64_t env = geom_of_env ? (int64_t)geom_of_env[i % n_envs] : i % n_envs;
     const bool hit = collides_wave(P, map, cull, L, exact_mode, dense_threshold, wide != 0, active, env, poses[3 * i],
                                    poses[3 * i + 1], poses[3 * i + 2]);
     if (active) out[i] = (uint8_t)hit;
@@ -1178,6 +1214,22 @@ extern "C" int bcp_seed(bcp_handle* h, uint64_t seed)
     return BCP_OK;
 }
 
+extern "C" int bcp_set_geometry_pool(bcp_handle* h, int32_t n_geoms, int32_t* geom_of_env, const int32_t* next_geom)
+{
+    if (!h) return fail(BCP_E_INVALID, "bcp_set_geometry_pool: null handle");
+    if (n_geoms < 0 || (n_geoms > 0 && !geom_of_env))
+        return fail(BCP_E_INVALID, "bcp_set_geometry_pool: n_geoms > 0 needs geom_of_env");
+    if ((n_geoms > 0) != (h->n_geoms > 0) || (n_geoms > 0 && n_geoms != h->n_geoms)) {
+        // the non-shared arrays change their entry count: they have to be given again
+        h->have_map = h->have_path = h->have_init = false;
+    }
+    h->n_geoms = n_geoms;
+    h->geom_of_env = n_geoms > 0 ? geom_of_env : nullptr;
+    h->next_geom = n_geoms > 0 ? next_geom : nullptr;
+    h->static_dirty = true;
+    return BCP_OK;
+}
+
 extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
 {
     if (!h) return fail(BCP_E_INVALID, "bcp_set_tuning: null handle");
@@ -1213,7 +1265,7 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int wpr = (cols + 31) / 32;
-    const int64_t n_maps = shared ? 1 : h->n;
+    const int64_t n_maps = shared ? 1 : n_slots(h);
     const size_t bytes = (size_t)n_maps * rows * wpr * sizeof(uint32_t);
     if (bytes > h->bitmap_bytes) {
         if (h->bitmap) HIP_TRY(hipFree(h->bitmap));
@@ -1307,7 +1359,7 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
     if (!shared && !lens) return fail(BCP_E_INVALID, "bcp_set_paths: per-env paths need lens");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    const int64_t total = (shared ? 1 : h->n) * (int64_t)max_len;
+    const int64_t total = (shared ? 1 : n_slots(h)) * (int64_t)max_len;
     const size_t bytes = (size_t)total * 5 * sizeof(double);
     if (bytes > h->path5_bytes) {
         if (h->path5) HIP_TRY(hipFree(h->path5));
@@ -1320,7 +1372,7 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
     const int blocks = (int)std::min<int64_t>((total + threads - 1) / threads, 65536);
     hipLaunchKernelGGL(path_trig_kernel, dim3(blocks), dim3(threads), 0, s, xytheta, h->path5, total);
     HIP_TRY(hipGetLastError());
-    const int64_t n_paths = shared ? 1 : h->n;
+    const int64_t n_paths = shared ? 1 : n_slots(h);
     const size_t bb_bytes = (size_t)n_paths * 8 * sizeof(double);
     if (bb_bytes > h->path_bbox_bytes) {
         if (h->path_bbox) HIP_TRY(hipFree(h->path_bbox));
@@ -1385,7 +1437,7 @@ extern "C" int bcp_reset_masked(bcp_handle* h, const uint8_t* mask, void* stream
     const int threads = 256;
     const int blocks = (int)((h->n + threads - 1) / threads);
     hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, h->st, h->init, mask, h->n,
-                       (int)(h->params.model == BCP_MODEL_TRICYCLE));
+                       (int)(h->params.model == BCP_MODEL_TRICYCLE), h->geom_of_env, h->next_geom);
     HIP_TRY(hipGetLastError());
     return BCP_OK;
 }
@@ -1414,6 +1466,8 @@ static int upload_step_static(bcp_handle* h, hipStream_t s)
     S.pending_cap = h->pending_cap;
     const bool defer = step_uses_deferral(h);
     S.pending = defer ? (Pending*)h->pending : nullptr;
+    S.geom_of_env = h->n_geoms > 0 ? h->geom_of_env : nullptr;
+    S.next_geom = h->n_geoms > 0 ? h->next_geom : nullptr;
     S.lds_path_doubles =
         (defer && h->path.shared && h->path.max_len * 5 * sizeof(double) <= 24 * 1024) ? h->path.max_len * 5 : 0;
     if (getenv("BCP_DEBUG_NO_LDS_PATH")) S.lds_path_doubles = 0;  // timing experiments
@@ -1572,7 +1626,7 @@ extern "C" int bcp_pose_collides(bcp_handle* h, const double* poses, int64_t n, 
     hipLaunchKernelGGL(pose_collides_kernel, dim3(blocks), dim3(kBlock),
                        collision_lds_bytes(h->params.n_verts, h->map.in_lds, h->map.rows, h->map.wpr),
                        (hipStream_t)stream, h->dev, h->map, h->cull, h->exact_mode, h->dense_threshold, h->wide, poses, n,
-                       h->n, out);
+                       h->n, h->geom_of_env, out);
     HIP_TRY(hipGetLastError());
     return BCP_OK;
 }

@@ -1,0 +1,385 @@
+"""RandomMiniEnv geometry: the reset-time side of the batched env.
+
+The reference's RandomMiniEnv (envs/mini_env.py:408-494) draws a fresh one-corner world on every reset(): rejection
+sampling of an obstacle wedge plus a start and an end pose (:269-361), two 1-px walls rendered with cv2.line
+(envs/base/maps.py:28-44, utilities/map_drawing_utils.py:140-156), and a collision test of the two path ends with the
+tricycle footprint (:324-343).  At 65 536 envs about a hundred episodes end per step, so a reset cannot be a host
+round trip: geometries are sampled ahead of time into a POOL (this module, host numpy + one batched GPU
+pose_collides per round), uploaded once, and the step / reset kernels move an env along its chain of pool entries
+(bcp_set_geometry_pool, include/bcplan.h).
+
+The sampler consumes its numpy RandomState exactly like the reference, draw for draw, so chain c of a pool is the
+sequence of worlds `RandomMiniEnv(seed=seeds[c])` goes through on successive resets.
+"""
+import ctypes as C
+
+import attr
+import numpy as np
+import torch
+
+from . import _lib, robots
+from .api import CostMap2D, EnvParams
+
+_TWO_PI = 2 * np.pi
+_MAX_TRIES = 1000
+
+
+@attr.s
+class RandomMiniEnvParams(object):
+    """Space the mini worlds are drawn from (same fields and defaults as envs/mini_env.py:30-47)."""
+    inner_h = attr.ib(default=3, type=float)
+    inner_w = attr.ib(default=3, type=float)
+    mid_margin = attr.ib(default=0.25, type=float)
+    out_margin = attr.ib(default=1, type=float)
+    min_obstacle_angle = attr.ib(default=np.pi / 8., type=float)
+    max_obstacle_angle = attr.ib(default=np.pi, type=float)
+    lim_euc_dist = attr.ib(default=1000, type=float)
+    lim_ang_dist = attr.ib(default=np.pi, type=float)
+    angular_pose_noise_scale = attr.ib(default=np.pi / 2.0, type=float)
+    env_params = attr.ib(factory=EnvParams)
+
+
+def default_random_mini_env_params():
+    """What RandomMiniEnv() uses when no params are given (envs/mini_env.py:424-430)."""
+    return RandomMiniEnvParams(env_params=EnvParams(goal_ang_dist=np.pi / 8., goal_spat_dist=0.2))
+
+
+@attr.s
+class MiniEnvParams(object):
+    """One sampled world (envs/mini_env.py:79-92); poses are (x, y, theta) arrays, points (x, y) arrays."""
+    h = attr.ib()
+    w = attr.ib()
+    start_pos = attr.ib()
+    end_pos = attr.ib()
+    obstacle_a = attr.ib()
+    obstacle_o = attr.ib()
+    obstacle_b = attr.ib()
+    env_params = attr.ib(factory=EnvParams)
+
+
+class SpaceSeemsEmptyError(Exception):
+    """No admissible start/end pair on the circle after 1000 draws (the caller redraws the obstacle)."""
+
+
+def _wrap(z):
+    # normalize_angle, utilities/coordinate_transformations.py:28-36
+    return (np.array(z) + np.pi) % _TWO_PI - np.pi
+
+
+def _pose(x, y, theta):
+    # OrientedPoint normalises its heading on construction (envs/mini_env.py:50-55)
+    return np.array([x, y, _wrap(theta)], dtype=float)
+
+
+class _Wedge(object):
+    """The angular sector behind the corner obstacle, seen from its apex (not_inside_obstacle, mini_env.py:199-208)."""
+
+    def __init__(self, apex, first, width):
+        self.apex, self.first, self.last = apex, first, first + width
+
+    def clear_of(self, x, y):
+        phi = _wrap(np.arctan2(y - self.apex[1], x - self.apex[0]))  # cart2pol, coordinate_transformations.py:124-135
+        for turn in (0.0, _TWO_PI):
+            if self.first <= phi + turn <= self.last:
+                return False
+        return True
+
+
+def _ends_on_circle(rng, p, wedge):
+    # _sample_pose_circ (mini_env.py:146-180): two antipodal points of a circle, both heading start -> end
+    for _ in range(_MAX_TRIES):
+        radius = min((p.inner_w + p.inner_h) / 4. + p.mid_margin, p.lim_euc_dist)
+        phi = rng.uniform(0, _TWO_PI)
+        x, y = radius * np.cos(phi), radius * np.sin(phi)
+        rng.uniform(0, _TWO_PI)  # the reference draws a heading here and then overwrites it
+        heading = np.arctan2(-y - y, -x - x)
+        if wedge.clear_of(x, y) and wedge.clear_of(-x, -y):
+            return _pose(x, y, heading), _pose(-x, -y, heading)
+    raise SpaceSeemsEmptyError()
+
+
+def _pose_in_square(rng, p, accept):
+    # _sample_pose (mini_env.py:120-143)
+    half_w, half_h = p.inner_w / 2 + p.mid_margin, p.inner_h / 2 + p.mid_margin
+    for _ in range(_MAX_TRIES):
+        x = rng.uniform(-half_w, half_w)
+        y = rng.uniform(-half_h, half_h)
+        cand = _pose(x, y, rng.uniform(0, _TWO_PI))
+        if accept(cand):
+            return cand
+    raise ValueError("Something went wrong, the sampling space looks empty.")
+
+
+def _ends_in_square(rng, p, wedge):
+    # _pick_pts_square_method (mini_env.py:183-236)
+    start = _pose_in_square(rng, p, lambda q: wedge.clear_of(q[0], q[1]))
+
+    def admissible(q):
+        if not wedge.clear_of(q[0], q[1]):
+            return False
+        if not np.mod(start[2] - q[2], _TWO_PI) < p.lim_ang_dist:       # angle_diff, coordinate_transformations.py:115
+            return False
+        return np.linalg.norm(np.array([start[0] - q[0], start[1] - q[1]])) < p.lim_euc_dist
+
+    end = _pose_in_square(rng, p, admissible)
+    heading = np.arctan2(end[1] - start[1], end[0] - start[0])
+    return _pose(start[0], start[1], heading), _pose(end[0], end[1], heading)
+
+
+def draw_candidate(params, rng):
+    """One unchecked world (_sample_mini_env_params_no_final_check, mini_env.py:269-325)."""
+    p = params
+    apex = np.array([rng.uniform(-p.inner_w / 2, p.inner_w / 2), rng.uniform(-p.inner_h / 2, p.inner_h / 2)], dtype=float)
+    first = rng.uniform(0, _TWO_PI)
+    width = rng.uniform(p.min_obstacle_angle, p.max_obstacle_angle)
+    reach = 3 * (p.inner_h + p.inner_w + p.mid_margin + p.out_margin)   # far outside the map: walls run off its edge
+
+    def ray_end(phi):
+        return np.array([reach * np.cos(phi) + apex[0], reach * np.sin(phi) + apex[1]], dtype=float)
+
+    side_h = p.inner_h + 2 * p.mid_margin + 2 * p.out_margin
+    side_w = p.inner_w + 2 * p.mid_margin + 2 * p.out_margin
+    wedge = _Wedge(apex, first, width)
+    start, end = (_ends_on_circle if rng.rand() < 0.7 else _ends_in_square)(rng, p, wedge)
+    half = p.angular_pose_noise_scale / 2.0
+    start = _pose(start[0], start[1], start[2] + rng.uniform(-half, half))
+    end = _pose(end[0], end[1], end[2] + rng.uniform(-half, half))
+    return MiniEnvParams(side_h, side_w, start, end, ray_end(first), apex, ray_end(first + width), p.env_params)
+
+
+# ---- map construction ---------------------------------------------------------------------------------------
+def _to_pixel(xy, origin, resolution):
+    # world_to_pixel, coordinate_transformations.py:185-205 (multiplies by the reciprocal, rounds half to even)
+    return np.round((np.asarray(xy, dtype=np.float64) - origin) * (1.0 / resolution)).astype(int)
+
+
+def _clip_segment(cols, rows, x1, y1, x2, y2):
+    """cv::clipLine for integer end points: the part of the segment inside [0, cols) x [0, rows), or None."""
+    right, bottom = cols - 1, rows - 1
+
+    def code(x, y):
+        return (x < 0) + (x > right) * 2 + (y < 0) * 4 + (y > bottom) * 8
+
+    c1, c2 = code(x1, y1), code(x2, y2)
+    if (c1 & c2) == 0 and (c1 | c2) != 0:
+        if c1 & 12:
+            a = 0 if c1 < 8 else bottom
+            x1 += int(float(a - y1) * float(x2 - x1) / float(y2 - y1))
+            y1 = a
+            c1 = (x1 < 0) + (x1 > right) * 2
+        if c2 & 12:
+            a = 0 if c2 < 8 else bottom
+            x2 += int(float(a - y2) * float(x2 - x1) / float(y2 - y1))
+            y2 = a
+            c2 = (x2 < 0) + (x2 > right) * 2
+        if (c1 & c2) == 0 and (c1 | c2) != 0:
+            if c1:
+                a = 0 if c1 == 1 else right
+                y1 += int(float(a - x1) * float(y2 - y1) / float(x2 - x1))
+                x1 = a
+                c1 = 0
+            if c2:
+                a = 0 if c2 == 1 else right
+                y2 += int(float(a - x2) * float(y2 - y1) / float(x2 - x1))
+                x2 = a
+                c2 = 0
+    return (x1, y1, x2, y2) if (c1 | c2) == 0 else None
+
+
+def draw_line(data, p0, p1, value):
+    """cv2.line(data, p0, p1, value, thickness=1): the segment is clipped to the image, then traced left to right by
+    the 8-connected Bresenham iterator; the minor coordinate after i major steps is floor((2*d*i + D - 1) / (2*D))."""
+    rows, cols = data.shape
+    seg = _clip_segment(cols, rows, int(p0[0]), int(p0[1]), int(p1[0]), int(p1[1]))
+    if seg is None:
+        return
+    x1, y1, x2, y2 = seg
+    if x2 < x1:
+        x1, y1, x2, y2 = x2, y2, x1, y1
+    dx, dy = x2 - x1, abs(y2 - y1)
+    sy = 1 if y2 >= y1 else -1
+    major, minor = (dy, dx) if dy > dx else (dx, dy)
+    i = np.arange(major + 1, dtype=np.int64)
+    k = (2 * minor * i + major - 1) // (2 * major) if major else np.zeros(1, dtype=np.int64)
+    if dy > dx:
+        data[y1 + sy * i, x1 + k] = value
+    else:
+        data[y1 + sy * k, x1 + i] = value
+
+
+def add_wall(costmap, p0, p1, width=0.05, cost=CostMap2D.LETHAL_OBSTACLE):
+    """Wall.render -> _mark_wall_on_static_map (map_drawing_utils.py:140-156)."""
+    thickness = max(1, int(width / costmap.get_resolution()))
+    if thickness != 1:
+        raise NotImplementedError("walls thicker than one pixel (resolution < %g m) are not supported" % (width / 2))
+    org, res = costmap.get_origin(), costmap.get_resolution()
+    draw_line(costmap.get_data(), _to_pixel(p0, org, res), _to_pixel(p1, org, res), cost)
+
+
+def prepare_map_and_path(mp):
+    """-> (CostMap2D with the two walls, coarse path [2, 3]) for one sampled world (mini_env.py:362-388)."""
+    res = mp.env_params.resolution
+    size = _to_pixel(np.array([mp.h, mp.w], dtype=np.float64), np.zeros(2), res)      # CostMap2D.create_empty
+    costmap = CostMap2D(np.zeros(tuple(size[::-1]), dtype=np.uint8), res, np.array([-mp.h / 2., -mp.w / 2.]))
+    add_wall(costmap, mp.obstacle_o, mp.obstacle_a)
+    add_wall(costmap, mp.obstacle_o, mp.obstacle_b)
+    return costmap, np.array([mp.start_pos, mp.end_pos])
+
+
+# ---- batched acceptance test on the GPU -----------------------------------------------------------------------
+class PoseCollider(object):
+    """pose_collides of the two path ends for up to `capacity` candidate worlds per call (one launch)."""
+
+    def __init__(self, env_params, capacity, device=0):
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("sampling mini-env geometries needs a GPU (libbcplan has no CPU path)")
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.capacity = int(capacity)
+        # the reference tests with a TricycleRobot carrying the configured robot's footprint (mini_env.py:336-337)
+        self._p = robots.make_bcp_params(env_params, env_params.robot_name, None)
+        self._h = C.c_void_p()
+        _lib.check(self._lib.bcp_create(C.byref(self._p), self.capacity, self.device.index or 0, 0, C.byref(self._h)))
+        self.resolution = float(env_params.resolution)
+
+    def __call__(self, costmaps, paths):
+        """costmaps: list of K <= capacity CostMap2D of one shape; paths: list of K [2,3] -> bool [K, 2]."""
+        k, cap = len(costmaps), self.capacity
+        rows, cols = costmaps[0].get_data().shape
+        data = np.zeros((cap, rows, cols), dtype=np.uint8)
+        origins = np.zeros((cap, 2), dtype=np.float64)
+        poses = np.zeros((2, cap, 3), dtype=np.float64)
+        for j in range(k):
+            data[j] = costmaps[j].get_data()
+            origins[j] = costmaps[j].get_origin()
+            poses[:, j] = paths[j]
+        dev = self.device
+        d, o, p = torch.from_numpy(data).to(dev), torch.from_numpy(origins).to(dev), torch.from_numpy(poses).to(dev)
+        out = torch.empty(2 * cap, dtype=torch.uint8, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(self._lib.bcp_set_costmaps(self._h, d.data_ptr(), rows, cols, 0, None, None, o.data_ptr(), 1,
+                                              self.resolution, stream))
+        _lib.check(self._lib.bcp_pose_collides(self._h, p.data_ptr(), 2 * cap, out.data_ptr(), stream))
+        hit = out.cpu().numpy().reshape(2, cap)[:, :k].T.astype(bool)   # (synchronises: d, o, p may go)
+        return hit
+
+    def close(self):
+        if self._h:
+            self._lib.bcp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Chain(object):
+    """The worlds one RandomMiniEnv goes through: a private RandomState and the 1000-try budget of the current draw."""
+
+    def __init__(self, seed):
+        self.rng = np.random.RandomState(seed=0)   # RandomMiniEnv.__init__: RandomState(0), then seed(seed)
+        if seed is not None:
+            self.rng.seed(seed)
+        self.tries = 0
+        self.accepted = []
+
+    def propose(self, params):
+        while self.tries < _MAX_TRIES:
+            self.tries += 1
+            try:
+                return draw_candidate(params, self.rng)
+            except SpaceSeemsEmptyError:
+                continue
+        raise ValueError("Something went wrong, the sampling space looks empty.")
+
+
+def _too_close(path, env_params):
+    # pose_distances of the two path ends against the goal tolerances (mini_env.py:347-351)
+    cart = np.hypot(path[0][0] - path[1][0], path[0][1] - path[1][1])
+    ang = np.abs(_wrap(path[0][2] - path[1][2]))
+    return bool(cart < env_params.goal_spat_dist and ang < env_params.goal_ang_dist)
+
+
+class MiniEnvPool(object):
+    """n_chains x episodes pre-sampled worlds.  Entry c * episodes + k is the k-th world of chain c; `next_geom`
+    walks a chain and wraps around at its end."""
+
+    def __init__(self, params, seeds, episodes, worlds):
+        self.params, self.seeds, self.episodes = params, list(seeds), int(episodes)
+        self.worlds = worlds                                        # list of MiniEnvParams, chain-major
+        built = [prepare_map_and_path(w) for w in worlds]
+        self.costmaps = [b[0] for b in built]
+        self.paths = [b[1] for b in built]
+        g = np.arange(len(worlds), dtype=np.int32)
+        self.next_geom = (g // self.episodes) * self.episodes + (g % self.episodes + 1) % self.episodes
+        self.next_geom = self.next_geom.astype(np.int32)
+
+    def __len__(self):
+        return len(self.worlds)
+
+    def first_of_chain(self, c):
+        return c * self.episodes
+
+
+def sample_pool(params=None, seeds=(0,), episodes=1, device=0, collider=None):
+    """Pre-sample `episodes` successive worlds for every seed (_sample_mini_env_params, mini_env.py:328-359, run for
+    all chains at once: each round every unfinished chain proposes its next candidate and one batched GPU call tests
+    the candidates' path ends)."""
+    params = default_random_mini_env_params() if params is None else params
+    chains = [_Chain(s) for s in seeds]
+    own = collider is None
+    if own:
+        collider = PoseCollider(params.env_params, min(len(chains), 4096), device)
+    try:
+        todo = [c for c in chains if len(c.accepted) < episodes]
+        while todo:
+            batch = todo[:collider.capacity]
+            cands = [c.propose(params) for c in batch]
+            built = [prepare_map_and_path(m) for m in cands]
+            hits = collider([b[0] for b in built], [b[1] for b in built])
+            for c, m, (_, path), hit in zip(batch, cands, built, hits):
+                if not hit.any() and not _too_close(path, params.env_params):
+                    c.accepted.append(m)
+                    c.tries = 0
+            todo = [c for c in chains if len(c.accepted) < episodes]
+    finally:
+        if own:
+            collider.close()
+    return MiniEnvPool(params, seeds, episodes, [m for c in chains for m in c.accepted])
+
+
+def _batched_plan_env():
+    from .batched_env import BatchedPlanEnv   # (imported late: batched_env does not need this module)
+    return BatchedPlanEnv
+
+
+class BatchedRandomMiniEnv(object):
+    """N RandomMiniEnv instances (envs/mini_env.py:408-494) on one GPU: a BatchedPlanEnv in geometry-pool mode.
+
+    Env i follows chain i % n_chains of the pool, starting (i // n_chains) % episodes entries into it, so replicas of a
+    chain are out of phase.  With one chain per env and seeds[i] = s_i, env i sees exactly the worlds
+    `RandomMiniEnv(seed=s_i)` sees for its first `episodes` resets (then the chain wraps around).  As in the
+    reference, construction leaves the env on world 0 of its chain and the first reset() moves it to world 1 --
+    BatchedPlanEnv's constructor already ends with that reset().
+
+    :param pool MiniEnvPool: pre-sampled worlds, or None to sample `n_chains` x `episodes` here
+    :param draw_new_turn_on_reset bool: False keeps every env on its first world (RandomMiniEnv's flag of that name)
+    Remaining keyword arguments go to BatchedPlanEnv (auto_reset, seed, noise_parameters, env_id_base, ...).
+    """
+
+    def __new__(cls, n_envs, params=None, pool=None, seeds=None, n_chains=None, episodes=4, device=0,
+                draw_new_turn_on_reset=True, **kw):
+        params = default_random_mini_env_params() if params is None else params
+        if pool is None:
+            if seeds is None:
+                seeds = range(int(n_chains) if n_chains else min(int(n_envs), 1024))
+            pool = sample_pool(params, list(seeds), episodes, device)
+        chains, per = len(pool.seeds), pool.episodes
+        i = np.arange(int(n_envs))
+        geom = (i % chains) * per + (i // chains) % per
+        env = _batched_plan_env()(pool.costmaps, pool.paths, params.env_params, n_envs=n_envs, device=device,
+                                  geom_of_env=geom, next_geom=pool.next_geom if draw_new_turn_on_reset else None, **kw)
+        env.pool = pool
+        return env

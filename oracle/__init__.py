@@ -66,6 +66,7 @@ class Batch(C.Structure):
         ("reward", _f64p), ("done", _u8p), ("collided_now", _u8p), ("err", _i32p),
         ("auto_reset", C.c_int32),
         ("init_st", _f64p * 7), ("init_min_dist", _f64p), ("init_target_idx", _i32p),
+        ("geom", _i32p), ("next_geom", _i32p),
     ]
 
 
@@ -289,9 +290,14 @@ def initial_reward_state(path, sp, ap):
 class OracleBatch(object):
     """N envs stepped by the oracle; same SoA inputs/outputs as the HIP path, numpy arrays on the host."""
 
-    def __init__(self, params, n, costmaps, origins, resolution, paths, lens=None, rows=None, cols=None):
+    def __init__(self, params, n, costmaps, origins, resolution, paths, lens=None, rows=None, cols=None, geom=None,
+                 next_geom=None):
+        """geom (int [n]) switches to geometry-pool mode: costmaps / origins / paths / lens / rows / cols then hold one
+        entry per pool geometry and env i uses entry geom[i]; resets follow next_geom."""
         self.params = params
         self.n = int(n)
+        self.geom = None if geom is None else np.ascontiguousarray(geom, dtype=np.int32).copy()
+        self.next_geom = None if next_geom is None else np.ascontiguousarray(next_geom, dtype=np.int32)
         self.resolution = float(resolution)
         cm = np.ascontiguousarray(costmaps, dtype=np.uint8)
         self.shared_map = cm.ndim == 2
@@ -307,7 +313,8 @@ class OracleBatch(object):
         if self.shared_path:
             self.lens = np.array([pa.shape[0]], dtype=np.int32)
         else:
-            self.lens = np.ascontiguousarray(lens if lens is not None else np.full(n, pa.shape[1]), dtype=np.int32)
+            self.lens = np.ascontiguousarray(lens if lens is not None else np.full(pa.shape[0], pa.shape[1]),
+                                             dtype=np.int32)
         self.st = [np.zeros(n) for _ in range(7)]
         self.min_dist = np.zeros(n)
         self.target_idx = np.zeros(n, dtype=np.int32)
@@ -323,6 +330,18 @@ class OracleBatch(object):
     def reset_from_paths(self, initial_wheel_angle=0.0):
         """make_initial_state (envs/base/env.py:179-214): pose = path[0], v=w=0, reward state from the path."""
         sp, ap = self.params.spatial_precision, self.params.angular_precision
+        if self.geom is not None:
+            # pool mode: one initial state per pool entry; every env starts on its entry's initial state
+            g_n = self.paths.shape[0]
+            per = [initial_reward_state(self.paths[g, :self.lens[g]], sp, ap) for g in range(g_n)]
+            self.init_st = [np.zeros(g_n) for _ in range(7)]
+            for g in range(g_n):
+                self.init_st[0][g], self.init_st[1][g], self.init_st[2][g] = self.paths[g, 0]
+            self.init_st[6][:] = initial_wheel_angle
+            self.init_min_dist = np.array([m for m, _ in per], dtype=np.float64)
+            self.init_target_idx = np.array([t for _, t in per], dtype=np.int32)
+            self.reset_all_to_geom()
+            return
         for i in range(self.n):
             path = self.paths if self.shared_path else self.paths[i, :self.lens[i]]
             if i == 0 or not self.shared_path:
@@ -336,6 +355,18 @@ class OracleBatch(object):
         self.cur_time[:] = 0.0
         self.collided[:] = 0
         self.snapshot_initial()
+
+    def reset_all_to_geom(self, advance=False):
+        """pool mode: (optionally move every env to its next entry, then) load the entry's initial state"""
+        if advance and self.next_geom is not None:
+            self.geom[:] = self.next_geom[self.geom]
+        for f in range(7):
+            self.st[f][:] = self.init_st[f][self.geom]
+        self.min_dist[:] = self.init_min_dist[self.geom]
+        self.target_idx[:] = self.init_target_idx[self.geom]
+        self.cur_iter[:] = 0
+        self.cur_time[:] = 0.0
+        self.collided[:] = 0
 
     def snapshot_initial(self):
         self.init_st = [a.copy() for a in self.st]
@@ -376,6 +407,9 @@ class OracleBatch(object):
         b.collided_now = _p(self.collided_now, _u8p)
         b.err = _p(self.err, _i32p)
         b.auto_reset = int(auto_reset)
+        if self.geom is not None:
+            b.geom = _p(self.geom, _i32p)
+            b.next_geom = _p(self.next_geom, _i32p) if self.next_geom is not None else None
         if auto_reset:
             assert self.init_st is not None
             for f in range(7):

@@ -572,12 +572,13 @@ static void *batch_worker(void *arg)
     for (int64_t i = job->lo; i < job->hi; ++i) {
         double st[7];
         for (int f = 0; f < 7; ++f) st[f] = b->st[f][i];
-        const uint8_t *map = b->maps + (size_t)i * (size_t)b->map_stride;
-        int rows = b->rows_per_env ? b->rows_per_env[i] : b->rows;
-        int cols = b->cols_per_env ? b->cols_per_env[i] : b->cols;
-        const double *origin = b->origins + (size_t)i * (size_t)b->origin_stride;
-        const double *path = b->paths + (size_t)i * (size_t)b->path_stride;
-        int m = b->path_stride ? b->lens[i] : b->lens[0];
+        int64_t g = b->geom ? b->geom[i] : i; /* entry of the per-env arrays this env uses */
+        const uint8_t *map = b->maps + (size_t)g * (size_t)b->map_stride;
+        int rows = b->rows_per_env ? b->rows_per_env[g] : b->rows;
+        int cols = b->cols_per_env ? b->cols_per_env[g] : b->cols;
+        const double *origin = b->origins + (size_t)g * (size_t)b->origin_stride;
+        const double *path = b->paths + (size_t)g * (size_t)b->path_stride;
+        int m = b->path_stride ? b->lens[g] : b->lens[0];
         double cmd[2] = {b->actions[2 * i], b->actions[2 * i + 1]};
         const double *z = b->z ? b->z + 3 * i : NULL;
         double cur_time = b->cur_time ? b->cur_time[i] : 0.0;
@@ -588,9 +589,13 @@ static void *batch_worker(void *arg)
         if (b->collided_now) b->collided_now[i] = cn;
         if (b->err) b->err[i] = err;
         if (b->auto_reset && b->done[i]) {
-            for (int f = 0; f < 7; ++f) st[f] = b->init_st[f][i];
-            b->min_dist[i] = b->init_min_dist[i];
-            b->target_idx[i] = b->init_target_idx[i];
+            if (b->geom) {
+                if (b->next_geom) g = b->next_geom[g];
+                b->geom[i] = (int32_t)g;
+            }
+            for (int f = 0; f < 7; ++f) st[f] = b->init_st[f][g];
+            b->min_dist[i] = b->init_min_dist[g];
+            b->target_idx[i] = b->init_target_idx[g];
             b->cur_iter[i] = 0;
             b->collided[i] = 0;
             cur_time = 0.0;

@@ -123,7 +123,10 @@ int bco_env_step(const bco_params *p, double st[7], double *min_dist, int32_t *t
 /* Batched SoA step over n envs with `threads` host threads.
  * state: 7 arrays of n doubles, state[f][i].  maps: shared (map_stride==0) or per-env at i*map_stride bytes.
  * paths: shared (path_stride==0, lens[0]) or per-env at i*path_stride doubles with lens[i].
- * actions: n*2 (float64).  z: n*3 or NULL.  auto_reset: when done, state <- init_* after outputs are written. */
+ * actions: n*2 (float64).  z: n*3 or NULL.  auto_reset: when done, state <- init_* after outputs are written.
+ * geom (optional, int32[n]): geometry-pool mode -- env i uses entry geom[i] of the per-env map / origin / path /
+ * init arrays instead of entry i; on auto-reset geom[i] <- next_geom[geom[i]] (when given) first, which is
+ * RandomMiniEnv.reset() drawing its next world (envs/mini_env.py:469-481) from a pre-sampled chain. */
 typedef struct bco_batch {
     int64_t n;
     double *st[7];
@@ -142,6 +145,7 @@ typedef struct bco_batch {
     double *reward; uint8_t *done; uint8_t *collided_now; int32_t *err;
     int32_t auto_reset;
     const double *init_st[7]; const double *init_min_dist; const int32_t *init_target_idx;
+    int32_t *geom; const int32_t *next_geom;
 } bco_batch;
 int bco_step_batch(const bco_params *p, const bco_batch *b, int threads);
 

@@ -464,6 +464,34 @@ def gen_kat_collision_table():
          resolution=costmap.get_resolution())
 
 
+def gen_mini_geometry():
+    """G9: the worlds RandomMiniEnv(seed=s) goes through on construction and on three successive reset() calls."""
+    from bc_gym_planning_env.envs.mini_env import RandomMiniEnv
+    seeds, episodes = list(range(12)), 4
+    worlds = np.zeros((len(seeds), episodes, 14))
+    maps, paths, lens, init = [], [], [], []
+    for si, s in enumerate(seeds):
+        env = RandomMiniEnv(seed=s)
+        for e in range(episodes):
+            if e:
+                env.reset()
+            cfg = env._env._config
+            worlds[si, e] = np.concatenate([cfg.start_pos.as_np(), cfg.end_pos.as_np(), cfg.obstacle_a.as_np(),
+                                            cfg.obstacle_o.as_np(), cfg.obstacle_b.as_np(), [cfg.h, cfg.w]])
+            st = env._env.get_state()
+            data = st.costmap.get_data()
+            assert set(np.unique(data)) <= {0, 254}
+            maps.append(np.packbits(data == 254, axis=1))
+            paths.append(st.original_path)
+            lens.append(len(st.original_path))
+            init.append([st.pose[0], st.pose[1], st.pose[2], st.reward_provider_state.min_spat_dist_so_far,
+                         st.reward_provider_state.target_idx])
+    save("g9_mini_geometry.npz", seeds=np.array(seeds), worlds=worlds, maps=np.stack(maps),
+         map_shape=np.array(data.shape), origin=np.array(st.costmap.get_origin()),
+         resolution=st.costmap.get_resolution(), paths=np.concatenate(paths), lens=np.array(lens),
+         init=np.array(init))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     O.build()
@@ -474,6 +502,7 @@ def main():
     gen_pose_collides()
     gen_reward()
     gen_kat_collision_table()
+    gen_mini_geometry()
     gen_diffdrive_trajectories()
     gen_trajectories()
 

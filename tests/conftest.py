@@ -25,3 +25,10 @@ def oracle():
     O.build()
     O.lib()
     return O
+
+
+@pytest.fixture(scope="session")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch

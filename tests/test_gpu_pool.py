@@ -1,0 +1,152 @@
+"""Geometry pool on the GPU: the batched sampler with its GPU acceptance test against the
+reference's worlds, and stepping / resetting along pool chains against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from util import ATOL, GOLDEN, z_in
+
+pytestmark = pytest.mark.gpu
+
+MODES = [dict(), dict(defer=0), dict(cull=0, exact_mode=1), dict(cull=0, exact_mode=2), dict(dense_threshold=0),
+         dict(dense_threshold=64)]
+
+
+def _ids(m):
+    return "-".join("%s%d" % (k[:4], v) for k, v in sorted(m.items())) or "default"
+
+
+def test_gpu_sampler_reproduces_reference_worlds(torch_cuda):
+    from bc_gym_planning_env_amd import mini_env
+    g = np.load(os.path.join(GOLDEN, "g9_mini_geometry.npz"))
+    seeds, episodes = [int(s) for s in g["seeds"]], g["worlds"].shape[1]
+    pool = mini_env.sample_pool(None, seeds, episodes)
+    cols = int(g["map_shape"][1])
+    for k, w in enumerate(pool.worlds):
+        ref = g["worlds"][k // episodes, k % episodes]
+        mine = np.concatenate([w.start_pos, w.end_pos, w.obstacle_a, w.obstacle_o, w.obstacle_b, [w.h, w.w]])
+        assert (mine == ref).all(), k
+        want = np.unpackbits(g["maps"][k], axis=1)[:, :cols].astype(bool)
+        assert ((pool.costmaps[k].get_data() == 254) == want).all()
+
+
+def _pool_and_oracle(oracle, mini_env, n, n_chains, episodes, timeout, next_geom=True):
+    from bc_gym_planning_env_amd import EnvParams
+    params = mini_env.RandomMiniEnvParams(
+        env_params=EnvParams(goal_ang_dist=np.pi / 8., goal_spat_dist=0.2, iteration_timeout=timeout))
+    pool = mini_env.sample_pool(params, list(range(100, 100 + n_chains)), episodes)
+    env = mini_env.BatchedRandomMiniEnv(n, params, pool=pool, auto_reset=True, seed=11,
+                                        draw_new_turn_on_reset=next_geom)
+    maps = np.stack([c.get_data() for c in pool.costmaps])
+    origins = np.stack([c.get_origin() for c in pool.costmaps])
+    paths = env._paths
+    max_len = max(len(p) for p in paths)
+    pbuf = np.zeros((len(paths), max_len, 3))
+    for k, p in enumerate(paths):
+        pbuf[k, :len(p)] = p
+    i = np.arange(n)
+    geom0 = (i % n_chains) * episodes + (i // n_chains) % episodes
+    p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE, spatial_precision=0.2, angular_precision=np.pi / 8,
+                           iteration_timeout=timeout)
+    ref = oracle.OracleBatch(p, n, maps, origins, params.env_params.resolution, pbuf, lens=[len(q) for q in paths],
+                             geom=geom0, next_geom=pool.next_geom if next_geom else None)
+    ref.reset_from_paths()
+    ref.reset_all_to_geom(advance=True)    # the constructor's reset() moves every env to world 1 of its chain
+    return env, ref, pool
+
+
+def _compare(env, ref, t=None):
+    np.testing.assert_array_equal(env.geom_of_env.cpu().numpy(), ref.geom, err_msg="geom step %s" % t)
+    np.testing.assert_array_equal(env.state.target_idx.cpu().numpy(), ref.target_idx)
+    np.testing.assert_array_equal(env.state.current_iter.cpu().numpy(), ref.cur_iter)
+    np.testing.assert_array_equal(env.state.robot_collided.cpu().numpy(), ref.collided)
+    np.testing.assert_allclose(env.state.robot.cpu().numpy(), np.stack(ref.st), rtol=0, atol=ATOL)
+    np.testing.assert_allclose(env.state.min_spat_dist_so_far.cpu().numpy(), ref.min_dist, rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=_ids)
+def test_pool_steps_and_resets_vs_oracle(torch_cuda, oracle, mode):
+    """Short episodes (timeout 25) over a small pool: hundreds of resets, each moving an env to its next world."""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import mini_env
+    n, steps = 768, 90
+    env, ref, pool = _pool_and_oracle(oracle, mini_env, n, n_chains=7, episodes=3, timeout=25)
+    env.set_tuning(**mode)
+    _compare(env, ref, "init")
+    rng = np.random.RandomState(4)
+    zout = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    resets = hits = 0
+    for t in range(steps):
+        a = env.action_space.sample_batch(n, rng)
+        a[:, 0] *= 3.0
+        env.step(a, noise_z_out=zout)
+        ref.step(a.astype(np.float64), z_in(zout.cpu().numpy()), auto_reset=True, threads=8)
+        np.testing.assert_array_equal(env.done.cpu().numpy(), ref.done, err_msg="done step %d" % t)
+        np.testing.assert_array_equal(env.collided_now.cpu().numpy(), ref.collided_now)
+        np.testing.assert_allclose(env.reward.cpu().numpy(), ref.reward, rtol=0, atol=ATOL)
+        _compare(env, ref, t)
+        resets += int(ref.done.sum())
+        hits += int(ref.collided_now.sum())
+    assert resets > 2 * n and hits > 20
+    assert len(np.unique(ref.geom)) == len(pool)        # every world of the pool was in use at the end
+
+
+def test_pool_without_successor_table_keeps_worlds(torch_cuda, oracle):
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import mini_env
+    n = 256
+    env, ref, pool = _pool_and_oracle(oracle, mini_env, n, n_chains=5, episodes=2, timeout=10, next_geom=False)
+    g0 = env.geom_of_env.cpu().numpy().copy()
+    rng = np.random.RandomState(1)
+    zout = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    for t in range(25):
+        a = env.action_space.sample_batch(n, rng)
+        env.step(a, noise_z_out=zout)
+        ref.step(a.astype(np.float64), z_in(zout.cpu().numpy()), auto_reset=True, threads=4)
+        _compare(env, ref, t)
+    np.testing.assert_array_equal(env.geom_of_env.cpu().numpy(), g0)
+
+
+def test_pool_masked_reset_and_views(torch_cuda, oracle):
+    """reset(mask) advances only the masked envs; envs[i] hands back the world the env is currently on."""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import mini_env
+    n = 128
+    env, ref, pool = _pool_and_oracle(oracle, mini_env, n, n_chains=4, episodes=4, timeout=1200)
+    before = env.geom_of_env.cpu().numpy().copy()
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    mask[::3] = 1
+    env.reset(mask)
+    after = env.geom_of_env.cpu().numpy()
+    m = mask.cpu().numpy().astype(bool)
+    np.testing.assert_array_equal(after[~m], before[~m])
+    np.testing.assert_array_equal(after[m], pool.next_geom[before[m]])
+    for i in (0, 1, 3, 127):
+        st = env.envs[i].get_state()
+        k = int(after[i])
+        assert st.costmap is pool.costmaps[k]
+        np.testing.assert_array_equal(st.original_path, env._paths[k])
+        np.testing.assert_array_equal(st.pose, env._paths[k][0])
+
+
+def test_pool_full_size_two_kernel_path(torch_cuda, oracle):
+    """65 536 envs over a 64 x 4 pool: the fast + pending kernel pair with per-env geometry entries; every env is
+    checked against the oracle."""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import mini_env
+    n, steps = 65536, 12
+    env, ref, pool = _pool_and_oracle(oracle, mini_env, n, n_chains=64, episodes=4, timeout=8)
+    rng = np.random.RandomState(2)
+    zout = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    resets = 0
+    for t in range(steps):
+        a = env.action_space.sample_batch(n, rng)
+        a[:, 0] *= 3.0
+        env.step(a, noise_z_out=zout)
+        ref.step(a.astype(np.float64), z_in(zout.cpu().numpy()), auto_reset=True, threads=16)
+        np.testing.assert_array_equal(env.done.cpu().numpy(), ref.done, err_msg="done step %d" % t)
+        np.testing.assert_array_equal(env.collided_now.cpu().numpy(), ref.collided_now)
+        _compare(env, ref, t)
+        resets += int(ref.done.sum())
+    assert resets >= n
