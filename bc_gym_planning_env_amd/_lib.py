@@ -72,6 +72,10 @@ SYMBOLS = {
                                       C.c_void_p]),
     "bcp_normalize_angle": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "bcp_world_to_pixel": (C.c_int, [_H, C.c_void_p, C.c_int64, _f64p, C.c_double, C.c_void_p, C.c_void_p]),
+    "bcp_egocentric_shape": (C.c_int, [_H, _f64p, _i32p]),
+    "bcp_egocentric_costmaps": (C.c_int, [_H, C.c_void_p, C.c_int64, _f64p, _f64p, C.c_uint8, C.c_void_p,
+                                          C.c_void_p]),
+    "bcp_goal_n_state": (C.c_int, [_H, _f64p, C.c_void_p, C.c_void_p]),
     "bcp_time_step_kernels": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p,
                                         C.POINTER(C.c_float)]),
     "bcp_time_steps": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]),

@@ -143,6 +143,9 @@ struct bcp_handle {
     int32_t dense_threshold;  // auto: more ambiguous lanes than this in a wave -> per-thread rasteriser
     int32_t cull_enabled;
     int32_t wide;             // kernel image may exceed 96 px: 8-word row masks in the cooperative path
+    const uint8_t* map_data;  // caller-owned raw costmap(s) as given to bcp_set_costmaps (egocentric views read them)
+    const int32_t* map_valid_rows;
+    const int32_t* map_valid_cols;
     int32_t n_geoms;          // > 0: geometry pool of that many entries
     int32_t* geom_of_env;     // caller-owned device int32 [n]
     const int32_t* next_geom; // caller-owned device int32 [n_geoms] or nullptr
@@ -1020,6 +1023,185 @@ __global__ void world_to_pixel_kernel(const double* __restrict__ xy, int64_t n, 
     out[2 * i + 1] = (int64_t)rint((xy[2 * i + 1] - oy) * inv_res);
 }
 
+// ---- egocentric observation ------------------------------------------------------------
+// extract_egocentric_costmap (utilities/costmap_utils.py:25-75) = cv2.getRotationMatrix2D + cv2.warpAffine with
+// INTER_NEAREST for every env at once.  OpenCV's nearest-neighbour warp works in 22.10 fixed point:
+//   X(x, y) = (sat_int((M1*y + M2)*1024) + 512 + sat_int(M0*x*1024)) >> 10      (and likewise Y with M4, M5, M3)
+// with M the float64 inverse of the 2x3 transform; a destination pixel copies src[Y][X] or takes the border value.
+struct EgoArgs {
+    const uint8_t* data;         // raw costmaps: [rows][cols] shared or one per map entry
+    int64_t map_stride;          // bytes per map entry (0 when shared)
+    const int32_t* valid_rows;   // per-entry true shape (optional)
+    const int32_t* valid_cols;
+    int32_t rows, cols;          // allocation shape of one map
+    const double* origins;       // per-entry origins or nullptr
+    double ox, oy, res, inv_res;
+    const double* poses;         // [n,3] or nullptr: the bound state
+    const double *sx, *sy, *sth;
+    const int32_t* geom_of_env;
+    int32_t shared;
+    int32_t has_window;
+    double win_ox, win_oy;
+    int32_t drows, dcols;        // output shape
+    uint32_t div_cols;           // floor(2^32 / dcols) + 1: exact l / dcols for l * dcols < 2^32
+    int32_t stage_map;           // shared map is copied to LDS (rows * cols bytes)
+    int32_t border;
+    int64_t n_envs;              // image i shows the costmap of env i % n_envs
+    uint8_t* out;                // [n][drows][dcols]
+};
+
+__device__ __forceinline__ int sat_int(double v)   // cv::saturate_cast<int>(double): nearest-even, saturating
+{
+    const double r = rint(v);
+    return r >= 2147483647.0 ? 2147483647 : (r <= -2147483648.0 ? (-2147483647 - 1) : (int)r);
+}
+
+// One workgroup per env.  LDS: [adelta, bdelta : dcols x 2 ints] [X0, Y0 : drows x 2 ints] [shared map bytes].
+__global__ void __launch_bounds__(256) ego_costmap_kernel(const EgoArgs a)
+{
+    const int64_t env = blockIdx.x;   // index of the image
+    const int tid = threadIdx.x;
+    const int64_t me = env % a.n_envs;
+    const int64_t g = a.shared ? 0 : (a.geom_of_env ? (int64_t)a.geom_of_env[me] : me);
+    double ox = a.ox, oy = a.oy;
+    if (a.origins) {
+        ox = a.origins[2 * g];
+        oy = a.origins[2 * g + 1];
+    }
+    double px, py, th;
+    if (a.poses) {
+        px = a.poses[3 * env];
+        py = a.poses[3 * env + 1];
+        th = a.poses[3 * env + 2];
+    } else {
+        px = a.sx[env];
+        py = a.sy[env];
+        th = a.sth[env];
+    }
+    // cv2.getRotationMatrix2D(world_to_pixel(pose), 180*theta/pi, 1): the centre is a Point2f
+    const float cx = (float)rint((px - ox) * a.inv_res), cy = (float)rint((py - oy) * a.inv_res);
+    const double angle = (180 * th / M_PI) * (M_PI / 180);
+    const double alpha = cos(angle), beta = sin(angle);
+    double M[6] = {alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy};
+    if (a.has_window) {
+        // shift so that the window origin lands on output pixel (0, 0); composed in float32 (costmap_utils.py:50-64)
+        const double dsx = rint((a.win_ox - (ox - px)) * a.inv_res), dsy = rint((a.win_oy - (oy - py)) * a.inv_res);
+        float t[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = (float)M[k];
+        t[2] = t[2] + (-(float)dsx);
+        t[5] = t[5] + (-(float)dsy);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) M[k] = (double)t[k];
+    }
+    {   // cv::warpAffine inverts the transform in float64
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0 ? 1. / D : 0;
+        const double A11 = M[4] * D, A22 = M[0] * D;
+        M[0] = A11;
+        M[1] *= -D;
+        M[3] *= -D;
+        M[4] = A22;
+        const double b1 = -M[0] * M[2] - M[1] * M[5];
+        const double b2 = -M[3] * M[2] - M[4] * M[5];
+        M[2] = b1;
+        M[5] = b2;
+    }
+    typedef __attribute__((address_space(3))) int* LdsI32;
+    const LdsI32 col_tab = (LdsI32)lds_dyn;          // [dcols][2] = adelta, bdelta
+    const LdsI32 row_tab = col_tab + 2 * a.dcols;    // [drows][2] = X0, Y0 (rounding term included)
+    __attribute__((address_space(3))) uint8_t* lmap = (__attribute__((address_space(3))) uint8_t*)(row_tab + 2 * a.drows);
+    for (int x = tid; x < a.dcols; x += 256) {
+        col_tab[2 * x] = sat_int(M[0] * x * 1024);
+        col_tab[2 * x + 1] = sat_int(M[3] * x * 1024);
+    }
+    for (int y = tid; y < a.drows; y += 256) {
+        row_tab[2 * y] = sat_int((M[1] * y + M[2]) * 1024) + 512;
+        row_tab[2 * y + 1] = sat_int((M[4] * y + M[5]) * 1024) + 512;
+    }
+    const uint8_t* src = a.data + g * a.map_stride;
+    if (a.stage_map) {
+        const int words = (a.rows * a.cols + 3) / 4;   // (the allocation behind a costmap tensor is dword-padded)
+        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+        __attribute__((address_space(3))) uint32_t* l32 = (__attribute__((address_space(3))) uint32_t*)lmap;
+        for (int k = tid; k < words; k += 256) l32[k] = s32[k];
+    }
+    __syncthreads();
+    const int vrows = a.valid_rows ? a.valid_rows[g] : a.rows, vcols = a.valid_cols ? a.valid_cols[g] : a.cols;
+    const int64_t P = (int64_t)a.drows * a.dcols;
+    const int64_t B = env * P;                       // byte offset of this env's image in `out`
+    const int64_t w0 = B >> 2, w1 = (B + P - 1) >> 2;  // aligned dwords that hold at least one of its bytes
+    for (int64_t w = w0 + tid; w <= w1; w += 256) {
+        const int64_t l0 = 4 * w - B;                // image-local index of the dword's first byte (may be < 0)
+        int l = (int)(l0 < 0 ? 0 : l0);
+        int y = (int)__umulhi((uint32_t)l, a.div_cols), x = l - y * a.dcols;
+        int yy = y < a.drows ? y : 0;
+        int rx = row_tab[2 * yy], ry = row_tab[2 * yy + 1];
+        uint32_t packed = 0;
+        uint32_t have = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t lj = l0 + j;
+            if (lj >= 0 && lj < P) {
+                const int X = (rx + col_tab[2 * x]) >> 10, Y = (ry + col_tab[2 * x + 1]) >> 10;  // (saturate_cast<short> never bites:
+                uint32_t v = (uint32_t)a.border;                              //  |X|, |Y| < 2^21 and maps are < 2^15)
+                if ((unsigned)X < (unsigned)vcols && (unsigned)Y < (unsigned)vrows)
+                    v = a.stage_map ? (uint32_t)lmap[Y * a.cols + X] : (uint32_t)src[(int64_t)Y * a.cols + X];
+                packed |= v << (8 * j);
+                have |= 1u << j;
+                if (++x == a.dcols) {
+                    x = 0;
+                    ++y;
+                    yy = y < a.drows ? y : 0;
+                    rx = row_tab[2 * yy];
+                    ry = row_tab[2 * yy + 1];
+                }
+            }
+        }
+        if (have == 0xFu) {
+            reinterpret_cast<uint32_t*>(a.out)[w] = packed;
+        } else {  // first / last dword of the image: shared with the neighbouring env's image
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (have & (1u << j)) a.out[4 * w + j] = (uint8_t)(packed >> (8 * j));
+        }
+    }
+}
+
+// EgocentricCostmap.observation's goal_n_state (envs/egocentric.py:140-160), one thread per env
+__global__ void goal_n_state_kernel(const StepStatic* __restrict__ S, double wsx, double wsy, int n_state,
+                                    float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S->n) return;
+    const int64_t g = S->geom_of_env ? (int64_t)S->geom_of_env[i] : i;
+    const int m = S->path.shared ? S->path.max_len : S->path.lens[g];
+    const int target = S->st.target_idx[i];
+    float* o = out + i * (3 + n_state);
+    if (target > m - 1) {   // nothing left of the path: zeros (egocentric.py:142-150)
+        for (int k = 0; k < 3 + n_state; ++k) o[k] = 0.0f;
+        return;
+    }
+    const double* wp = S->path.pts + ((S->path.shared ? 0 : g * (int64_t)S->path.max_len) + target) * 5;
+    const double x = S->st.x[i], y = S->st.y[i], th = S->st.angle[i];
+    // inverse_transform (coordinate_transformations.py:57-84), then project_poses (:310-328)
+    const double c = cos(th), s = sin(th);
+    const double tx = -x * c - y * s, ty = x * s - y * c, tt = normalize_angle(-th);
+    const double ct = cos(tt), st = sin(tt);
+    const double ex = ct * wp[0] + (-st) * wp[1] + tx;
+    const double ey = st * wp[0] + ct * wp[1] + ty;
+    const double eth = normalize_angle(wp[2] + tt);
+    o[0] = (float)fmin(fmax(ex / wsx, -1.0), 1.0);
+    o[1] = (float)fmin(fmax(ey / wsy, -1.0), 1.0);
+    o[2] = (float)eth;
+    o[3] = (float)x;                    // robot_state.to_numpy_array(): x, y, angle, v, w (, wheel_angle)
+    o[4] = (float)y;
+    o[5] = (float)th;
+    o[6] = (float)S->st.v[i];
+    o[7] = (float)S->st.w[i];
+    if (n_state > 5) o[8] = (float)S->st.wheel[i];
+}
+
 // ------------------------------------------------------------------------------------------------ host API
 // ---- sample points of the distance-field classification (see bcp_coop.h) -----------------------------------
 static double seg_dist(double px, double py, double ax, double ay, double bx, double by)
@@ -1281,6 +1463,9 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
                        valid_rows, valid_cols);
     HIP_TRY(hipGetLastError());
     h->resolution = resolution;
+    h->map_data = data;
+    h->map_valid_rows = valid_rows;
+    h->map_valid_cols = valid_cols;
     fill_dev_params(h);
     MapDesc& m = h->map;
     m.bits = h->bitmap;
@@ -1676,6 +1861,95 @@ extern "C" int bcp_world_to_pixel(bcp_handle* h, const double* xy, int64_t n, co
     HIP_TRY(hipSetDevice(h->device));
     hipLaunchKernelGGL(world_to_pixel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xy, n,
                        origin[0], origin[1], 1.0 / resolution, out);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+// ---- egocentric observation ----------------------------------------------------------------------------------
+static int ego_shape(const bcp_handle* h, const double* window_size, int32_t* drows, int32_t* dcols)
+{
+    if (window_size) {
+        const double inv = 1.0 / h->resolution;
+        *dcols = (int32_t)std::nearbyint(window_size[0] * inv);  // world_to_pixel(resulting_size, (0, 0), resolution)
+        *drows = (int32_t)std::nearbyint(window_size[1] * inv);
+    } else {
+        *drows = h->map.rows;
+        *dcols = h->map.cols;
+    }
+    return *drows > 0 && *dcols > 0 && (int64_t)*drows * *dcols * *dcols < (int64_t)1 << 32 && *dcols <= 8192 && *drows <= 8192;
+}
+
+extern "C" int bcp_egocentric_shape(bcp_handle* h, const double* window_size, int32_t* shape_hw)
+{
+    if (!h || !shape_hw) return fail(BCP_E_INVALID, "bcp_egocentric_shape: null argument");
+    if (!h->have_map) return fail(BCP_E_STATE, "bcp_egocentric_shape: costmaps not set");
+    if (!ego_shape(h, window_size, &shape_hw[0], &shape_hw[1]))
+        return fail(BCP_E_INVALID, "bcp_egocentric_shape: unsupported window size");
+    return BCP_OK;
+}
+
+extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64_t n, const double* window_origin,
+                                       const double* window_size, uint8_t border_value, uint8_t* out, void* stream)
+{
+    if (!h || !out) return fail(BCP_E_INVALID, "bcp_egocentric_costmaps: null argument");
+    if (!h->have_map) return fail(BCP_E_STATE, "bcp_egocentric_costmaps: costmaps not set");
+    if (!poses && !h->have_state) return fail(BCP_E_STATE, "bcp_egocentric_costmaps: no poses given and no state bound");
+    if (n <= 0 || (!poses && n != h->n)) return fail(BCP_E_INVALID, "bcp_egocentric_costmaps: n must be n_envs without poses");
+    if ((window_origin == nullptr) != (window_size == nullptr))
+        return fail(BCP_E_INVALID, "bcp_egocentric_costmaps: window origin and size go together");
+    EgoArgs a;
+    memset(&a, 0, sizeof(a));
+    if (!ego_shape(h, window_size, &a.drows, &a.dcols))
+        return fail(BCP_E_INVALID, "bcp_egocentric_costmaps: unsupported window size");
+    HIP_TRY(hipSetDevice(h->device));
+    a.data = h->map_data;
+    a.shared = h->map.shared;
+    a.rows = h->map.rows;
+    a.cols = h->map.cols;
+    a.map_stride = a.shared ? 0 : (int64_t)a.rows * a.cols;
+    a.valid_rows = h->map_valid_rows;
+    a.valid_cols = h->map_valid_cols;
+    a.origins = h->map.origins;
+    a.ox = h->map.ox;
+    a.oy = h->map.oy;
+    a.res = h->resolution;
+    a.inv_res = h->map.inv_res;
+    a.poses = poses;
+    a.sx = h->st.x;
+    a.sy = h->st.y;
+    a.sth = h->st.angle;
+    a.geom_of_env = h->n_geoms > 0 ? h->geom_of_env : nullptr;
+    a.has_window = window_origin != nullptr;
+    if (window_origin) {
+        a.win_ox = window_origin[0];
+        a.win_oy = window_origin[1];
+    }
+    a.div_cols = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)a.dcols) + 1;
+    const size_t tab_bytes = (size_t)(a.dcols + a.drows) * 2 * sizeof(int32_t);
+    const size_t map_bytes = ((size_t)a.rows * a.cols + 3) & ~(size_t)3;
+    a.stage_map = (a.shared && tab_bytes + map_bytes <= 60 * 1024) ? 1 : 0;
+    a.border = border_value;
+    a.out = out;
+    a.n_envs = h->n;
+    hipLaunchKernelGGL(ego_costmap_kernel, dim3((unsigned)n), dim3(256), tab_bytes + (a.stage_map ? map_bytes : 0),
+                       (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+extern "C" int bcp_goal_n_state(bcp_handle* h, const double* world_size, float* out, void* stream)
+{
+    if (!h || !world_size || !out) return fail(BCP_E_INVALID, "bcp_goal_n_state: null argument");
+    if (!h->have_path || !h->have_state) return fail(BCP_E_STATE, "bcp_goal_n_state: paths and state must be set first");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (h->static_dirty) {
+        const int rc = upload_step_static(h, s);
+        if (rc != BCP_OK) return rc;
+    }
+    const int n_state = h->params.model == BCP_MODEL_TRICYCLE ? 6 : 5;
+    hipLaunchKernelGGL(goal_n_state_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, h->dev_static,
+                       world_size[0], world_size[1], n_state, out);
     HIP_TRY(hipGetLastError());
     return BCP_OK;
 }

@@ -5,6 +5,7 @@ try/except ImportError), batched over many inputs.
   pose_collides         envs/base/env.py:464-489, utilities/costmap_utils.py:178-203
   normalize_angle       utilities/coordinate_transformations.py:17-36   (normalize_angle_impl)
   world_to_pixel        utilities/coordinate_transformations.py:169-205 (world_to_pixel_impl)
+  extract_egocentric_costmap   utilities/costmap_utils.py:25-75 (cv2.getRotationMatrix2D + cv2.warpAffine, nearest)
   robot_step            IRobot.step: tricycle_model.py:478-538 / differential_drive.py:236-265
 """
 import ctypes as C
@@ -89,6 +90,23 @@ class NativeOps(object):
         p = self._dev(poses, torch.float64)
         out = torch.empty(p.shape[0], dtype=torch.uint8, device=self.device)
         _lib.check(self._lib.bcp_pose_collides(self._h, p.data_ptr(), p.shape[0], out.data_ptr(), self._stream()))
+        return out
+
+    def extract_egocentric_costmap(self, poses, resulting_origin=None, resulting_size=None, border_value=0):
+        """The costmap given to set_costmap seen from each of poses [n,3] -> uint8 [n, rows, cols] (robot at (0, 0)
+        heading +x; resulting_origin / resulting_size in metres, both or neither)."""
+        p = self._dev(np.atleast_2d(poses) if not isinstance(poses, torch.Tensor) else poses, torch.float64)
+        f64p = C.POINTER(C.c_double)
+        org = sz = None
+        if resulting_origin is not None:
+            org = np.ascontiguousarray(resulting_origin, dtype=np.float64)
+            sz = np.ascontiguousarray(resulting_size, dtype=np.float64)
+        shape = (C.c_int32 * 2)()
+        _lib.check(self._lib.bcp_egocentric_shape(self._h, sz.ctypes.data_as(f64p) if sz is not None else None, shape))
+        out = torch.empty((p.shape[0], shape[0], shape[1]), dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.bcp_egocentric_costmaps(
+            self._h, p.data_ptr(), p.shape[0], org.ctypes.data_as(f64p) if org is not None else None,
+            sz.ctypes.data_as(f64p) if sz is not None else None, int(border_value), out.data_ptr(), self._stream()))
         return out
 
     def robot_step(self, state7, actions, noise_z=None):

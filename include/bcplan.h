@@ -198,6 +198,24 @@ int bcp_normalize_angle(bcp_handle *h, const double *in, double *out, int64_t n,
 int bcp_world_to_pixel(bcp_handle *h, const double *xy, int64_t n, const double *origin, double resolution,
                        int64_t *out, void *stream);
 
+/* ---- egocentric observation (what envs/egocentric.py:102-160 feeds a policy) ------------------------------ */
+/* extract_egocentric_costmap(costmap, pose, resulting_origin, resulting_size, border_value)
+ * (utilities/costmap_utils.py:25-75: cv2.getRotationMatrix2D + cv2.warpAffine, INTER_NEAREST) for all envs in one
+ * launch: image i = the costmap of env (i % n_envs) seen from poses[i] ([n,3] device doubles; NULL = the bound
+ * state's current poses, n = n_envs), robot at (0, 0) heading along +x.  window_origin / window_size: host double[2] in metres (both or neither; NULL = output has
+ * the costmap's shape and only the rotation is applied).  out: uint8 [n, shape_hw[0], shape_hw[1]] as reported by
+ * bcp_egocentric_shape.  Reads the RAW uint8 costmaps last given to bcp_set_costmaps, which must still be alive
+ * (shared maps: the allocation must be readable up to the next multiple of 4 bytes). */
+int bcp_egocentric_shape(bcp_handle *h, const double *window_size /*host, or NULL*/, int32_t *shape_hw /*host [2]*/);
+int bcp_egocentric_costmaps(bcp_handle *h, const double *poses, int64_t n, const double *window_origin /*host*/,
+                            const double *window_size /*host*/, uint8_t border_value, uint8_t *out, void *stream);
+/* EgocentricCostmap.observation's `goal_n_state` (envs/egocentric.py:140-160) for all envs: the next way point in
+ * the robot frame (from_global_to_egocentric, coordinate_transformations.py:341-362) with its position divided by
+ * world_size (host double[2] = CostMap2D.world_size() of the egocentric map) and clipped to [-1, 1], followed by
+ * robot_state.to_numpy_array().  out: float32 [N, 3 + 6] (tricycle) / [N, 3 + 5] (diff-drive); zeros for envs whose
+ * path is exhausted. */
+int bcp_goal_n_state(bcp_handle *h, const double *world_size /*host*/, float *out, void *stream);
+
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* Runs `steps` bcp_step() launches back to back on `stream` bracketed by HIP events recorded on that stream and
  * returns the average kernel-launch duration in milliseconds (synchronises).  Used by bench.py for

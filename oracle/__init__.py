@@ -111,6 +111,13 @@ def lib():
         L.bco_reward.restype = C.c_double
         L.bco_initial_reward_state.argtypes = [_f64p, C.c_int, C.c_double, C.c_double, _f64p, _i32p]
         L.bco_initial_reward_state.restype = C.c_int
+        _f32p = C.POINTER(C.c_float)
+        L.bco_rotation_matrix_2d.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, _f64p]
+        L.bco_warp_affine_nearest.argtypes = [_u8p, C.c_int, C.c_int, _f64p, _u8p, C.c_int, C.c_int, C.c_uint8]
+        L.bco_extract_egocentric.argtypes = [_u8p, C.c_int, C.c_int, _f64p, C.c_double, _f64p, C.c_int, _f64p, _f64p,
+                                             C.c_uint8, _u8p, _i32p, _f64p]
+        L.bco_rotate_costmap.argtypes = [_u8p, C.c_int, C.c_int, C.c_double, C.c_uint8, _u8p]
+        L.bco_goal_n_state.argtypes = [_f64p, _f64p, C.c_int, _f64p, _f64p, C.c_int, _f32p]
         L.bco_step_batch.argtypes = [C.POINTER(Params), C.POINTER(Batch), C.c_int]
         L.bco_step_batch.restype = C.c_int
         _lib = L
@@ -260,6 +267,60 @@ def pose_collides(x, y, angle, verts, costmap, origin, resolution):
                                 float(resolution))
     assert r >= 0
     return bool(r)
+
+
+def rotation_matrix_2d(center, angle_deg, scale=1.0):
+    """cv2.getRotationMatrix2D -> float64 [2, 3]"""
+    m = np.zeros(6)
+    lib().bco_rotation_matrix_2d(float(center[0]), float(center[1]), float(angle_deg), float(scale), _p(m, _f64p))
+    return m.reshape(2, 3)
+
+
+def warp_affine_nearest(src, M, dsize, border=0):
+    """cv2.warpAffine(src, M, dsize=(cols, rows), flags=INTER_NEAREST, borderValue=border) for uint8 images"""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    m = _f64(np.asarray(M, dtype=np.float64).reshape(6))
+    out = np.zeros((int(dsize[1]), int(dsize[0])), dtype=np.uint8)
+    lib().bco_warp_affine_nearest(_p(src, _u8p), src.shape[0], src.shape[1], _p(m, _f64p), _p(out, _u8p), out.shape[0],
+                                  out.shape[1], int(border))
+    return out
+
+
+def extract_egocentric(data, origin, resolution, pose, resulting_origin=None, resulting_size=None, border=0,
+                       return_transform=False):
+    """extract_egocentric_costmap (utilities/costmap_utils.py:25-75) -> uint8 image [rows, cols]"""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    origin, pose = _f64(origin), _f64(pose)
+    win = resulting_origin is not None
+    assert win == (resulting_size is not None), "the oracle takes resulting_origin and resulting_size together"
+    wo = _f64(resulting_origin) if win else np.zeros(2)
+    ws = _f64(resulting_size) if win else np.zeros(2)
+    shape = np.zeros(2, dtype=np.int32)
+    m = np.zeros(6)
+    args = (_p(data, _u8p), data.shape[0], data.shape[1], _p(origin, _f64p), float(resolution), _p(pose, _f64p), int(win),
+            _p(wo, _f64p), _p(ws, _f64p), int(border))
+    lib().bco_extract_egocentric(*args, None, _p(shape, _i32p), _p(m, _f64p))
+    out = np.zeros((int(shape[0]), int(shape[1])), dtype=np.uint8)
+    lib().bco_extract_egocentric(*args, _p(out, _u8p), _p(shape, _i32p), _p(m, _f64p))
+    return (out, m.reshape(2, 3)) if return_transform else out
+
+
+def rotate_costmap(data, angle, border=0):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.zeros_like(data)
+    lib().bco_rotate_costmap(_p(data, _u8p), data.shape[0], data.shape[1], float(angle), int(border), _p(out, _u8p))
+    return out
+
+
+def goal_n_state(pose, remaining_path, world_size, robot_state):
+    """EgocentricCostmap.observation's goal_n_state (envs/egocentric.py:140-160) -> float32 [3 + len(robot_state)]"""
+    pose, ws, rs = _f64(pose), _f64(world_size), _f64(robot_state)
+    rem = _f64(remaining_path).reshape(-1, 3)
+    out = np.zeros(3 + len(rs), dtype=np.float32)
+    nxt = _f64(rem[0]) if len(rem) else np.zeros(3)
+    lib().bco_goal_n_state(_p(pose, _f64p), _p(nxt, _f64p), len(rem), _p(ws, _f64p), _p(rs, _f64p), len(rs),
+                           out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
 
 
 def find_last_reached(pose, path, sp, ap):

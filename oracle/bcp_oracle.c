@@ -557,6 +557,137 @@ int bco_env_step(const bco_params *p, double st[7], double *min_dist, int32_t *t
     return err;
 }
 
+/* ---- egocentric observation ---------------------------------------------------------------------------- */
+/* cv::getRotationMatrix2D (opencv imgproc imgwarp.cpp) */
+void bco_rotation_matrix_2d(double cx, double cy, double angle_deg, double scale, double M[6])
+{
+    float fx = (float)cx, fy = (float)cy; /* Point2f center */
+    double angle = angle_deg * (M_PI / 180);
+    double alpha = cos(angle) * scale, beta = sin(angle) * scale;
+    M[0] = alpha;
+    M[1] = beta;
+    M[2] = (1 - alpha) * fx - beta * fy;
+    M[3] = -beta;
+    M[4] = alpha;
+    M[5] = beta * fx + (1 - alpha) * fy;
+}
+
+static int sat_int(double v) /* cv::saturate_cast<int>(double) == cvRound: nearest, ties to even */
+{
+    double r = rint(v);
+    if (r >= 2147483647.0) return 2147483647;
+    if (r <= -2147483648.0) return (-2147483647 - 1);
+    return (int)r;
+}
+
+static int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+/* cv::warpAffine + hal::warpAffine / WarpAffineInvoker + remapNearest, INTER_NEAREST, BORDER_CONSTANT */
+void bco_warp_affine_nearest(const uint8_t *src, int rows, int cols, const double M_in[6], uint8_t *dst, int drows,
+                             int dcols, uint8_t border)
+{
+    const int AB_BITS = 10, AB_SCALE = 1 << 10, round_delta = (1 << 10) / 2;
+    double M[6];
+    for (int k = 0; k < 6; ++k) M[k] = M_in[k];
+    { /* dst -> src map */
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0 ? 1. / D : 0;
+        double A11 = M[4] * D, A22 = M[0] * D;
+        M[0] = A11;
+        M[1] *= -D;
+        M[3] *= -D;
+        M[4] = A22;
+        double b1 = -M[0] * M[2] - M[1] * M[5];
+        double b2 = -M[3] * M[2] - M[4] * M[5];
+        M[2] = b1;
+        M[5] = b2;
+    }
+    for (int y = 0; y < drows; ++y) {
+        int X0 = sat_int((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+        int Y0 = sat_int((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+        for (int x = 0; x < dcols; ++x) {
+            int adelta = sat_int(M[0] * x * AB_SCALE), bdelta = sat_int(M[3] * x * AB_SCALE);
+            int sx = sat_short((X0 + adelta) >> AB_BITS), sy = sat_short((Y0 + bdelta) >> AB_BITS);
+            uint8_t v = border;
+            if ((unsigned)sx < (unsigned)cols && (unsigned)sy < (unsigned)rows) v = src[(size_t)sy * cols + sx];
+            dst[(size_t)y * dcols + x] = v;
+        }
+    }
+}
+
+/* utilities/costmap_utils.py:25-75 */
+void bco_extract_egocentric(const uint8_t *map, int rows, int cols, const double origin[2], double resolution,
+                            const double pose[3], int has_window, const double window_origin[2],
+                            const double window_size[2], uint8_t border, uint8_t *out, int32_t out_shape[2],
+                            double *M_used)
+{
+    int64_t pix[2];
+    const double zero[2] = {0.0, 0.0};
+    bco_world_to_pixel(pose, 1, origin, resolution, pix); /* :41 */
+    double M[6];
+    bco_rotation_matrix_2d((double)pix[0], (double)pix[1], 180 * pose[2] / M_PI, 1.0, M); /* :43 */
+    int dcols = cols, drows = rows;
+    if (has_window) {
+        int64_t sz[2], dsp[2];
+        bco_world_to_pixel(window_size, 1, zero, resolution, sz); /* :48 */
+        dcols = (int)sz[0];
+        drows = (int)sz[1];
+        double delta[2] = {window_origin[0] - (origin[0] - pose[0]), window_origin[1] - (origin[1] - pose[1])}; /* :53 */
+        bco_world_to_pixel(delta, 1, zero, resolution, dsp);
+        /* _compose_affine_transforms (:57-62): both operands become float32 3x3 matrices and are multiplied in
+         * float32; with the shift matrix [[1,0,-dx],[0,1,-dy],[0,0,1]] on the left the only inexact operation is
+         * the final addition of the translation column. */
+        float t[6];
+        for (int k = 0; k < 6; ++k) t[k] = (float)M[k];
+        t[2] = t[2] + (-(float)dsp[0]);
+        t[5] = t[5] + (-(float)dsp[1]);
+        for (int k = 0; k < 6; ++k) M[k] = (double)t[k];
+    }
+    out_shape[0] = drows;
+    out_shape[1] = dcols;
+    if (M_used)
+        for (int k = 0; k < 6; ++k) M_used[k] = M[k];
+    if (out) bco_warp_affine_nearest(map, rows, cols, M, out, drows, dcols, border);
+}
+
+/* utilities/costmap_utils.py:78-104 (center_pixel_coords=None) */
+void bco_rotate_costmap(const uint8_t *map, int rows, int cols, double angle, uint8_t border, uint8_t *out)
+{
+    double deg = -angle * (180.0 / M_PI); /* np.rad2deg(-angle) */
+    if (deg != 0.) {
+        double M[6];
+        bco_rotation_matrix_2d((double)(cols / 2), (double)(rows / 2), deg, 1.0, M);
+        bco_warp_affine_nearest(map, rows, cols, M, out, rows, cols, border);
+    } else {
+        memcpy(out, map, (size_t)rows * cols);
+    }
+}
+
+/* envs/egocentric.py:140-160 */
+void bco_goal_n_state(const double pose[3], const double *next_waypoint, int remaining, const double world_size[2],
+                      const double *robot_state, int n_state, float *out)
+{
+    if (remaining <= 0) {
+        for (int k = 0; k < 3 + n_state; ++k) out[k] = 0.0f;
+        return;
+    }
+    /* inverse_transform (coordinate_transformations.py:57-84) */
+    double c = cos(pose[2]), s = sin(pose[2]);
+    double tx = -pose[0] * c - pose[1] * s;
+    double ty = pose[0] * s - pose[1] * c;
+    double tt = bco_normalize_angle(-pose[2]);
+    /* project_poses (:310-328): homogeneous matrix times (x, y, 1) */
+    double ct = cos(tt), st = sin(tt);
+    double ex = ct * next_waypoint[0] + (-st) * next_waypoint[1] + tx;
+    double ey = st * next_waypoint[0] + ct * next_waypoint[1] + ty;
+    double eth = bco_normalize_angle(next_waypoint[2] + tt);
+    double gx = clipd(ex / world_size[0], -1., 1.), gy = clipd(ey / world_size[1], -1., 1.);
+    out[0] = (float)gx;
+    out[1] = (float)gy;
+    out[2] = (float)eth;
+    for (int k = 0; k < n_state; ++k) out[3 + k] = (float)robot_state[k];
+}
+
 /* ------------------------------------------------------------------------------------ */
 typedef struct {
     const bco_params *p;

@@ -14,7 +14,11 @@
  * absent from /root/reference and from this image); it is pinned only by the reference
  * KATs test_path_tools.py:465-468 (493 cells) and test_costmap_utils.py:251-314
  * (20-pose collision table).  Beyond those the exact pixel set of a filled polygon is
- * "parity unpinned".
+ * "parity unpinned".  The same holds for the egocentric-observation functions
+ * bco_rotation_matrix_2d() / bco_warp_affine_nearest() (cv2.getRotationMatrix2D / cv2.warpAffine,
+ * INTER_NEAREST): restated from the published OpenCV algorithm (fixed-point AB_BITS = 10 coordinates)
+ * and pinned only by the reference KATs test_costmap_utils.py:38-189, 192-207 (mark positions after
+ * rotation / shift / cut, the 5-pixel image of a rotated 2x2 block, rotate_costmap's (29, 47)).
  *
  * Build:  make -C oracle         (gcc -O2 -ffp-contract=off, no fast-math)
  */
@@ -119,6 +123,29 @@ int bco_env_step(const bco_params *p, double st[7], double *min_dist, int32_t *t
                  double *cur_time, uint8_t *collided_sticky, const double cmd[2], const double z[3],
                  const uint8_t *map, int rows, int cols, const double origin[2], double resolution,
                  const double *path, int m, double *reward, uint8_t *done, uint8_t *collided_now, int *drawn);
+
+/* ---- egocentric observation -------------------------------------------------------- */
+/* cv2.getRotationMatrix2D(center, angle_deg, scale): center is a Point2f (float32), everything else float64. */
+void bco_rotation_matrix_2d(double cx, double cy, double angle_deg, double scale, double M[6]);
+/* cv2.warpAffine(src, M, (dcols, drows), flags=INTER_NEAREST, borderMode=BORDER_CONSTANT, borderValue): M maps
+ * src -> dst and is inverted in float64 first; source coordinates are 22.10 fixed point. */
+void bco_warp_affine_nearest(const uint8_t *src, int rows, int cols, const double M[6], uint8_t *dst, int drows,
+                             int dcols, uint8_t border);
+/* extract_egocentric_costmap (utilities/costmap_utils.py:25-75).  has_window: resulting_origin / resulting_size given
+ * (size in metres); otherwise the output has the source's shape.  out must hold out_shape[0]*out_shape[1] bytes
+ * (call with out == NULL to get the shape only).  M_used (optional) receives the 2x3 transform given to warpAffine. */
+void bco_extract_egocentric(const uint8_t *map, int rows, int cols, const double origin[2], double resolution,
+                            const double pose[3], int has_window, const double window_origin[2],
+                            const double window_size[2], uint8_t border, uint8_t *out, int32_t out_shape[2],
+                            double *M_used);
+/* rotate_costmap (costmap_utils.py:78-104), center None */
+void bco_rotate_costmap(const uint8_t *map, int rows, int cols, double angle, uint8_t border, uint8_t *out);
+/* EgocentricCostmap.observation's goal_n_state vector (envs/egocentric.py:140-160): the next way point in the robot
+ * frame (from_global_to_egocentric, coordinate_transformations.py:341-362), its position divided by the window's world
+ * size and clipped to [-1, 1], then robot_state.to_numpy_array(); float32.  n_state = 6 (tricycle) / 5 (diff-drive).
+ * remaining == 0 (path exhausted) gives zeros. */
+void bco_goal_n_state(const double pose[3], const double *next_waypoint, int remaining, const double world_size[2],
+                      const double *robot_state, int n_state, float *out);
 
 /* Batched SoA step over n envs with `threads` host threads.
  * state: 7 arrays of n doubles, state[f][i].  maps: shared (map_stride==0) or per-env at i*map_stride bytes.

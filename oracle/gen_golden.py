@@ -492,6 +492,43 @@ def gen_mini_geometry():
          init=np.array(init))
 
 
+def gen_egocentric():
+    """G10: EgocentricCostmap(env).step observations (envs/egocentric.py:102-160) along sampled-action trajectories:
+    the 133 x 117 egocentric costmap and the goal_n_state vector, with the state they were computed from."""
+    from bc_gym_planning_env.envs.egocentric import EgocentricCostmap
+    from bc_gym_planning_env.envs.synth_turn_env import AisleTurnEnv, AisleTurnEnvParams
+    from bc_gym_planning_env.envs.base import spaces
+    from bc_gym_planning_env.robot_models import differential_drive as dd
+    cases = [("mini_00", lambda: make_mini_env(0), 120), ("mini_05", lambda: make_mini_env(5), 120),
+             ("aisle", lambda: AisleTurnEnv(AisleTurnEnvParams()), 150)]
+    for tag, make, steps in cases:
+        base = make()
+        plan_env = base._env if hasattr(base, "_env") else base
+        env = EgocentricCostmap(base)
+        spaces.SPACE_LOCAL_RANDOM_STATE.seed(77)
+        st0 = plan_env.get_state()
+        imgs, vecs, states, tidx = [], [], [], []
+        with SlotTap(dd, 5):
+            for t in range(steps):
+                a = env.action_space.sample()
+                a = type(a)(command=np.array([a.command[0] * 2.5, a.command[1]]))    # drive faster: see more of the map
+                obs, _r, done, _ = env.step(a)
+                s = plan_env._state
+                img = obs['env'][:, :, 0]
+                assert set(np.unique(img)) <= {0, 254}
+                imgs.append(np.packbits(img == 254, axis=1))
+                vecs.append(obs['goal_n_state'][:, 0].copy())
+                states.append(tri_state_vec(s.robot_state))
+                tidx.append(s.reward_provider_state.target_idx)
+                if done:
+                    break
+        save("g10_ego_%s.npz" % tag, costmap=st0.costmap.get_data().copy(), origin=np.array(st0.costmap.get_origin()),
+             resolution=np.float64(st0.costmap.get_resolution()), path=np.array(st0.reward_provider_state.path),
+             images=np.stack(imgs), image_shape=np.array(img.shape), goal_n_state=np.stack(vecs),
+             states=np.stack(states), target_idx=np.array(tidx, dtype=np.int32),
+             window_origin=np.array([-0.5, -2.0]), window_size=np.array([3.5, 4.0]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     O.build()
@@ -503,6 +540,7 @@ def main():
     gen_reward()
     gen_kat_collision_table()
     gen_mini_geometry()
+    gen_egocentric()
     gen_diffdrive_trajectories()
     gen_trajectories()
 

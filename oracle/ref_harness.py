@@ -3,8 +3,9 @@
 The reference (/root/reference, pure Python) does not import as-is here: `cv2` is not installed and numpy >= 1.24
 dropped the `np.int` / `np.float` aliases it uses.  These are ordinary Python errors (nothing was denied by the
 environment).  This harness
-  * registers a stand-in module object for `cv2` whose only working entry points are `fillPoly` and `line`, both
-    backed by the oracle's own OpenCV restatement (oracle/bcp_oracle.c: bco_fill_poly / bco_line), and
+  * registers a stand-in module object for `cv2` whose only working entry points are `fillPoly`, `line`,
+    `getRotationMatrix2D` and `warpAffine` (INTER_NEAREST), all backed by the oracle's own OpenCV restatement
+    (oracle/bcp_oracle.c: bco_fill_poly / bco_line / bco_rotation_matrix_2d / bco_warp_affine_nearest), and
   * restores `np.int = int`, `np.float = float`.
 Everything else that then runs is the reference's own code.  Consequently golden vectors that pass through
 `cv2.fillPoly` (get_pixel_footprint / pose_collides / full PlanEnv.step) pin the *rest* of the arithmetic exactly,
@@ -58,9 +59,24 @@ def _install_cv2_stub():
         O.line(img, p0, p1, int(value))
         return img
 
+    def get_rotation_matrix_2d(center, angle, scale=1):
+        return O.rotation_matrix_2d(center, angle, scale)
+
+    def warp_affine(src, M, dsize, flags=0, borderValue=0, *_a, **_k):
+        if flags != 0:
+            raise NotImplementedError("harness cv2.warpAffine only does INTER_NEAREST")
+        if np.asarray(src).dtype != np.uint8 or np.asarray(src).ndim != 2:
+            raise NotImplementedError("harness cv2.warpAffine only takes single-channel uint8 images")
+        value = borderValue[0] if isinstance(borderValue, (tuple, list)) else borderValue
+        return O.warp_affine_nearest(src, np.asarray(M, dtype=np.float64), dsize, int(value))
+
     cv2.fillPoly = fill_poly
     cv2.line = line
+    cv2.getRotationMatrix2D = get_rotation_matrix_2d
+    cv2.warpAffine = warp_affine
     cv2.setNumThreads = lambda *_a: None
+    cv2.getNumThreads = lambda *_a: 1
+    cv2.ipp = types.SimpleNamespace(setUseIPP=lambda *_a, **_k: None)
     cv2.ocl = types.SimpleNamespace(setUseOpenCL=lambda *_a: None)
     sys.modules["cv2"] = cv2
     return cv2

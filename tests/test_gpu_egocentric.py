@@ -1,0 +1,157 @@
+"""Egocentric observation on the GPU against the reference's fixtures (g10, recorded
+from the genuine EgocentricCostmap wrapper), the reference's known answers, and the oracle on random inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _marks(img):
+    r, c = np.where(img == 254)
+    return list(zip(c.tolist(), r.tolist()))
+
+
+def test_kat_extract_egocentric_costmap_gpu(torch_cuda):
+    """utilities/test_costmap_utils.py:38-195 through the HIP kernel"""
+    from bc_gym_planning_env_amd.ops import NativeOps
+    ops = NativeOps()
+    data = np.zeros((100, 100), dtype=np.uint8)
+    data[10, 20] = 254
+    ops.set_costmap(data, np.array([0.0, 0.0]), 0.05)
+
+    def ego(pose, org=None, size=None):
+        return ops.extract_egocentric_costmap(np.array([pose]), org, size)[0].cpu().numpy()
+
+    assert _marks(ego((0., 0., 0.))) == [(20, 10)]
+    assert _marks(ego((0.2, 0.2, 0.0))) == [(20, 10)]
+    assert ego((0.0, 0.0, np.pi / 6 - 0.05))[0, 22] == 254
+    assert _marks(ego((2.5, 2.5, -np.pi / 2.))) == [(90, 20)]
+    assert _marks(ego((2.5, 2.5, -np.pi / 2), [-2.5, -2.5], (5., 5.))) == [(90, 20)]
+    img = ego((2.5, 2.5, -np.pi / 2), [-2.5, -2.5], (4.6, 4.9))
+    assert img.shape == (98, 92) and _marks(img) == [(90, 20)]
+    assert _marks(ego((2.5, 2.5, 0.0), [-5., -4.], (5, 5))) == [(70, 40)]
+    img = ego((2.5, 2.5, 0.0), [-5., -4.], (4, 4))
+    assert img.shape == (80, 80) and _marks(img) == [(70, 40)]
+    assert _marks(ego((1.5, 1.5, -np.pi / 4), [-2., -2.], (4, 4))) == [(47, 19)]
+    img = ego((1., 1.5, -np.pi / 4), [-3., -3.], (7, 6))
+    assert img.shape == (120, 140) and _marks(img) == [(74, 46)]
+    ops.set_costmap(data, np.array([1.0, 2.0]), 0.05)
+    assert _marks(ego((3.5, 3.5, -np.pi / 4), [-2., -2.], (4, 4))) == [(33, 5)]
+    block = np.zeros((100, 100), dtype=np.uint8)
+    block[30:32, 30:32] = 254
+    ops.set_costmap(block, np.array([0.0, 0.0]), 0.05)
+    r, c = np.where(ego((1.5, 1.5, -np.pi / 4), [-2.0, -2.0], (4., 4)) != 0)
+    assert r.tolist() == [40, 41, 41, 41, 42] and c.tolist() == [40, 39, 40, 41, 40]
+
+
+@pytest.mark.parametrize("name", ["g10_ego_mini_00.npz", "g10_ego_mini_05.npz", "g10_ego_aisle.npz"])
+def test_g10_observation_from_reference_states(torch_cuda, name):
+    """every recorded state of the fixture becomes one env of a batch; one observation() must reproduce the
+    reference wrapper's images bit for bit and its goal_n_state vectors"""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    from bc_gym_planning_env_amd.egocentric import BatchedEgocentricCostmap
+    g = np.load(os.path.join(GOLDEN, name))
+    n = len(g["states"])
+    res = float(g["resolution"])
+    env = BatchedPlanEnv(CostMap2D(g["costmap"], res, g["origin"]), g["path"], EnvParams(resolution=res, refine_path=False),
+                         n_envs=n)
+    env.state.robot.copy_(torch.from_numpy(np.ascontiguousarray(g["states"].T)).cuda())
+    env.state.target_idx.copy_(torch.from_numpy(g["target_idx"]).cuda())
+    wrap = BatchedEgocentricCostmap(env)
+    assert wrap.image_shape == tuple(int(v) for v in g["image_shape"])
+    obs = wrap.observation()
+    cols = wrap.image_shape[1]
+    want = np.unpackbits(g["images"], axis=2)[:, :, :cols].astype(bool)
+    img = obs['env'].cpu().numpy()
+    assert img.shape == (n,) + wrap.image_shape + (1,)
+    assert ((img[..., 0] == 254) == want).all() and set(np.unique(img)) <= {0, 254}
+    vec = obs['goal_n_state'].cpu().numpy()
+    assert vec.shape == (n, 9, 1) and vec.dtype == np.float32
+    np.testing.assert_allclose(vec[:, :, 0], g["goal_n_state"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("shared", [True, False], ids=["shared-map", "private-maps"])
+def test_random_poses_vs_oracle(torch_cuda, oracle, shared):
+    """random poses (inside and far outside the map), several windows and border values, a costmap with arbitrary
+    byte values; private maps of different shapes go through the global-memory gather"""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    rng = np.random.RandomState(8)
+    n = 96
+    res = 0.05
+    shapes = [(90, 70)] if shared else [(90, 70), (64, 101), (33, 47)]
+    maps = [rng.randint(0, 256, s).astype(np.uint8) for s in shapes]
+    orgs = [rng.uniform(-2, 0, 2) for _ in shapes]
+    path = np.array([[0., 0., 0.], [1., 0., 0.], [2., 0., 0.]])
+    params = EnvParams(resolution=res, refine_path=False)
+    if shared:
+        env = BatchedPlanEnv(CostMap2D(maps[0], res, orgs[0]), path, params, n_envs=n)
+    else:
+        env = BatchedPlanEnv([CostMap2D(maps[i % 3], res, orgs[i % 3]) for i in range(n)], [path] * n, params, n_envs=n)
+    poses = np.stack([rng.uniform(-4, 6, n), rng.uniform(-4, 6, n), rng.uniform(-7, 7, n)], axis=1)
+    poses[0] = (0., 0., 0.)
+    poses[1] = (1.0, 1.0, np.pi)
+    pt = torch.from_numpy(poses).cuda()
+    import ctypes as C
+    from bc_gym_planning_env_amd import _lib
+    f64p = C.POINTER(C.c_double)
+    for org, size, border in (((-0.5, -2.0), (3.5, 4.0), 0), ((-1.0, -1.0), (2.0, 2.0), 255), (None, None, 7),
+                              ((-3.0, -0.7), (6.05, 1.45), 100)):
+        o = None if org is None else np.array(org, dtype=np.float64)
+        s = None if size is None else np.array(size, dtype=np.float64)
+        shape = (C.c_int32 * 2)()
+        _lib.check(env._lib.bcp_egocentric_shape(env._h, s.ctypes.data_as(f64p) if s is not None else None, shape))
+        if size is None and not shared:
+            assert tuple(shape) == (90, 101)         # allocation shape of the padded private maps
+        out = torch.full((n, shape[0], shape[1]), 99, dtype=torch.uint8, device="cuda")
+        guard = torch.full((16,), 123, dtype=torch.uint8, device="cuda")  # (allocated right after `out`, not adjacent)
+        _lib.check(env._lib.bcp_egocentric_costmaps(env._h, pt.data_ptr(), n, o.ctypes.data_as(f64p) if o is not None else None,
+                                                    s.ctypes.data_as(f64p) if s is not None else None, border,
+                                                    out.data_ptr(), None))
+        got = out.cpu().numpy()
+        assert (guard.cpu().numpy() == 123).all()
+        for i in range(n):
+            k = 0 if shared else i % 3
+            if size is None and not shared:
+                continue   # whole-map output of padded private maps has no reference counterpart of that shape
+            ref = oracle.extract_egocentric(maps[k], orgs[k], res, poses[i], o, s, border)
+            assert ref.shape == got[i].shape
+            assert (ref == got[i]).all(), (org, size, i, int((ref != got[i]).sum()))
+
+
+def test_wrapper_steps_with_pool_env(torch_cuda, oracle):
+    """EgocentricCostmap(RandomMiniEnv) batched: after every step the observation of each env matches the oracle on
+    that env's current world and state (including envs that were just reset onto their next world)"""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import EnvParams, mini_env
+    from bc_gym_planning_env_amd.egocentric import BatchedEgocentricCostmap
+    params = mini_env.RandomMiniEnvParams(
+        env_params=EnvParams(goal_ang_dist=np.pi / 8., goal_spat_dist=0.2, iteration_timeout=12))
+    pool = mini_env.sample_pool(params, [1, 2, 3], 3)
+    n = 48
+    env = mini_env.BatchedRandomMiniEnv(n, params, pool=pool, auto_reset=True, seed=2)
+    wrap = BatchedEgocentricCostmap(env)
+    rng = np.random.RandomState(0)
+    res = params.env_params.resolution
+    rows, cols = wrap.image_shape
+    world = np.array([(-0.5 + res * cols) - -0.5, (-2.0 + res * rows) - -2.0])
+    for t in range(30):
+        obs, _r, _d, _ = wrap.step(env.action_space.sample_batch(n, rng) * np.array([3.0, 1.0], dtype=np.float32))
+        img = obs['env'].cpu().numpy()[..., 0]
+        vec = obs['goal_n_state'].cpu().numpy()[..., 0]
+        st = env.state.robot.cpu().numpy()
+        geom = env.geom_of_env.cpu().numpy()
+        tidx = env.state.target_idx.cpu().numpy()
+        for i in range(n):
+            cm = pool.costmaps[geom[i]]
+            ref = oracle.extract_egocentric(cm.get_data(), cm.get_origin(), res, st[:3, i], (-0.5, -2.0), (3.5, 4.0))
+            assert (ref == img[i]).all(), (t, i)
+            rs = np.array([st[0, i], st[1, i], st[2, i], st[3, i], st[4, i], st[6, i]])
+            want = oracle.goal_n_state(st[:3, i], env._paths[geom[i]][tidx[i]:], world, rs)
+            np.testing.assert_allclose(vec[i], want, rtol=0, atol=1e-6)
+    assert len(np.unique(geom)) > 3

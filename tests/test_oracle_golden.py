@@ -156,3 +156,24 @@ def test_g8_diffdrive_trajectories(oracle, path):
         np.testing.assert_array_equal([env.st[f][0] for f in range(7)], g["states"][t], err_msg="step %d" % t)
         assert (env.reward[0], env.done[0], env.collided[0], env.target_idx[0], env.min_dist[0]) == \
             (g["reward"][t], g["done"][t], g["collided"][t], g["target_idx"][t], g["min_dist"][t]), t
+
+
+# ---- G10: egocentric observation (envs/egocentric.py:102-160 through the genuine reference) ---------------------
+@pytest.mark.parametrize("name", ["g10_ego_mini_00.npz", "g10_ego_mini_05.npz", "g10_ego_aisle.npz"])
+def test_g10_egocentric_observation(oracle, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name))
+    res, org = float(g["resolution"]), g["origin"]
+    wo, ws = g["window_origin"], g["window_size"]
+    rows, cols = [int(v) for v in g["image_shape"]]
+    # CostMap2D.world_size() of the extracted map (costmap_2d.py:107-121)
+    world = np.array([(wo[0] + res * cols) - wo[0], (wo[1] + res * rows) - wo[1]])
+    for t in range(len(g["states"])):
+        st = g["states"][t]
+        img = oracle.extract_egocentric(g["costmap"], org, res, st[:3], wo, ws)
+        want = np.unpackbits(g["images"][t], axis=1)[:, :cols].astype(bool)
+        assert img.shape == (rows, cols)
+        assert ((img == 254) == want).all() and set(np.unique(img)) <= {0, 254}, (name, t)
+        # robot_state.to_numpy_array() = x, y, angle, v, w, wheel_angle (tricycle_model.py:267-271)
+        rs = np.array([st[0], st[1], st[2], st[3], st[4], st[6]])
+        vec = oracle.goal_n_state(st[:3], g["path"][g["target_idx"][t]:], world, rs)
+        np.testing.assert_allclose(vec, g["goal_n_state"][t], rtol=0, atol=1e-6)

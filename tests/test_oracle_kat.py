@@ -70,3 +70,60 @@ def test_fill_matches_scanline_definition(oracle):
                     nz = np.flatnonzero(row)
                     if len(nz):
                         assert nz[-1] - nz[0] + 1 == len(nz)
+
+
+# ---- egocentric costmap: the reference's own known answers (utilities/test_costmap_utils.py:38-207) ------------
+def _marks(img):
+    r, c = np.where(img == 254)
+    return list(zip(c.tolist(), r.tolist()))   # (x, y) like assert_mark_at
+
+
+def test_kat_extract_egocentric_costmap(oracle):
+    O = oracle
+    data = np.zeros((100, 100), dtype=np.uint8)
+    data[10, 20] = 254
+    org, res = np.array([0.0, 0.0]), 0.05
+    # dummy cut / pure shift of the robot: the data stay where they are (test_costmap_utils.py:45-63)
+    assert _marks(O.extract_egocentric(data, org, res, (0., 0., 0.))) == [(20, 10)]
+    assert _marks(O.extract_egocentric(data, org, res, (0.2, 0.2, 0.0))) == [(20, 10)]
+    # rotated so that the mark is almost in front of the robot (:66-73)
+    img = O.extract_egocentric(data, org, res, (0.0, 0.0, np.pi / 6 - 0.05))
+    assert img.shape == (100, 100) and img[0, 22] == 254
+    # robot in the centre, turned by -pi/2, with and without explicit window (:76-93)
+    assert _marks(O.extract_egocentric(data, org, res, (2.5, 2.5, -np.pi / 2.))) == [(90, 20)]
+    img = O.extract_egocentric(data, org, res, (2.5, 2.5, -np.pi / 2), np.array([-2.5, -2.5]), np.array((5., 5.)))
+    assert img.shape == (100, 100) and _marks(img) == [(90, 20)]
+    img = O.extract_egocentric(data, org, res, (2.5, 2.5, -np.pi / 2), np.array([-2.5, -2.5]), (4.6, 4.9))
+    assert img.shape == (98, 92) and _marks(img) == [(90, 20)]
+    # shift, shift and cut (:107-129)
+    img = O.extract_egocentric(data, org, res, (2.5, 2.5, 0.0), np.array([-5., -4.]), (5, 5))
+    assert img.shape == (100, 100) and _marks(img) == [(70, 40)]
+    img = O.extract_egocentric(data, org, res, (2.5, 2.5, 0.0), np.array([-5., -4.]), (4, 4))
+    assert img.shape == (80, 80) and _marks(img) == [(70, 40)]
+    # rotate, shift and cut / expand (:132-155)
+    img = O.extract_egocentric(data, org, res, (1.5, 1.5, -np.pi / 4), np.array([-2., -2.]), (4, 4))
+    assert img.shape == (80, 80) and _marks(img) == [(47, 19)]
+    img = O.extract_egocentric(data, org, res, (1., 1.5, -np.pi / 4), np.array([-3., -3.]), (7, 6))
+    assert img.shape == (120, 140) and _marks(img) == [(74, 46)]
+    # non-zero map origin (:161-176)
+    img = O.extract_egocentric(data, np.array([1.0, 2.0]), res, (3.5, 3.5, -np.pi / 4), np.array([-2., -2.]), (4, 4))
+    assert img.shape == (80, 80) and _marks(img) == [(33, 5)]
+
+
+def test_kat_extract_egocentric_binary_block(oracle):
+    """a 2x2 lethal block seen from a robot turned by -pi/4 is exactly these five pixels (:179-195)"""
+    data = np.zeros((100, 100), dtype=np.uint8)
+    data[30:32, 30:32] = 254
+    img = oracle.extract_egocentric(data, np.array([0., 0.]), 0.05, (1.5, 1.5, -np.pi / 4), np.array([-2.0, -2.0]),
+                                    (4., 4))
+    r, c = np.where(img != 0)
+    assert r.tolist() == [40, 41, 41, 41, 42] and c.tolist() == [40, 39, 40, 41, 40]
+    assert (img[r, c] == 254).all()
+
+
+def test_kat_rotate_costmap(oracle):
+    """rotate_costmap by -pi/4 moves the mark at (30, 30) of a 80 x 100 map to (29, 47) (:198-207)"""
+    data = np.zeros((80, 100), dtype=np.uint8)   # create_empty((5, 4), 0.05): 100 columns, 80 rows
+    data[30, 30] = 254
+    assert _marks(oracle.rotate_costmap(data, -np.pi / 4)) == [(29, 47)]
+    assert (oracle.rotate_costmap(data, 0.0) == data).all()
