@@ -1043,10 +1043,10 @@ struct EgoArgs {
     int32_t has_window;
     double win_ox, win_oy;
     int32_t drows, dcols;        // output shape
-    uint32_t div_cols;           // floor(2^32 / dcols) + 1: exact l / dcols for l * dcols < 2^32
     int32_t stage_map;           // shared map is copied to LDS (rows * cols bytes)
     int32_t border;
     int64_t n_envs;              // image i shows the costmap of env i % n_envs
+    int64_t n_images;
     uint8_t* out;                // [n][drows][dcols]
 };
 
@@ -1056,114 +1056,198 @@ __device__ __forceinline__ int sat_int(double v)   // cv::saturate_cast<int>(dou
     return r >= 2147483647.0 ? 2147483647 : (r <= -2147483648.0 ? (-2147483647 - 1) : (int)r);
 }
 
-// One workgroup per env.  LDS: [adelta, bdelta : dcols x 2 ints] [X0, Y0 : drows x 2 ints] [shared map bytes].
+// clamp(v, lo, hi) as ONE instruction (the compiler emits v_max + v_min for min(max()))
+__device__ __forceinline__ int clamp_med3(int v, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+
+// byte at a raw LDS address (no symbol base is added: the caller folds the base into the address)
+__device__ __forceinline__ uint32_t lds_byte_at(uint32_t addr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t) * (__attribute__((address_space(3))) const uint8_t*)addr;
+#else
+    (void)addr;
+    return 0;
+#endif
+}
+
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+// One WAVEFRONT per image, persistent workgroups of 4 waves that stage a shared costmap in LDS once and then walk
+// over images.
+//   * transforms: lane l of a wave prepares the (inverted) warp matrix of the wave's l-th image, so the float64
+//     sin / cos / inversion work is done once per image by one lane; the wave then takes the images one by one and
+//     broadcasts that lane's matrix (v_readlane -> scalar registers).
+//   * pixels: lane = (row mod 4, group of 8 consecutive columns).  The column terms of a lane's 8 pixels stay in
+//     registers, the per-row terms come from a small per-wave LDS table, and the 8 pixels leave as one 64-bit store
+//     (image rows are dcols bytes apart, so these stores are generally unaligned).
+//   * rows whose source segment lies entirely off the map are filled with the border value without sampling: the
+//     source coordinates are monotone in x, so it is enough to look at the row's two ends.
+//   * shared map: the LDS copy carries a one-cell ring of the border value and the source coordinates are clamped
+//     onto it (v_med3), so a pixel is add, add, shift, shift, clamp, clamp, multiply-add, LDS byte read, pack --
+//     no bounds compare and no select.  The ring offset and the LDS base address ride in the per-row terms.
+// LDS: [shared map + ring, dword padded] [4 waves x drows x {X0 (INT_MIN = row is off the map), Y0}]
+template <bool STAGED, int PX>
 __global__ void __launch_bounds__(256) ego_costmap_kernel(const EgoArgs a)
 {
-    const int64_t env = blockIdx.x;   // index of the image
-    const int tid = threadIdx.x;
-    const int64_t me = env % a.n_envs;
-    const int64_t g = a.shared ? 0 : (a.geom_of_env ? (int64_t)a.geom_of_env[me] : me);
-    double ox = a.ox, oy = a.oy;
-    if (a.origins) {
-        ox = a.origins[2 * g];
-        oy = a.origins[2 * g + 1];
-    }
-    double px, py, th;
-    if (a.poses) {
-        px = a.poses[3 * env];
-        py = a.poses[3 * env + 1];
-        th = a.poses[3 * env + 2];
-    } else {
-        px = a.sx[env];
-        py = a.sy[env];
-        th = a.sth[env];
-    }
-    // cv2.getRotationMatrix2D(world_to_pixel(pose), 180*theta/pi, 1): the centre is a Point2f
-    const float cx = (float)rint((px - ox) * a.inv_res), cy = (float)rint((py - oy) * a.inv_res);
-    const double angle = (180 * th / M_PI) * (M_PI / 180);
-    const double alpha = cos(angle), beta = sin(angle);
-    double M[6] = {alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy};
-    if (a.has_window) {
-        // shift so that the window origin lands on output pixel (0, 0); composed in float32 (costmap_utils.py:50-64)
-        const double dsx = rint((a.win_ox - (ox - px)) * a.inv_res), dsy = rint((a.win_oy - (oy - py)) * a.inv_res);
-        float t[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) t[k] = (float)M[k];
-        t[2] = t[2] + (-(float)dsx);
-        t[5] = t[5] + (-(float)dsy);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) M[k] = (double)t[k];
-    }
-    {   // cv::warpAffine inverts the transform in float64
-        double D = M[0] * M[4] - M[1] * M[3];
-        D = D != 0 ? 1. / D : 0;
-        const double A11 = M[4] * D, A22 = M[0] * D;
-        M[0] = A11;
-        M[1] *= -D;
-        M[3] *= -D;
-        M[4] = A22;
-        const double b1 = -M[0] * M[2] - M[1] * M[5];
-        const double b2 = -M[3] * M[2] - M[4] * M[5];
-        M[2] = b1;
-        M[5] = b2;
-    }
     typedef __attribute__((address_space(3))) int* LdsI32;
-    const LdsI32 col_tab = (LdsI32)lds_dyn;          // [dcols][2] = adelta, bdelta
-    const LdsI32 row_tab = col_tab + 2 * a.dcols;    // [drows][2] = X0, Y0 (rounding term included)
-    __attribute__((address_space(3))) uint8_t* lmap = (__attribute__((address_space(3))) uint8_t*)(row_tab + 2 * a.drows);
-    for (int x = tid; x < a.dcols; x += 256) {
-        col_tab[2 * x] = sat_int(M[0] * x * 1024);
-        col_tab[2 * x + 1] = sat_int(M[3] * x * 1024);
-    }
-    for (int y = tid; y < a.drows; y += 256) {
-        row_tab[2 * y] = sat_int((M[1] * y + M[2]) * 1024) + 512;
-        row_tab[2 * y + 1] = sat_int((M[4] * y + M[5]) * 1024) + 512;
-    }
-    const uint8_t* src = a.data + g * a.map_stride;
-    if (a.stage_map) {
-        const int words = (a.rows * a.cols + 3) / 4;   // (the allocation behind a costmap tensor is dword-padded)
-        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    typedef __attribute__((address_space(3))) uint8_t* LdsU8;
+    const int pitch = a.cols + 2;
+    const int map_bytes = STAGED ? (((a.rows + 2) * pitch + 3) & ~3) : 0;
+    const LdsU8 lmap = (LdsU8)lds_dyn;
+    const LdsI32 row_tab = (LdsI32)(lmap + map_bytes) + wave * (2 * a.drows);
+    constexpr int kRowOff = -2147483647 - 1;   // never a real X0: those are >= INT_MIN + 512
+    if (STAGED) {
+        const int vr0 = a.valid_rows ? a.valid_rows[0] : a.rows, vc0 = a.valid_cols ? a.valid_cols[0] : a.cols;
         __attribute__((address_space(3))) uint32_t* l32 = (__attribute__((address_space(3))) uint32_t*)lmap;
-        for (int k = tid; k < words; k += 256) l32[k] = s32[k];
+        for (int k = threadIdx.x; k < map_bytes / 4; k += 256) l32[k] = (uint32_t)a.border * 0x01010101u;
+        __syncthreads();
+        for (int r = wave; r < vr0; r += 4)
+            for (int c = lane; c < vc0; c += 64) lmap[(r + 1) * pitch + 1 + c] = a.data[(int64_t)r * a.cols + c];
+        __syncthreads();
     }
-    __syncthreads();
-    const int vrows = a.valid_rows ? a.valid_rows[g] : a.rows, vcols = a.valid_cols ? a.valid_cols[g] : a.cols;
+    // staged sampling: X' = X + x_shift and Y' = Y + 1 index the ringed copy directly (raw LDS byte address)
+    const int x_shift = 1 + (int)(uint32_t)(uintptr_t)lmap;
+    constexpr int kGroups = 128 / PX, kRows = 64 / kGroups;   // lanes of a wave: kRows image rows x kGroups pixel groups
+    const int cg = lane % kGroups, rl = lane / kGroups;
     const int64_t P = (int64_t)a.drows * a.dcols;
-    const int64_t B = env * P;                       // byte offset of this env's image in `out`
-    const int64_t w0 = B >> 2, w1 = (B + P - 1) >> 2;  // aligned dwords that hold at least one of its bytes
-    for (int64_t w = w0 + tid; w <= w1; w += 256) {
-        const int64_t l0 = 4 * w - B;                // image-local index of the dword's first byte (may be < 0)
-        int l = (int)(l0 < 0 ? 0 : l0);
-        int y = (int)__umulhi((uint32_t)l, a.div_cols), x = l - y * a.dcols;
-        int yy = y < a.drows ? y : 0;
-        int rx = row_tab[2 * yy], ry = row_tab[2 * yy + 1];
-        uint32_t packed = 0;
-        uint32_t have = 0;
+    const uint32_t border = (uint32_t)a.border;
+    const uint64_t border8 = (uint64_t)border * 0x0101010101010101ull;
+    const int64_t first = (int64_t)blockIdx.x * 4 + wave, stride = (int64_t)gridDim.x * 4;
+    for (int64_t base = first; base < a.n_images; base += 64 * stride) {
+        // ---- lane l: transform of image base + l * stride
+        double M[6] = {0, 0, 0, 0, 0, 0};
+        int vrows = 0, vcols = 0, g_lo = 0, g_hi = 0;
+        const int64_t mine = base + lane * stride;
+        if (mine < a.n_images) {
+            const int64_t me = mine % a.n_envs;
+            const int64_t g = a.shared ? 0 : (a.geom_of_env ? (int64_t)a.geom_of_env[me] : me);
+            double ox = a.ox, oy = a.oy;
+            if (a.origins) {
+                ox = a.origins[2 * g];
+                oy = a.origins[2 * g + 1];
+            }
+            double px, py, th;
+            if (a.poses) {
+                px = a.poses[3 * mine];
+                py = a.poses[3 * mine + 1];
+                th = a.poses[3 * mine + 2];
+            } else {
+                px = a.sx[mine];
+                py = a.sy[mine];
+                th = a.sth[mine];
+            }
+            // cv2.getRotationMatrix2D(world_to_pixel(pose), 180*theta/pi, 1): the centre is a Point2f
+            const float cx = (float)rint((px - ox) * a.inv_res), cy = (float)rint((py - oy) * a.inv_res);
+            const double angle = (180 * th / M_PI) * (M_PI / 180);
+            const double alpha = cos(angle), beta = sin(angle);
+            M[0] = alpha;
+            M[1] = beta;
+            M[2] = (1 - alpha) * cx - beta * cy;
+            M[3] = -beta;
+            M[4] = alpha;
+            M[5] = beta * cx + (1 - alpha) * cy;
+            if (a.has_window) {
+                // shift so that the window origin lands on output pixel (0, 0); composed in float32
+                // (costmap_utils.py:50-64)
+                const double dsx = rint((a.win_ox - (ox - px)) * a.inv_res), dsy = rint((a.win_oy - (oy - py)) * a.inv_res);
+                float t[6];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t lj = l0 + j;
-            if (lj >= 0 && lj < P) {
-                const int X = (rx + col_tab[2 * x]) >> 10, Y = (ry + col_tab[2 * x + 1]) >> 10;  // (saturate_cast<short> never bites:
-                uint32_t v = (uint32_t)a.border;                              //  |X|, |Y| < 2^21 and maps are < 2^15)
-                if ((unsigned)X < (unsigned)vcols && (unsigned)Y < (unsigned)vrows)
-                    v = a.stage_map ? (uint32_t)lmap[Y * a.cols + X] : (uint32_t)src[(int64_t)Y * a.cols + X];
-                packed |= v << (8 * j);
-                have |= 1u << j;
-                if (++x == a.dcols) {
-                    x = 0;
-                    ++y;
-                    yy = y < a.drows ? y : 0;
-                    rx = row_tab[2 * yy];
-                    ry = row_tab[2 * yy + 1];
+                for (int k = 0; k < 6; ++k) t[k] = (float)M[k];
+                t[2] = t[2] + (-(float)dsx);
+                t[5] = t[5] + (-(float)dsy);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) M[k] = (double)t[k];
+            }
+            {   // cv::warpAffine inverts the transform in float64
+                double D = M[0] * M[4] - M[1] * M[3];
+                D = D != 0 ? 1. / D : 0;
+                const double A11 = M[4] * D, A22 = M[0] * D;
+                M[0] = A11;
+                M[1] *= -D;
+                M[3] *= -D;
+                M[4] = A22;
+                const double b1 = -M[0] * M[2] - M[1] * M[5];
+                const double b2 = -M[3] * M[2] - M[4] * M[5];
+                M[2] = b1;
+                M[5] = b2;
+            }
+            vrows = a.valid_rows ? a.valid_rows[g] : a.rows;
+            vcols = a.valid_cols ? a.valid_cols[g] : a.cols;
+            g_lo = (int)(uint32_t)g;
+            g_hi = (int)(g >> 32);
+        }
+        const int64_t left = (a.n_images - base + stride - 1) / stride;
+        const int count = (int)(left < 64 ? left : 64);
+        // ---- the wave's images, one at a time
+        for (int k = 0; k < count; ++k) {
+            const int64_t img = base + k * stride;
+            const double m0 = bcast_d(M[0], k), m1 = bcast_d(M[1], k), m2 = bcast_d(M[2], k);
+            const double m3 = bcast_d(M[3], k), m4 = bcast_d(M[4], k), m5 = bcast_d(M[5], k);
+            const int vr = bcast_i(vrows, k), vc = bcast_i(vcols, k);
+            const int64_t g = ((int64_t)bcast_i(g_hi, k) << 32) | (uint32_t)bcast_i(g_lo, k);
+            const uint8_t* src = a.data + g * a.map_stride;
+            const int x_lo = x_shift - 1, x_hi = x_shift + vc, y_lo = 0, y_hi = vr + 1;   // ring coordinates (staged sampling)
+            // per-row terms (rounding term included) and the off-map flag of the row
+            const int last_cx = sat_int(m0 * (a.dcols - 1) * 1024), last_cy = sat_int(m3 * (a.dcols - 1) * 1024);
+            for (int y = lane; y < a.drows; y += 64) {
+                const int rx = sat_int((m1 * y + m2) * 1024) + 512, ry = sat_int((m4 * y + m5) * 1024) + 512;
+                const int xa = rx >> 10, xb = (rx + last_cx) >> 10, ya = ry >> 10, yb = (ry + last_cy) >> 10;
+                const bool off = (xa < 0 && xb < 0) || (xa >= vc && xb >= vc) || (ya < 0 && yb < 0) || (ya >= vr && yb >= vr);
+                row_tab[2 * y] = off ? kRowOff : (STAGED ? rx + x_shift * 1024 : rx);
+                row_tab[2 * y + 1] = STAGED ? ry + 1024 : ry;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint8_t* const image = a.out + img * P;
+            // pixel groups of PX columns; the last group of a row is shifted left so that it ends at the last column
+            // (it recomputes a few pixels of its neighbour instead of needing a narrower store)
+            for (int xg = PX * cg; xg < a.dcols; xg += 128) {
+                const int x0 = min(xg, a.dcols - PX);
+                int ccx[PX], ccy[PX];
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {   // cv::hal::warpAffine's adelta / bdelta for this lane's columns
+                    ccx[j] = sat_int(m0 * (x0 + j) * 1024);
+                    ccy[j] = sat_int(m3 * (x0 + j) * 1024);
+                }
+                for (int y = rl; y < a.drows; y += kRows) {
+                    const int rx = row_tab[2 * y], ry = row_tab[2 * y + 1];
+                    uint64_t packed = border8;
+                    if (rx != kRowOff) {
+                        uint32_t half[2] = {0, 0};
+#pragma unroll
+                        for (int j = 0; j < PX; ++j) {
+                            // (saturate_cast<short> never bites: |X|, |Y| < 2^21 and maps are < 2^15)
+                            const int X = (rx + ccx[j]) >> 10, Y = (ry + ccy[j]) >> 10;
+                            uint32_t val;
+                            if (STAGED) {   // clamp onto the border ring of the LDS copy: every address is valid
+                                const int xc = clamp_med3(X, x_lo, x_hi), yc = clamp_med3(Y, y_lo, y_hi);
+                                val = lds_byte_at((uint32_t)(__mul24(yc, pitch) + xc));
+                            } else {        // global gather: only the in-map lanes issue a load
+                                val = border;
+                                if ((unsigned)X < (unsigned)vc && (unsigned)Y < (unsigned)vr)
+                                    val = (uint32_t)src[(uint32_t)__mul24(Y, a.cols) + (uint32_t)X];
+                            }
+                            half[j >> 2] |= val << (8 * (j & 3));
+                        }
+                        packed = ((uint64_t)half[1] << 32) | half[0];
+                    }
+                    uint8_t* const p = image + (int64_t)y * a.dcols + x0;
+                    if (PX == 8)
+                        *reinterpret_cast<u64_unaligned*>(p) = packed;
+                    else
+                        *reinterpret_cast<u32_unaligned*>(p) = (uint32_t)packed;
                 }
             }
-        }
-        if (have == 0xFu) {
-            reinterpret_cast<uint32_t*>(a.out)[w] = packed;
-        } else {  // first / last dword of the image: shared with the neighbouring env's image
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (have & (1u << j)) a.out[4 * w + j] = (uint8_t)(packed >> (8 * j));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the table is rewritten for the next image
         }
     }
 }
@@ -1924,15 +2008,32 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
         a.win_ox = window_origin[0];
         a.win_oy = window_origin[1];
     }
-    a.div_cols = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)a.dcols) + 1;
-    const size_t tab_bytes = (size_t)(a.dcols + a.drows) * 2 * sizeof(int32_t);
-    const size_t map_bytes = ((size_t)a.rows * a.cols + 3) & ~(size_t)3;
+    const size_t map_bytes = ((size_t)(a.rows + 2) * (a.cols + 2) + 3) & ~(size_t)3;   // LDS copy with a border ring
+    const size_t tab_bytes = (size_t)4 * a.drows * 2 * sizeof(int32_t);
     a.stage_map = (a.shared && tab_bytes + map_bytes <= 60 * 1024) ? 1 : 0;
     a.border = border_value;
     a.out = out;
     a.n_envs = h->n;
-    hipLaunchKernelGGL(ego_costmap_kernel, dim3((unsigned)n), dim3(256), tab_bytes + (a.stage_map ? map_bytes : 0),
-                       (hipStream_t)stream, a);
+    a.n_images = n;
+    // persistent workgroups: as many as are resident at once (LDS footprint and registers decide), no more
+    const size_t lds = tab_bytes + (a.stage_map ? map_bytes : 0);
+    const bool px8 = a.dcols >= 8;   // 8 pixels (one 64-bit store) per lane; narrow windows fall back to 4
+    if (a.dcols < 4) return fail(BCP_E_INVALID, "bcp_egocentric_costmaps: windows narrower than 4 px are not supported");
+    const void* fn = a.stage_map ? (px8 ? (const void*)ego_costmap_kernel<true, 8> : (const void*)ego_costmap_kernel<true, 4>)
+                                 : (px8 ? (const void*)ego_costmap_kernel<false, 8> : (const void*)ego_costmap_kernel<false, 4>);
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    const int64_t groups = std::min<int64_t>((n + 3) / 4, (int64_t)std::max(per_cu, 1) * std::max(cus, 1));
+    const dim3 grid((unsigned)groups), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.stage_map) {
+        if (px8) hipLaunchKernelGGL((ego_costmap_kernel<true, 8>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((ego_costmap_kernel<true, 4>), grid, block, lds, st, a);
+    } else {
+        if (px8) hipLaunchKernelGGL((ego_costmap_kernel<false, 8>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((ego_costmap_kernel<false, 4>), grid, block, lds, st, a);
+    }
     HIP_TRY(hipGetLastError());
     return BCP_OK;
 }
