@@ -143,6 +143,10 @@ struct bcp_handle {
     int32_t dense_threshold;  // auto: more ambiguous lanes than this in a wave -> per-thread rasteriser
     int32_t cull_enabled;
     int32_t wide;             // kernel image may exceed 96 px: 8-word row masks in the cooperative path
+    int32_t* ego_bins;        // owned: [2][bins] image counts / first slots per map entry (egocentric views)
+    int64_t ego_bins_cap;
+    int32_t* ego_order;       // owned: [2][images] rank within the bin / images grouped by map entry
+    int64_t ego_order_cap;
     const uint8_t* map_data;  // caller-owned raw costmap(s) as given to bcp_set_costmaps (egocentric views read them)
     const int32_t* map_valid_rows;
     const int32_t* map_valid_cols;
@@ -1043,6 +1047,7 @@ struct EgoArgs {
     int32_t has_window;
     double win_ox, win_oy;
     int32_t drows, dcols;        // output shape
+    uint32_t cols_magic;         // floor(2^32 / cols) + 1: idx / cols == umulhi(idx, magic) for idx * cols < 2^32
     int32_t stage_map;           // shared map is copied to LDS (rows * cols bytes)
     int32_t border;
     int64_t n_envs;              // image i shows the costmap of env i % n_envs
@@ -1078,6 +1083,210 @@ __device__ __forceinline__ uint32_t lds_byte_at(uint32_t addr)
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
+// ---- building blocks ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) int* LdsI32;
+typedef __attribute__((address_space(3))) uint8_t* LdsU8;
+constexpr int kRowOff = -2147483647 - 1;   // row-table X0 of a row that lies off the map (real X0 are >= INT_MIN + 512)
+
+struct EgoXform {
+    double M[6];   // dst -> src, as cv::warpAffine uses it
+    int vrows, vcols;
+    int g_lo, g_hi;   // map entry
+};
+
+// cv2.getRotationMatrix2D(world_to_pixel(pose), 180*theta/pi, 1), the window shift, and warpAffine's inversion
+__device__ __forceinline__ EgoXform ego_transform(const EgoArgs& a, int64_t img)
+{
+    EgoXform T;
+    const int64_t me = img % a.n_envs;
+    const int64_t g = a.shared ? 0 : (a.geom_of_env ? (int64_t)a.geom_of_env[me] : me);
+    double ox = a.ox, oy = a.oy;
+    if (a.origins) {
+        ox = a.origins[2 * g];
+        oy = a.origins[2 * g + 1];
+    }
+    double px, py, th;
+    if (a.poses) {
+        px = a.poses[3 * img];
+        py = a.poses[3 * img + 1];
+        th = a.poses[3 * img + 2];
+    } else {
+        px = a.sx[img];
+        py = a.sy[img];
+        th = a.sth[img];
+    }
+    double* M = T.M;
+    const float cx = (float)rint((px - ox) * a.inv_res), cy = (float)rint((py - oy) * a.inv_res);   // Point2f centre
+    const double angle = (180 * th / M_PI) * (M_PI / 180);
+    const double alpha = cos(angle), beta = sin(angle);
+    M[0] = alpha;
+    M[1] = beta;
+    M[2] = (1 - alpha) * cx - beta * cy;
+    M[3] = -beta;
+    M[4] = alpha;
+    M[5] = beta * cx + (1 - alpha) * cy;
+    if (a.has_window) {
+        // shift so that the window origin lands on output pixel (0, 0); composed in float32 (costmap_utils.py:50-64)
+        const double dsx = rint((a.win_ox - (ox - px)) * a.inv_res), dsy = rint((a.win_oy - (oy - py)) * a.inv_res);
+        float t[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = (float)M[k];
+        t[2] = t[2] + (-(float)dsx);
+        t[5] = t[5] + (-(float)dsy);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) M[k] = (double)t[k];
+    }
+    {   // cv::warpAffine inverts the transform in float64
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0 ? 1. / D : 0;
+        const double A11 = M[4] * D, A22 = M[0] * D;
+        M[0] = A11;
+        M[1] *= -D;
+        M[3] *= -D;
+        M[4] = A22;
+        const double b1 = -M[0] * M[2] - M[1] * M[5];
+        const double b2 = -M[3] * M[2] - M[4] * M[5];
+        M[2] = b1;
+        M[5] = b2;
+    }
+    T.vrows = a.valid_rows ? a.valid_rows[g] : a.rows;
+    T.vcols = a.valid_cols ? a.valid_cols[g] : a.cols;
+    T.g_lo = (int)(uint32_t)g;
+    T.g_hi = (int)(g >> 32);
+    return T;
+}
+
+// lane k's transform, broadcast to the whole wave (scalar registers)
+struct EgoImage {
+    double m0, m1, m2, m3, m4, m5;
+    int vr, vc;
+    int64_t g;
+};
+
+__device__ __forceinline__ EgoImage ego_broadcast(const EgoXform& T, int k)
+{
+    EgoImage I;
+    I.m0 = bcast_d(T.M[0], k);
+    I.m1 = bcast_d(T.M[1], k);
+    I.m2 = bcast_d(T.M[2], k);
+    I.m3 = bcast_d(T.M[3], k);
+    I.m4 = bcast_d(T.M[4], k);
+    I.m5 = bcast_d(T.M[5], k);
+    I.vr = bcast_i(T.vrows, k);
+    I.vc = bcast_i(T.vcols, k);
+    I.g = ((int64_t)bcast_i(T.g_hi, k) << 32) | (uint32_t)bcast_i(T.g_lo, k);
+    return I;
+}
+
+// LDS copy of one costmap with a one-cell ring of the border value.  Whole workgroup; ends with a barrier.
+// The map is fetched as aligned dwords, eight independent loads in flight per thread (a cold map costs a few memory
+// round trips instead of one per row), and scattered into the ringed layout byte by byte.
+__device__ __forceinline__ void ego_stage_map(const EgoArgs& a, const uint8_t* __restrict__ src, int vr, int vc, LdsU8 lmap,
+                                              int pitch, int map_bytes)
+{
+    __attribute__((address_space(3))) uint32_t* l32 = (__attribute__((address_space(3))) uint32_t*)lmap;
+    for (int k = threadIdx.x; k < map_bytes / 4; k += 256) l32[k] = (uint32_t)a.border * 0x01010101u;
+    __syncthreads();
+    const int total = a.rows * a.cols;
+    const int off = (int)((uintptr_t)src & 3);   // the map entry need not start on a dword boundary
+    const uint32_t* __restrict__ w32 = reinterpret_cast<const uint32_t*>(src - off);
+    const int n_words = (off + total + 3) >> 2;
+    for (int w0 = threadIdx.x; w0 < n_words; w0 += 8 * 256) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int w = w0 + u * 256;
+            v[u] = w < n_words ? w32[w] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int w = w0 + u * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = 4 * w + j - off;                       // linear index into the map entry
+                if (idx >= 0 && idx < total) {
+                    const int r = (int)__umulhi((uint32_t)idx, a.cols_magic), c = idx - r * a.cols;
+                    if (r < vr && c < vc) lmap[(r + 1) * pitch + 1 + c] = (uint8_t)(v[u] >> (8 * j));
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// per-row terms of one image (rounding term included; staged sampling: ring offset and LDS base folded in) and the
+// off-map flag of each row, for rows t0, t0 + tstep, ...
+template <bool STAGED>
+__device__ __forceinline__ void ego_row_terms(const EgoArgs& a, const EgoImage& I, int x_shift, LdsI32 row_tab, int t0,
+                                              int tstep)
+{
+    const int last_cx = sat_int(I.m0 * (a.dcols - 1) * 1024), last_cy = sat_int(I.m3 * (a.dcols - 1) * 1024);
+    for (int y = t0; y < a.drows; y += tstep) {
+        const int rx = sat_int((I.m1 * y + I.m2) * 1024) + 512, ry = sat_int((I.m4 * y + I.m5) * 1024) + 512;
+        const int xa = rx >> 10, xb = (rx + last_cx) >> 10, ya = ry >> 10, yb = (ry + last_cy) >> 10;
+        const bool off = (xa < 0 && xb < 0) || (xa >= I.vc && xb >= I.vc) || (ya < 0 && yb < 0) || (ya >= I.vr && yb >= I.vr);
+        row_tab[2 * y] = off ? kRowOff : (STAGED ? rx + x_shift * 1024 : rx);
+        row_tab[2 * y + 1] = STAGED ? ry + 1024 : ry;
+    }
+}
+
+// the pixels of rows r0, r0 + rstep, ... for this lane's column groups.  Pixel groups are PX columns wide; the last
+// group of a row is shifted left so that it ends at the last column (it recomputes a few pixels of its neighbour
+// instead of needing a narrower store).
+template <bool STAGED, int PX>
+__device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, int x_shift, int pitch,
+                                           const uint8_t* __restrict__ src, LdsI32 row_tab, uint8_t* __restrict__ image,
+                                           int cg, int r0, int rstep)
+{
+    const uint32_t border = (uint32_t)a.border;
+    const uint64_t border8 = (uint64_t)border * 0x0101010101010101ull;
+    const int x_lo = x_shift - 1, x_hi = x_shift + I.vc, y_lo = 0, y_hi = I.vr + 1;   // ring coordinates (staged sampling)
+    for (int xg = PX * cg; xg < a.dcols; xg += 128) {
+        const int x0 = min(xg, a.dcols - PX);
+        int ccx[PX], ccy[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {   // cv::hal::warpAffine's adelta / bdelta for this lane's columns
+            ccx[j] = sat_int(I.m0 * (x0 + j) * 1024);
+            ccy[j] = sat_int(I.m3 * (x0 + j) * 1024);
+        }
+        for (int y = r0; y < a.drows; y += rstep) {
+            const int rx = row_tab[2 * y], ry = row_tab[2 * y + 1];
+            uint64_t packed = border8;
+            if (rx != kRowOff) {
+                uint32_t half[2] = {0, 0};
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    // (saturate_cast<short> never bites: |X|, |Y| < 2^21 and maps are < 2^15)
+                    const int X = (rx + ccx[j]) >> 10, Y = (ry + ccy[j]) >> 10;
+                    uint32_t val;
+                    if (STAGED) {   // clamp onto the border ring of the LDS copy: every address is valid
+                        const int xc = clamp_med3(X, x_lo, x_hi), yc = clamp_med3(Y, y_lo, y_hi);
+                        val = lds_byte_at((uint32_t)(__mul24(yc, pitch) + xc));
+                    } else {        // global gather: only the in-map lanes issue a load
+                        val = border;
+                        if ((unsigned)X < (unsigned)I.vc && (unsigned)Y < (unsigned)I.vr)
+                            val = (uint32_t)src[(uint32_t)__mul24(Y, a.cols) + (uint32_t)X];
+                    }
+                    half[j >> 2] |= val << (8 * (j & 3));
+                }
+                packed = ((uint64_t)half[1] << 32) | half[0];
+            }
+            uint8_t* const p = image + (int64_t)y * a.dcols + x0;
+            if (PX == 8)
+                *reinterpret_cast<u64_unaligned*>(p) = packed;
+            else
+                *reinterpret_cast<u32_unaligned*>(p) = (uint32_t)packed;
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // One WAVEFRONT per image, persistent workgroups of 4 waves that stage a shared costmap in LDS once and then walk
 // over images.
 //   * transforms: lane l of a wave prepares the (inverted) warp matrix of the wave's l-th image, so the float64
@@ -1091,165 +1300,162 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 //   * shared map: the LDS copy carries a one-cell ring of the border value and the source coordinates are clamped
 //     onto it (v_med3), so a pixel is add, add, shift, shift, clamp, clamp, multiply-add, LDS byte read, pack --
 //     no bounds compare and no select.  The ring offset and the LDS base address ride in the per-row terms.
-// LDS: [shared map + ring, dword padded] [4 waves x drows x {X0 (INT_MIN = row is off the map), Y0}]
+// LDS: [shared map + ring, dword padded] [4 waves x drows x {X0 (kRowOff = row is off the map), Y0}]
+// STAGED = false: maps that do not fit LDS are sampled straight from global memory.
 template <bool STAGED, int PX>
 __global__ void __launch_bounds__(256) ego_costmap_kernel(const EgoArgs a)
 {
-    typedef __attribute__((address_space(3))) int* LdsI32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    typedef __attribute__((address_space(3))) uint8_t* LdsU8;
     const int pitch = a.cols + 2;
     const int map_bytes = STAGED ? (((a.rows + 2) * pitch + 3) & ~3) : 0;
     const LdsU8 lmap = (LdsU8)lds_dyn;
     const LdsI32 row_tab = (LdsI32)(lmap + map_bytes) + wave * (2 * a.drows);
-    constexpr int kRowOff = -2147483647 - 1;   // never a real X0: those are >= INT_MIN + 512
-    if (STAGED) {
-        const int vr0 = a.valid_rows ? a.valid_rows[0] : a.rows, vc0 = a.valid_cols ? a.valid_cols[0] : a.cols;
-        __attribute__((address_space(3))) uint32_t* l32 = (__attribute__((address_space(3))) uint32_t*)lmap;
-        for (int k = threadIdx.x; k < map_bytes / 4; k += 256) l32[k] = (uint32_t)a.border * 0x01010101u;
-        __syncthreads();
-        for (int r = wave; r < vr0; r += 4)
-            for (int c = lane; c < vc0; c += 64) lmap[(r + 1) * pitch + 1 + c] = a.data[(int64_t)r * a.cols + c];
-        __syncthreads();
-    }
+    if (STAGED)
+        ego_stage_map(a, a.data, a.valid_rows ? a.valid_rows[0] : a.rows, a.valid_cols ? a.valid_cols[0] : a.cols, lmap,
+                      pitch, map_bytes);
     // staged sampling: X' = X + x_shift and Y' = Y + 1 index the ringed copy directly (raw LDS byte address)
     const int x_shift = 1 + (int)(uint32_t)(uintptr_t)lmap;
     constexpr int kGroups = 128 / PX, kRows = 64 / kGroups;   // lanes of a wave: kRows image rows x kGroups pixel groups
     const int cg = lane % kGroups, rl = lane / kGroups;
     const int64_t P = (int64_t)a.drows * a.dcols;
-    const uint32_t border = (uint32_t)a.border;
-    const uint64_t border8 = (uint64_t)border * 0x0101010101010101ull;
     const int64_t first = (int64_t)blockIdx.x * 4 + wave, stride = (int64_t)gridDim.x * 4;
     for (int64_t base = first; base < a.n_images; base += 64 * stride) {
-        // ---- lane l: transform of image base + l * stride
-        double M[6] = {0, 0, 0, 0, 0, 0};
-        int vrows = 0, vcols = 0, g_lo = 0, g_hi = 0;
-        const int64_t mine = base + lane * stride;
-        if (mine < a.n_images) {
-            const int64_t me = mine % a.n_envs;
-            const int64_t g = a.shared ? 0 : (a.geom_of_env ? (int64_t)a.geom_of_env[me] : me);
-            double ox = a.ox, oy = a.oy;
-            if (a.origins) {
-                ox = a.origins[2 * g];
-                oy = a.origins[2 * g + 1];
-            }
-            double px, py, th;
-            if (a.poses) {
-                px = a.poses[3 * mine];
-                py = a.poses[3 * mine + 1];
-                th = a.poses[3 * mine + 2];
-            } else {
-                px = a.sx[mine];
-                py = a.sy[mine];
-                th = a.sth[mine];
-            }
-            // cv2.getRotationMatrix2D(world_to_pixel(pose), 180*theta/pi, 1): the centre is a Point2f
-            const float cx = (float)rint((px - ox) * a.inv_res), cy = (float)rint((py - oy) * a.inv_res);
-            const double angle = (180 * th / M_PI) * (M_PI / 180);
-            const double alpha = cos(angle), beta = sin(angle);
-            M[0] = alpha;
-            M[1] = beta;
-            M[2] = (1 - alpha) * cx - beta * cy;
-            M[3] = -beta;
-            M[4] = alpha;
-            M[5] = beta * cx + (1 - alpha) * cy;
-            if (a.has_window) {
-                // shift so that the window origin lands on output pixel (0, 0); composed in float32
-                // (costmap_utils.py:50-64)
-                const double dsx = rint((a.win_ox - (ox - px)) * a.inv_res), dsy = rint((a.win_oy - (oy - py)) * a.inv_res);
-                float t[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) t[k] = (float)M[k];
-                t[2] = t[2] + (-(float)dsx);
-                t[5] = t[5] + (-(float)dsy);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) M[k] = (double)t[k];
-            }
-            {   // cv::warpAffine inverts the transform in float64
-                double D = M[0] * M[4] - M[1] * M[3];
-                D = D != 0 ? 1. / D : 0;
-                const double A11 = M[4] * D, A22 = M[0] * D;
-                M[0] = A11;
-                M[1] *= -D;
-                M[3] *= -D;
-                M[4] = A22;
-                const double b1 = -M[0] * M[2] - M[1] * M[5];
-                const double b2 = -M[3] * M[2] - M[4] * M[5];
-                M[2] = b1;
-                M[5] = b2;
-            }
-            vrows = a.valid_rows ? a.valid_rows[g] : a.rows;
-            vcols = a.valid_cols ? a.valid_cols[g] : a.cols;
-            g_lo = (int)(uint32_t)g;
-            g_hi = (int)(g >> 32);
-        }
+        EgoXform T;
+        memset(&T, 0, sizeof(T));
+        const int64_t mine = base + lane * stride;   // lane l: transform of the wave's l-th image of this batch
+        if (mine < a.n_images) T = ego_transform(a, mine);
         const int64_t left = (a.n_images - base + stride - 1) / stride;
         const int count = (int)(left < 64 ? left : 64);
-        // ---- the wave's images, one at a time
-        for (int k = 0; k < count; ++k) {
+        for (int k = 0; k < count; ++k) {            // the wave's images, one at a time
             const int64_t img = base + k * stride;
-            const double m0 = bcast_d(M[0], k), m1 = bcast_d(M[1], k), m2 = bcast_d(M[2], k);
-            const double m3 = bcast_d(M[3], k), m4 = bcast_d(M[4], k), m5 = bcast_d(M[5], k);
-            const int vr = bcast_i(vrows, k), vc = bcast_i(vcols, k);
-            const int64_t g = ((int64_t)bcast_i(g_hi, k) << 32) | (uint32_t)bcast_i(g_lo, k);
-            const uint8_t* src = a.data + g * a.map_stride;
-            const int x_lo = x_shift - 1, x_hi = x_shift + vc, y_lo = 0, y_hi = vr + 1;   // ring coordinates (staged sampling)
-            // per-row terms (rounding term included) and the off-map flag of the row
-            const int last_cx = sat_int(m0 * (a.dcols - 1) * 1024), last_cy = sat_int(m3 * (a.dcols - 1) * 1024);
-            for (int y = lane; y < a.drows; y += 64) {
-                const int rx = sat_int((m1 * y + m2) * 1024) + 512, ry = sat_int((m4 * y + m5) * 1024) + 512;
-                const int xa = rx >> 10, xb = (rx + last_cx) >> 10, ya = ry >> 10, yb = (ry + last_cy) >> 10;
-                const bool off = (xa < 0 && xb < 0) || (xa >= vc && xb >= vc) || (ya < 0 && yb < 0) || (ya >= vr && yb >= vr);
-                row_tab[2 * y] = off ? kRowOff : (STAGED ? rx + x_shift * 1024 : rx);
-                row_tab[2 * y + 1] = STAGED ? ry + 1024 : ry;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint8_t* const image = a.out + img * P;
-            // pixel groups of PX columns; the last group of a row is shifted left so that it ends at the last column
-            // (it recomputes a few pixels of its neighbour instead of needing a narrower store)
-            for (int xg = PX * cg; xg < a.dcols; xg += 128) {
-                const int x0 = min(xg, a.dcols - PX);
-                int ccx[PX], ccy[PX];
-#pragma unroll
-                for (int j = 0; j < PX; ++j) {   // cv::hal::warpAffine's adelta / bdelta for this lane's columns
-                    ccx[j] = sat_int(m0 * (x0 + j) * 1024);
-                    ccy[j] = sat_int(m3 * (x0 + j) * 1024);
-                }
-                for (int y = rl; y < a.drows; y += kRows) {
-                    const int rx = row_tab[2 * y], ry = row_tab[2 * y + 1];
-                    uint64_t packed = border8;
-                    if (rx != kRowOff) {
-                        uint32_t half[2] = {0, 0};
-#pragma unroll
-                        for (int j = 0; j < PX; ++j) {
-                            // (saturate_cast<short> never bites: |X|, |Y| < 2^21 and maps are < 2^15)
-                            const int X = (rx + ccx[j]) >> 10, Y = (ry + ccy[j]) >> 10;
-                            uint32_t val;
-                            if (STAGED) {   // clamp onto the border ring of the LDS copy: every address is valid
-                                const int xc = clamp_med3(X, x_lo, x_hi), yc = clamp_med3(Y, y_lo, y_hi);
-                                val = lds_byte_at((uint32_t)(__mul24(yc, pitch) + xc));
-                            } else {        // global gather: only the in-map lanes issue a load
-                                val = border;
-                                if ((unsigned)X < (unsigned)vc && (unsigned)Y < (unsigned)vr)
-                                    val = (uint32_t)src[(uint32_t)__mul24(Y, a.cols) + (uint32_t)X];
-                            }
-                            half[j >> 2] |= val << (8 * (j & 3));
-                        }
-                        packed = ((uint64_t)half[1] << 32) | half[0];
-                    }
-                    uint8_t* const p = image + (int64_t)y * a.dcols + x0;
-                    if (PX == 8)
-                        *reinterpret_cast<u64_unaligned*>(p) = packed;
-                    else
-                        *reinterpret_cast<u32_unaligned*>(p) = (uint32_t)packed;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();   // the table is rewritten for the next image
+            const EgoImage I = ego_broadcast(T, k);
+            ego_row_terms<STAGED>(a, I, x_shift, row_tab, lane, 64);
+            wave_lds_sync();
+            ego_pixels<STAGED, PX>(a, I, x_shift, pitch, a.data + I.g * a.map_stride, row_tab, a.out + img * P, cg, rl, kRows);
+            wave_lds_sync();   // the table is rewritten for the next image
         }
     }
+}
+
+// Private / pooled costmaps that fit LDS: images are first grouped by map entry (ego_bin_* kernels below); every
+// workgroup then takes an equal slice of that grouped list and walks through it run by run (a run = consecutive
+// images of one map entry): stage the entry (with the border ring), produce the run's images four at a time, one per
+// wavefront exactly like the shared-map kernel, and let the 4 waves share each of the up to three left-over images --
+// wave w takes every 4th slice of rows -- so that nobody idles (private maps: every run is a single image).
+// LDS: [map + ring] [4 row tables].
+template <int PX>
+__global__ void __launch_bounds__(256) ego_costmap_binned_kernel(const EgoArgs a, const int32_t* __restrict__ bin_start,
+                                                                 const int32_t* __restrict__ bin_count,
+                                                                 const int32_t* __restrict__ order)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pitch = a.cols + 2;
+    const int map_bytes = ((a.rows + 2) * pitch + 3) & ~3;
+    const LdsU8 lmap = (LdsU8)lds_dyn;
+    const LdsI32 tables = (LdsI32)(lmap + map_bytes);
+    const LdsI32 wave_tab = tables + wave * (2 * a.drows);
+    const int x_shift = 1 + (int)(uint32_t)(uintptr_t)lmap;
+    constexpr int kGroups = 128 / PX, kRows = 64 / kGroups;
+    const int cg = lane % kGroups, rl = lane / kGroups;
+    const int64_t P = (int64_t)a.drows * a.dcols;
+    const int64_t chunk = (a.n_images + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = blockIdx.x * chunk, hi = min(lo + chunk, a.n_images);
+    for (int64_t pos = lo; pos < hi;) {
+        const int64_t me = (int64_t)order[pos] % a.n_envs;
+        const int64_t g = a.geom_of_env ? (int64_t)a.geom_of_env[me] : me;
+        const int64_t run_end = min(hi, (int64_t)bin_start[g] + bin_count[g]);
+        const int run = (int)(run_end - pos);   // (uniform over the workgroup)
+        __syncthreads();                        // everyone is done with the previous map
+        ego_stage_map(a, a.data + g * a.map_stride, a.valid_rows ? a.valid_rows[g] : a.rows,
+                      a.valid_cols ? a.valid_cols[g] : a.cols, lmap, pitch, map_bytes);
+        const int whole = run & ~3;
+        // ---- one image per wavefront: wave w takes the run's images w, w + 4, ...; lane l prepares the l-th of them
+        for (int base = wave; base < whole; base += 256) {
+            EgoXform T;
+            memset(&T, 0, sizeof(T));
+            int my_img = 0;
+            if (base + 4 * lane < whole) {
+                my_img = order[pos + base + 4 * lane];
+                T = ego_transform(a, my_img);
+            }
+            const int batch = min(64, (whole - base + 3) / 4);
+            for (int k = 0; k < batch; ++k) {
+                const int64_t img = (uint32_t)bcast_i(my_img, k);
+                const EgoImage I = ego_broadcast(T, k);
+                ego_row_terms<true>(a, I, x_shift, wave_tab, lane, 64);
+                wave_lds_sync();
+                ego_pixels<true, PX>(a, I, x_shift, pitch, nullptr, wave_tab, a.out + img * P, cg, rl, kRows);
+                wave_lds_sync();
+            }
+        }
+        // ---- the left-over images: the four waves share each of them (one row table, two barriers per image)
+        if (run > whole) {
+            int my_img = 0;
+            EgoXform T;
+            memset(&T, 0, sizeof(T));
+            if (whole + lane < run) {
+                my_img = order[pos + whole + lane];
+                T = ego_transform(a, my_img);
+            }
+            for (int k = 0; k < run - whole; ++k) {
+                const int64_t img = (uint32_t)bcast_i(my_img, k);
+                const EgoImage I = ego_broadcast(T, k);
+                __syncthreads();   // the table is free (earlier images are finished)
+                ego_row_terms<true>(a, I, x_shift, tables, threadIdx.x, 256);
+                __syncthreads();
+                ego_pixels<true, PX>(a, I, x_shift, pitch, nullptr, tables, a.out + img * P, cg, wave * kRows + rl, 4 * kRows);
+            }
+        }
+        pos = run_end;
+    }
+}
+
+// ---- grouping images by map entry: count -> exclusive scan -> scatter ------------------------------------------
+__global__ void ego_bin_count_kernel(const int32_t* __restrict__ geom_of_env, int64_t n_envs, int64_t n_images,
+                                     int32_t* __restrict__ bin_count, int32_t* __restrict__ rank)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_images) return;
+    const int64_t me = i % n_envs;
+    const int64_t g = geom_of_env ? (int64_t)geom_of_env[me] : me;
+    rank[i] = atomicAdd(bin_count + g, 1);
+}
+
+__global__ void __launch_bounds__(1024) ego_bin_scan_kernel(const int32_t* __restrict__ bin_count, int64_t n_bins,
+                                                            int32_t* __restrict__ bin_start)
+{
+    __shared__ int32_t part[1024];
+    __shared__ int32_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_bins; base += 1024) {
+        const int64_t i = base + tid;
+        const int32_t v = i < n_bins ? bin_count[i] : 0;
+        part[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan
+            const int32_t t = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += t;
+            __syncthreads();
+        }
+        if (i < n_bins) bin_start[i] = carry + part[tid] - v;
+        __syncthreads();
+        if (tid == 1023) carry += part[1023];
+        __syncthreads();
+    }
+}
+
+__global__ void ego_bin_scatter_kernel(const int32_t* __restrict__ geom_of_env, int64_t n_envs, int64_t n_images,
+                                       const int32_t* __restrict__ bin_start, const int32_t* __restrict__ rank,
+                                       int32_t* __restrict__ order)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_images) return;
+    const int64_t me = i % n_envs;
+    const int64_t g = geom_of_env ? (int64_t)geom_of_env[me] : me;
+    order[bin_start[g] + rank[i]] = (int32_t)i;
 }
 
 // EgocentricCostmap.observation's goal_n_state (envs/egocentric.py:140-160), one thread per env
@@ -1468,6 +1674,8 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->pending) (void)hipFree(h->pending);
     if (h->pending_count) (void)hipFree(h->pending_count);
     if (h->dev_static) (void)hipFree(h->dev_static);
+    if (h->ego_bins) (void)hipFree(h->ego_bins);
+    if (h->ego_order) (void)hipFree(h->ego_order);
     delete h;
     return BCP_OK;
 }
@@ -2009,30 +2217,70 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
         a.win_oy = window_origin[1];
     }
     const size_t map_bytes = ((size_t)(a.rows + 2) * (a.cols + 2) + 3) & ~(size_t)3;   // LDS copy with a border ring
-    const size_t tab_bytes = (size_t)4 * a.drows * 2 * sizeof(int32_t);
-    a.stage_map = (a.shared && tab_bytes + map_bytes <= 60 * 1024) ? 1 : 0;
+    const size_t row_bytes = (size_t)a.drows * 2 * sizeof(int32_t);                   // one row table
     a.border = border_value;
     a.out = out;
     a.n_envs = h->n;
     a.n_images = n;
-    // persistent workgroups: as many as are resident at once (LDS footprint and registers decide), no more
-    const size_t lds = tab_bytes + (a.stage_map ? map_bytes : 0);
-    const bool px8 = a.dcols >= 8;   // 8 pixels (one 64-bit store) per lane; narrow windows fall back to 4
+    a.cols_magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)a.cols) + 1;   // (staged maps are < 64 KB: exact)
     if (a.dcols < 4) return fail(BCP_E_INVALID, "bcp_egocentric_costmaps: windows narrower than 4 px are not supported");
-    const void* fn = a.stage_map ? (px8 ? (const void*)ego_costmap_kernel<true, 8> : (const void*)ego_costmap_kernel<true, 4>)
-                                 : (px8 ? (const void*)ego_costmap_kernel<false, 8> : (const void*)ego_costmap_kernel<false, 4>);
-    int per_cu = 0, cus = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-    const int64_t groups = std::min<int64_t>((n + 3) / 4, (int64_t)std::max(per_cu, 1) * std::max(cus, 1));
-    const dim3 grid((unsigned)groups), block(256);
+    const bool px8 = a.dcols >= 8;   // 8 pixels (one 64-bit store) per lane; narrow windows fall back to 4
     hipStream_t st = (hipStream_t)stream;
-    if (a.stage_map) {
-        if (px8) hipLaunchKernelGGL((ego_costmap_kernel<true, 8>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((ego_costmap_kernel<true, 4>), grid, block, lds, st, a);
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    cus = std::max(cus, 1);
+    const dim3 block(256);
+    if (!a.shared && map_bytes + 4 * row_bytes <= 60 * 1024 && n < ((int64_t)1 << 31)) {
+        // private / pooled maps that fit LDS: group the images by map entry, then one workgroup per entry at a time
+        const int64_t n_bins = n_slots(h);
+        if (n_bins > h->ego_bins_cap) {
+            if (h->ego_bins) HIP_TRY(hipFree(h->ego_bins));
+            h->ego_bins = nullptr;
+            h->ego_bins_cap = 0;
+            HIP_TRY(hipMalloc((void**)&h->ego_bins, (size_t)2 * n_bins * sizeof(int32_t)));
+            h->ego_bins_cap = n_bins;
+        }
+        if (n > h->ego_order_cap) {
+            if (h->ego_order) HIP_TRY(hipFree(h->ego_order));
+            h->ego_order = nullptr;
+            h->ego_order_cap = 0;
+            HIP_TRY(hipMalloc((void**)&h->ego_order, (size_t)2 * n * sizeof(int32_t)));
+            h->ego_order_cap = n;
+        }
+        int32_t* bin_count = h->ego_bins;
+        int32_t* bin_start = h->ego_bins + h->ego_bins_cap;
+        int32_t* rank = h->ego_order;
+        int32_t* order = h->ego_order + h->ego_order_cap;
+        HIP_TRY(hipMemsetAsync(bin_count, 0, (size_t)n_bins * sizeof(int32_t), st));
+        const dim3 per_image((unsigned)((n + 255) / 256));
+        hipLaunchKernelGGL(ego_bin_count_kernel, per_image, block, 0, st, a.geom_of_env, a.n_envs, n, bin_count, rank);
+        hipLaunchKernelGGL(ego_bin_scan_kernel, dim3(1), dim3(1024), 0, st, bin_count, n_bins, bin_start);
+        hipLaunchKernelGGL(ego_bin_scatter_kernel, per_image, block, 0, st, a.geom_of_env, a.n_envs, n, bin_start, rank, order);
+        const size_t lds = map_bytes + 4 * row_bytes;
+        const void* fn = px8 ? (const void*)ego_costmap_binned_kernel<8> : (const void*)ego_costmap_binned_kernel<4>;
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
+        const dim3 grid((unsigned)std::min<int64_t>(n, (int64_t)std::max(per_cu, 1) * cus));
+        a.stage_map = 1;
+        if (px8) hipLaunchKernelGGL((ego_costmap_binned_kernel<8>), grid, block, lds, st, a, bin_start, bin_count, order);
+        else hipLaunchKernelGGL((ego_costmap_binned_kernel<4>), grid, block, lds, st, a, bin_start, bin_count, order);
     } else {
-        if (px8) hipLaunchKernelGGL((ego_costmap_kernel<false, 8>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((ego_costmap_kernel<false, 4>), grid, block, lds, st, a);
+        // shared map (staged in LDS when it fits) or maps too large for LDS (sampled from global memory):
+        // persistent workgroups, as many as are resident at once
+        a.stage_map = (a.shared && map_bytes + 4 * row_bytes <= 60 * 1024) ? 1 : 0;
+        const size_t lds = 4 * row_bytes + (a.stage_map ? map_bytes : 0);
+        const void* fn = a.stage_map ? (px8 ? (const void*)ego_costmap_kernel<true, 8> : (const void*)ego_costmap_kernel<true, 4>)
+                                     : (px8 ? (const void*)ego_costmap_kernel<false, 8> : (const void*)ego_costmap_kernel<false, 4>);
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
+        const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)std::max(per_cu, 1) * cus));
+        if (a.stage_map) {
+            if (px8) hipLaunchKernelGGL((ego_costmap_kernel<true, 8>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((ego_costmap_kernel<true, 4>), grid, block, lds, st, a);
+        } else {
+            if (px8) hipLaunchKernelGGL((ego_costmap_kernel<false, 8>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((ego_costmap_kernel<false, 4>), grid, block, lds, st, a);
+        }
     }
     HIP_TRY(hipGetLastError());
     return BCP_OK;
