@@ -6,9 +6,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbcplan.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_VERTS = 32
 MODEL_TRICYCLE, MODEL_DIFFDRIVE = 0, 1
+REWARD_CONTINUOUS, REWARD_PURE_PURSUIT = 0, 1
 STEP_AUTO_RESET, STEP_ACTIONS_F32 = 1, 2
 ERR_ANGLE_JUMP = 1
 TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL, TUNE_DEFER = 0, 1, 2, 3
@@ -31,6 +32,8 @@ class BcpParams(C.Structure):
         ("alpha", C.c_double * 6),
         ("spatial_precision", C.c_double), ("angular_precision", C.c_double),
         ("spatial_progress_multiplier", C.c_double),
+        ("reward_provider", C.c_int32), ("control_delay", C.c_int32), ("pose_delay", C.c_int32),
+        ("state_delay", C.c_int32),
     ]
 
 
@@ -39,6 +42,8 @@ class BcpState(C.Structure):
         ("x", C.c_void_p), ("y", C.c_void_p), ("angle", C.c_void_p), ("v", C.c_void_p), ("w", C.c_void_p),
         ("steering_motor_command", C.c_void_p), ("wheel_angle", C.c_void_p), ("min_spat_dist_so_far", C.c_void_p),
         ("target_idx", C.c_void_p), ("current_iter", C.c_void_p), ("robot_collided", C.c_void_p),
+        ("pose_seen", C.c_void_p), ("robot_state_seen", C.c_void_p), ("control_queue", C.c_void_p),
+        ("poses_queue", C.c_void_p), ("robot_state_queue", C.c_void_p),
     ]
 
 

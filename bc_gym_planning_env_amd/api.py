@@ -20,6 +20,7 @@ import numpy as np
 INDUSTRIAL_TRICYCLE_V1 = 'industrial_tricycle_v1'
 INDUSTRIAL_DIFFDRIVE_V1 = 'industrial_diffdrive_v1'
 CONTINUOUS_REWARD = 'continuous_reward'
+CONTINUOUS_REWARD_PURE_PURSUIT = 'continuous_reward_pure_pursuit'
 
 
 @attr.s(eq=False)
@@ -181,6 +182,30 @@ class ContinuousRewardProviderState(object):
 
     def __eq__(self, other):
         return (isinstance(other, ContinuousRewardProviderState) and not (self.path != other.path).any()
+                and self.min_spat_dist_so_far == other.min_spat_dist_so_far and self.target_idx == other.target_idx)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+
+@attr.s(eq=False)
+class ContinuousRewardPurePursuitProviderState(object):
+    """envs/base/reward.py:76-159: the goal is always the last way point, target_idx the look-ahead way point"""
+    min_spat_dist_so_far = attr.ib(type=float)
+    path = attr.ib(type=np.ndarray)
+    target_idx = attr.ib(type=int, default=0)
+
+    def copy(self):
+        return attr.evolve(self, path=np.copy(self.path))
+
+    def current_goal_pose(self):
+        return self.path[-1]
+
+    def current_path(self):
+        return self.path[:self.target_idx + 1]
+
+    def __eq__(self, other):
+        return (isinstance(other, ContinuousRewardPurePursuitProviderState) and not (self.path != other.path).any()
                 and self.min_spat_dist_so_far == other.min_spat_dist_so_far and self.target_idx == other.target_idx)
 
     def __ne__(self, other):

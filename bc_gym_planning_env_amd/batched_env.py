@@ -11,7 +11,8 @@ import numpy as np
 import torch
 
 from . import _lib, host_init, robots
-from .api import (Action, Box, ContinuousRewardProviderState, CostMap2D, DiffdriveRobotState, EnvParams,
+from .api import (Action, Box, CONTINUOUS_REWARD_PURE_PURSUIT, ContinuousRewardProviderState,
+                  ContinuousRewardPurePursuitProviderState, CostMap2D, DiffdriveRobotState, EnvParams,
                   INDUSTRIAL_TRICYCLE_V1, Observation, State, TricycleRobotState)
 
 _STATE_FIELDS = ("x", "y", "angle", "v", "w", "steering_motor_command", "wheel_angle")
@@ -38,16 +39,28 @@ def _as_device_actions(actions, n, device):
 class BatchedState(object):
     """Snapshot of every env's mutable state (what PlanEnv.get_state() deep-copies, env.py:287-291)."""
 
-    def __init__(self, robot, min_spat_dist_so_far, target_idx, current_iter, robot_collided):
+    # with delays > 0 (EnvParams.pose_delay / state_delay / control_delay, env.py:27-49, 363-398): what State exposes
+    # and the FIFO contents; `robot` is always the robot's TRUE state.  Element k pushed since the last reset lives
+    # in slot (k - 1) % delay.
+    DELAY_FIELDS = ("pose_seen", "robot_state_seen", "control_queue", "poses_queue", "robot_state_queue")
+
+    def __init__(self, robot, min_spat_dist_so_far, target_idx, current_iter, robot_collided, pose_seen=None,
+                 robot_state_seen=None, control_queue=None, poses_queue=None, robot_state_queue=None):
         self.robot = robot                      # float64 [7, N]: x, y, angle, v, w, steering_motor_command, wheel_angle
         self.min_spat_dist_so_far = min_spat_dist_so_far
         self.target_idx = target_idx
         self.current_iter = current_iter
         self.robot_collided = robot_collided
+        self.pose_seen = pose_seen                      # [3, N] State.pose when pose_delay > 0
+        self.robot_state_seen = robot_state_seen        # [7, N] State.robot_state when state_delay > 0
+        self.control_queue = control_queue              # [control_delay, 2, N]
+        self.poses_queue = poses_queue                  # [pose_delay, 3, N]
+        self.robot_state_queue = robot_state_queue      # [state_delay, 7, N]
 
     def copy(self):
+        extra = {k: (getattr(self, k).clone() if getattr(self, k) is not None else None) for k in self.DELAY_FIELDS}
         return BatchedState(self.robot.clone(), self.min_spat_dist_so_far.clone(), self.target_idx.clone(),
-                            self.current_iter.clone(), self.robot_collided.clone())
+                            self.current_iter.clone(), self.robot_collided.clone(), **extra)
 
 
 class BatchedObservation(object):
@@ -56,8 +69,11 @@ class BatchedObservation(object):
 
     def __init__(self, env):
         self._env = env
-        self.pose = env.state.robot[0:3]          # [3, N] view
-        self.robot_state = env.state.robot[3:7]   # [4, N] view: v, w, steering_motor_command, wheel_angle
+        st = env.state
+        # (with delays the observation shows the delayed pose / robot state, env.py:377-394)
+        self.pose = st.pose_seen if st.pose_seen is not None else st.robot[0:3]          # [3, N]
+        seen = st.robot_state_seen if st.robot_state_seen is not None else st.robot
+        self.robot_state = seen[3:7]              # [4, N] view: v, w, steering_motor_command, wheel_angle
         self.target_idx = env.state.target_idx
         self.current_iter = env.state.current_iter
         self.dt = env.params.dt
@@ -86,17 +102,31 @@ class EnvView(object):
 
     def get_state(self):
         e, i = self._env, self._i
-        col = e.state.robot[:, i].cpu().numpy()
+        s = e.state
+        col = s.robot[:, i].cpu().numpy()
         path = e.path_of(i)
-        tidx = int(e.state.target_idx[i])
-        it = int(e.state.current_iter[i])
-        rps = ContinuousRewardProviderState(min_spat_dist_so_far=float(e.state.min_spat_dist_so_far[i]), path=path,
-                                            target_idx=tidx)
+        tidx = int(s.target_idx[i])
+        it = int(s.current_iter[i])
+        cls = (ContinuousRewardPurePursuitProviderState if e.params.reward_provider_name == CONTINUOUS_REWARD_PURE_PURSUIT
+               else ContinuousRewardProviderState)
+        rps = cls(min_spat_dist_so_far=float(s.min_spat_dist_so_far[i]), path=path, target_idx=tidx)
+        pose = s.pose_seen[:, i].cpu().numpy() if s.pose_seen is not None else col[:3].copy()
+        seen = s.robot_state_seen[:, i].cpu().numpy() if s.robot_state_seen is not None else col
+
+        def fifo(q):   # the queue as the reference's list: oldest element first
+            if q is None:
+                return []
+            d = q.shape[0]
+            rows = q[:, :, i].cpu().numpy()
+            return [rows[(k - 1) % d].copy() for k in range(max(1, it - d + 1), it + 1)]
+
         return State(reward_provider_state=rps, path=rps.current_path(), original_path=np.copy(path),
                      costmap=e.costmap_of(i), iter_timeout=e.params.iteration_timeout,
-                     current_time=float(e.time_of(e.state.current_iter[i:i + 1])[0]), current_iter=it,
-                     robot_collided=bool(e.state.robot_collided[i]), poses_queue=[], robot_state_queue=[],
-                     control_queue=[], pose=col[:3].copy(), robot_state=self._robot_state(col))
+                     current_time=float(e.time_of(s.current_iter[i:i + 1])[0]), current_iter=it,
+                     robot_collided=bool(s.robot_collided[i]), poses_queue=fifo(s.poses_queue),
+                     robot_state_queue=[self._robot_state(v) for v in fifo(s.robot_state_queue)],
+                     control_queue=[Action(command=v) for v in fifo(s.control_queue)], pose=pose,
+                     robot_state=self._robot_state(seen))
 
     def set_state(self, state):
         e, i = self._env, self._i
@@ -154,11 +184,8 @@ class BatchedPlanEnv(object):
                  auto_reset=False, env_id_base=0, seed=0, footprint_scale=1.0, dynamic_model=True,
                  model_front_column_pid=True, template_of_env=None, geom_of_env=None, next_geom=None):
         params = EnvParams() if params is None else params
-        if params.pose_delay or params.control_delay or params.state_delay:
-            raise NotImplementedError("pose/control/state delays > 0 are not supported by the batched step")
-        if params.reward_provider_name != 'continuous_reward':
-            raise NotImplementedError("only the continuous reward provider is supported")
         self.params = params
+        self._pure_pursuit = params.reward_provider_name == CONTINUOUS_REWARD_PURE_PURSUIT
         self.n_envs = int(n_envs)
         self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
         self.robot_name = params.robot_name if robot_name is None else robot_name
@@ -183,11 +210,16 @@ class BatchedPlanEnv(object):
         self._time_table_dev = torch.from_numpy(self.time_table).to(self.device)
 
         n, dev = self.n_envs, self.device
-        self.state = BatchedState(torch.zeros(7, n, dtype=torch.float64, device=dev),
-                                  torch.zeros(n, dtype=torch.float64, device=dev),
+        def f64(*shape):
+            return torch.zeros(*shape, dtype=torch.float64, device=dev)
+
+        cd, pd, sd = int(params.control_delay), int(params.pose_delay), int(params.state_delay)
+        self.state = BatchedState(f64(7, n), f64(n), torch.zeros(n, dtype=torch.int32, device=dev),
                                   torch.zeros(n, dtype=torch.int32, device=dev),
-                                  torch.zeros(n, dtype=torch.int32, device=dev),
-                                  torch.zeros(n, dtype=torch.uint8, device=dev))
+                                  torch.zeros(n, dtype=torch.uint8, device=dev),
+                                  pose_seen=f64(3, n) if pd else None, robot_state_seen=f64(7, n) if sd else None,
+                                  control_queue=f64(cd, 2, n) if cd else None, poses_queue=f64(pd, 3, n) if pd else None,
+                                  robot_state_queue=f64(sd, 7, n) if sd else None)
         self.reward = torch.zeros(n, dtype=torch.float64, device=dev)
         self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
         self.collided_now = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -247,6 +279,9 @@ class BatchedPlanEnv(object):
         st.target_idx = s.target_idx.data_ptr()
         st.current_iter = s.current_iter.data_ptr()
         st.robot_collided = s.robot_collided.data_ptr()
+        for name in BatchedState.DELAY_FIELDS:
+            t = getattr(s, name)
+            setattr(st, name, t.data_ptr() if t is not None else None)
         _lib.check(fn(self._h, C.byref(st)))
 
     def _set_costmaps(self, costmap):
@@ -374,26 +409,31 @@ class BatchedPlanEnv(object):
         rp = self.params.reward_provider_params
         if self.geom_of_env is not None:   # one initial state per pool entry
             for g, p in enumerate(self._paths):
-                md[g], ti[g] = host_init.initial_reward_state(p, rp)
+                md[g], ti[g] = self._first_reward_state(p, rp)
                 robot[0:3, g] = p[0]
         elif self._shared_path:
             p = self._paths[0]
-            m0, t0 = host_init.initial_reward_state(p, rp)
+            m0, t0 = self._first_reward_state(p, rp)
             robot[0:3, :] = p[0][:, None]
             md[:], ti[:] = m0, t0
         elif self._template_of_env is not None:
-            per = [host_init.initial_reward_state(p, rp) for p in self._paths]
+            per = [self._first_reward_state(p, rp) for p in self._paths]
             tix = self._template_of_env
             md[:] = np.array([m for m, _ in per])[tix]
             ti[:] = np.array([t for _, t in per])[tix]
             robot[0:3, :] = np.stack([p[0] for p in self._paths])[tix].T
         else:
             for i, p in enumerate(self._paths):
-                md[i], ti[i] = host_init.initial_reward_state(p, rp)
+                md[i], ti[i] = self._first_reward_state(p, rp)
                 robot[0:3, i] = p[0]
         dev = self.device
         return BatchedState(torch.from_numpy(robot).to(dev), torch.from_numpy(md).to(dev), torch.from_numpy(ti).to(dev),
                             torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev))
+
+    def _first_reward_state(self, path, reward_params):
+        if self._pure_pursuit:
+            return host_init.initial_pure_pursuit_state(path)
+        return host_init.initial_reward_state(path, reward_params)
 
     def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None, defer=None):
         """Execution knobs of libbcplan (bcp_set_tuning); results never depend on them."""
@@ -453,6 +493,9 @@ class BatchedPlanEnv(object):
         s.target_idx.copy_(state.target_idx)
         s.current_iter.copy_(state.current_iter)
         s.robot_collided.copy_(state.robot_collided)
+        for name in BatchedState.DELAY_FIELDS:
+            if getattr(s, name) is not None:
+                getattr(s, name).copy_(getattr(state, name))
 
     def step(self, actions, noise_z=None, noise_z_out=None):
         """One tick for every env.  actions: [N,2] (float32 or float64) tensor / array, or a list of Action.

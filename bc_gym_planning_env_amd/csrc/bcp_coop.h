@@ -151,20 +151,6 @@ __device__ __forceinline__ double bcast_d(double v, int src)
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
-__device__ __forceinline__ int wave_min_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
-}
-
-__device__ __forceinline__ int wave_max_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
-
 // bits [pos, 32*NW) of an NW-word row mask, word w
 __device__ __forceinline__ uint32_t suffix_word(int pos, int w)
 {

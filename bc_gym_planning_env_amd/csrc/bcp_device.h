@@ -25,6 +25,8 @@ struct DevParams {
     double sp2_lo, sp2_hi;   // sp^2 (1 -+ 1e-13): dx^2+dy^2 outside this band decides hypot(dx,dy) < sp on its own
     double sp_prune;         // sp nudged up two ulps: |dx| > sp_prune  =>  hypot(dx,dy) >= sp for any faithful hypot
     double qverts[BCP_MAX_VERTS][2];  // footprint / resolution (path_tools.py:145), divided on the host in fp64
+    int32_t reward_provider;          // BCP_REWARD_*
+    int32_t control_delay, pose_delay, state_delay;   // EnvParams delays (envs/base/params.py:28-30)
 };
 
 // numpy float `%`: the result takes the sign of the divisor (npy_divmod)

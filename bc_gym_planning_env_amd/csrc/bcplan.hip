@@ -47,6 +47,8 @@ struct DevState {
     double *x, *y, *angle, *v, *w, *steer, *wheel, *min_dist;
     int32_t *target_idx, *cur_iter;
     uint8_t* collided;
+    double *pose_seen, *state_seen;         // [3][n] / [7][n], delays > 0 only
+    double *control_q, *pose_q, *state_q;   // [delay][width][n]
 };
 
 struct MapDesc {
@@ -104,6 +106,17 @@ struct StepArgs {
     int32_t* pending_next;     // [kShards] the next step's counters (the two sets alternate); kernel 1 zeroes them
     uint64_t seed, step_counter;
     uint32_t flags;
+};
+
+// Ablation switches in the upper half of the step flags (tools/ablate*.py time the step with stages removed; results
+// are then WRONG by construction).  Not part of the ABI: bcplan.h only defines bits 0-1.
+enum : uint32_t {
+    kAblateNoCollision = 1u << 16,   // skip pose_collides altogether
+    kAblateNoReward = 1u << 17,      // skip the reward scan
+    kAblateNoCoop = 1u << 19,        // kernel 2: skip the cooperative rasteriser
+    kAblateNoInner = 1u << 20,       // kernel 2: skip the inner distance-field test
+    kAblateNoPark = 1u << 21,        // kernel 1: do not park undecided envs
+    kAblateNoClassify = 1u << 22     // kernel 1: skip the distance-field lookups
 };
 
 struct bcp_handle {
@@ -164,12 +177,19 @@ static DevState to_dev_state(const bcp_state* s)
     d.x = s->x; d.y = s->y; d.angle = s->angle; d.v = s->v; d.w = s->w;
     d.steer = s->steering_motor_command; d.wheel = s->wheel_angle; d.min_dist = s->min_spat_dist_so_far;
     d.target_idx = s->target_idx; d.cur_iter = s->current_iter; d.collided = s->robot_collided;
+    d.pose_seen = s->pose_seen; d.state_seen = s->robot_state_seen;
+    d.control_q = s->control_queue; d.pose_q = s->poses_queue; d.state_q = s->robot_state_queue;
     return d;
 }
 
-static int check_state(const bcp_state* s, int tricycle)
+static int check_state(const bcp_state* s, int tricycle, const bcp_params* p = nullptr, bool queues = true)
 {
     if (!s) return 0;
+    if (p) {   // delays > 0 need the arrays State exposes, and (for the live state) the queues
+        if (p->pose_delay > 0 && (!s->pose_seen || (queues && !s->poses_queue))) return 0;
+        if (p->state_delay > 0 && (!s->robot_state_seen || (queues && !s->robot_state_queue))) return 0;
+        if (p->control_delay > 0 && queues && !s->control_queue) return 0;
+    }
     if (!s->x || !s->y || !s->angle || !s->v || !s->w || !s->min_spat_dist_so_far || !s->target_idx ||
         !s->current_iter || !s->robot_collided)
         return 0;
@@ -333,14 +353,7 @@ __device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path, 
                                               double th, double& min_dist, int& target)
 {
     if (target > m - 1) return 0.0;
-#if defined(BCP_EXP_NOLOOP)
-    const int last = -1;
-#else
     const int last = last_reached_from(P, path, w, m, target, x, y, th);
-#endif
-#if defined(BCP_EXP_NOHYPOT)
-#define hypot(a, b) sqrt((a) * (a) + (b) * (b))
-#endif
     if (last >= 0) {
         target = last + 1;
         if (!(target > m - 1)) {
@@ -359,6 +372,56 @@ __device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path, 
         return r * P.progress_mult;
     }
     return 0.0;
+}
+
+// ContinuousRewardPurePursuitProvider.reward (envs/base/reward.py:330-353) with update_goal (:125-139): the target is
+// the first way point from target_idx on that is more than 2 m away (np.linalg.norm = sqrt of an fma-contracted
+// 2-term dot product, like every 2-element np.dot in this code base), the goal is always the LAST way point.
+template <typename PathPtr>
+__device__ __forceinline__ double reward_pure_pursuit(PathPtr path, int m, double x, double y, bool collided,
+                                                      double& min_dist, int& target)
+{
+    int found = m - 1;
+    for (int i = target; i < m; ++i) {
+        const double dx = path[5 * i] - x, dy = path[5 * i + 1] - y;
+        if (sqrt(fma(dy, dy, dx * dx)) > 2.) {
+            found = i;
+            break;
+        }
+    }
+    target = found;
+    const PathPtr g = path + 5 * (m - 1);
+    const double dist = hypot(g[0] - x, g[1] - y);
+    double reward = -0.05;
+    reward += min_dist - dist;
+    min_dist = dist;
+    if (collided) reward -= 100;
+    return reward;
+}
+
+// _get_element_from_list_with_delay (envs/base/env.py:27-49) for the k-th push since the last reset: queue q is
+// [delay][W][n]; element k lives in slot (k - 1) % delay.  `v` holds the new element on entry, the delayed one on exit.
+template <int W>
+__device__ __forceinline__ void fifo_delay(double* __restrict__ q, int delay, int64_t n, int64_t i, int k, double (&v)[W])
+{
+    if (delay <= 0) return;
+    const int slot = (k - 1) % delay;
+    double* cell = q + ((int64_t)slot * W) * n + i;
+    if (k <= delay) {   // the list is not longer than `delay` yet: append, hand back the first element
+#pragma unroll
+        for (int c = 0; c < W; ++c) cell[c * n] = v[c];
+        if (k > 1) {
+#pragma unroll
+            for (int c = 0; c < W; ++c) v[c] = q[c * n + i];
+        }
+    } else {            // pop(0): element k - delay, whose slot the new element takes
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            const double first = cell[c * n];
+            cell[c * n] = v[c];
+            v[c] = first;
+        }
+    }
 }
 
 #ifdef BCP_DIAG
@@ -494,13 +557,14 @@ __device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const
     return S->geom_of_env ? (int64_t)q.geom : i;
 }
 
-// Everything of PlanEnv.step() that follows pose_collides(): rollback (env.py:458-459), bookkeeping (:382-396),
-// reward (:352), done (:407-419), outputs, optional reset, state write-back.  Runs on one lane for env i.
+// Everything of PlanEnv.step() that follows pose_collides(): rollback (env.py:458-459), bookkeeping and delay queues
+// (:377-396), reward (:352), done (:407-419), outputs, optional reset, state write-back.  Runs on one lane for env i.
 __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
                                              const PathWindow* free_window = nullptr)
 {
     const DevParams& P = a.S->P;
     const bool tri = P.model == BCP_MODEL_TRICYCLE;
+    const int64_t n = a.S->n;
     Robot& r = q.r;
     if (hit) {  // robot.set_pose(*old_position): pose restored, v = w = 0 (tricycle_model.py:471-476)
         r.p = q.old;
@@ -511,32 +575,37 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     bool collided = q.collided != 0 || hit;
     double min_dist = q.min_dist;
     int target = q.target;
+    // State.pose / State.robot_state: what the reward provider and the observation see (env.py:377-394)
+    double seen[3] = {r.p.x, r.p.y, r.p.th};
+    double seen_rs[7] = {r.p.x, r.p.y, r.p.th, r.v, r.w, r.steer, r.wheel};
+    if (P.pose_delay) fifo_delay<3>(a.S->st.pose_q, P.pose_delay, n, i, iter, seen);
+    if (P.state_delay) fifo_delay<7>(a.S->st.state_q, P.state_delay, n, i, iter, seen_rs);
 
     // shared path: uniform pointers (scalar cache); private paths: per-lane pointers
     double rew = 0.0;
     int m;
-    // way-point window of the final pose: the caller may have looked it up already for the un-rolled-back pose
+    bool goal;
     const int64_t g = slot_of(a.S, i, q);
-    const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : g * 8);
-    const int16_t* index = a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
-    if (a.S->path.shared) {
-        m = a.S->path.max_len;
-        if (a.flags & (1u << 17)) {
-        } else {
-            const PathWindow w = (free_window && !hit) ? *free_window : path_window(P, bbox, index, r.p.x, r.p.y);
-            if (lds_path)  // way points staged in LDS by the step kernel: no global round trip per candidate
-                rew = reward_step(P, lds_path, w, m, r.p.x, r.p.y, r.p.th, min_dist, target);
-            else
-                rew = reward_step(P, a.S->path.pts, w, m, r.p.x, r.p.y, r.p.th, min_dist, target);
-        }
+    const double* pts = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
+    m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
+    if (P.reward_provider == BCP_REWARD_PURE_PURSUIT) {
+        if (!(a.flags & kAblateNoReward)) rew = reward_pure_pursuit(pts, m, seen[0], seen[1], collided, min_dist, target);
+        goal = hypot(pts[5 * (m - 1)] - seen[0], pts[5 * (m - 1) + 1] - seen[1]) < 1.0;   // done(), reward.py:141-150
     } else {
-        m = a.S->path.lens[g];
-        if (!(a.flags & (1u << 17))) {
-            const PathWindow w = (free_window && !hit) ? *free_window : path_window(P, bbox, index, r.p.x, r.p.y);
-            rew = reward_step(P, a.S->path.pts + g * (int64_t)a.S->path.max_len * 5, w, m, r.p.x, r.p.y, r.p.th, min_dist, target);
+        if (!(a.flags & kAblateNoReward)) {
+            // way-point window of the pose: the caller may have looked it up already for the un-rolled-back pose
+            const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : g * 8);
+            const int16_t* index = a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
+            const PathWindow w =
+                (free_window && !hit && !P.pose_delay) ? *free_window : path_window(P, bbox, index, seen[0], seen[1]);
+            if (lds_path && a.S->path.shared)  // way points staged in LDS by the step kernel
+                rew = reward_step(P, lds_path, w, m, seen[0], seen[1], seen[2], min_dist, target);
+            else
+                rew = reward_step(P, pts, w, m, seen[0], seen[1], seen[2], min_dist, target);
         }
+        goal = target > m - 1;
     }
-    const bool done = (target > m - 1) || (iter >= P.iteration_timeout) || collided;
+    const bool done = goal || (iter >= P.iteration_timeout) || collided;
     if (free_window) DIAG1_STAMP(5);
 
     a.reward[i] = rew;
@@ -571,6 +640,17 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
         target = a.S->init.target_idx[k];
         iter = a.S->init.cur_iter[k];
         collided = a.S->init.collided[k] != 0;
+        // the restored State exposes the initial pose / robot state; its queues are empty (pushes restart at k = 1)
+        seen[0] = r.p.x;
+        seen[1] = r.p.y;
+        seen[2] = r.p.th;
+        seen_rs[0] = r.p.x;
+        seen_rs[1] = r.p.y;
+        seen_rs[2] = r.p.th;
+        seen_rs[3] = r.v;
+        seen_rs[4] = r.w;
+        seen_rs[5] = r.steer;
+        seen_rs[6] = r.wheel;
     }
 
     if (free_window) DIAG1_STAMP(6);
@@ -587,14 +667,18 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     a.S->st.target_idx[i] = target;
     a.S->st.cur_iter[i] = iter;
     a.S->st.collided[i] = (uint8_t)collided;
+    if (P.pose_delay) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.S->st.pose_seen[c * n + i] = seen[c];
+    }
+    if (P.state_delay) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) a.S->st.state_seen[c * n + i] = seen_rs[c];
+    }
 }
 
-#if defined(BCP_EXP_NOHYPOT)
-#undef hypot
-#endif
-
 // ---- loads shared by the step kernels ------------------------------------------------------------------------
-__device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, Pending& q, double& cmd0, double& cmd1)
+__device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, bool active, Pending& q, double& cmd0, double& cmd1)
 {
     const DevParams& P = a.S->P;
     Robot& r = q.r;
@@ -619,6 +703,12 @@ __device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, Pending& 
         const double2 c = reinterpret_cast<const double2*>(a.actions)[i];
         cmd0 = c.x;
         cmd1 = c.y;
+    }
+    if (P.control_delay && active) {   // the robot executes the command given control_delay steps ago (env.py:371-373)
+        double cmd[2] = {cmd0, cmd1};
+        fifo_delay<2>(a.S->st.control_q, P.control_delay, a.S->n, i, q.iter + 1, cmd);
+        cmd0 = cmd[0];
+        cmd1 = cmd[1];
     }
     q.z[0] = q.z[1] = q.z[2] = 0.0;
     if (P.noise_on) {
@@ -646,14 +736,14 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     const CollisionLds L = collision_lds_setup(P, a.S->map, tid);
     Pending q;
     double cmd0, cmd1;
-    load_env(a, i, q, cmd0, cmd1);
+    load_env(a, i, active, q, cmd0, cmd1);
 
     // ---- _env_step (envs/base/env.py:442-461)
     q.old = q.r.p;
     q.drawn = 0;
     q.err = robot_step(P, q.r, cmd0, cmd1, q.z, q.drawn);
     bool hit = false;
-    if (!(a.flags & (1u << 16)))
+    if (!(a.flags & kAblateNoCollision))
         hit = collides_wave(P, a.S->map, a.S->cull, L, a.S->exact_mode, a.S->dense_threshold, a.S->wide != 0, active,
                             slot_of(a.S, i, q), q.r.p.x, q.r.p.y, q.r.p.th);
     if (!active) return;
@@ -690,7 +780,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
     // (2) ... then state, action, noise (the first-touch lines of this step): all of it is in flight together
     Pending q;
     double cmd0, cmd1;
-    load_env(a, i, q, cmd0, cmd1);
+    load_env(a, i, active, q, cmd0, cmd1);
     if (gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
     // (3) LDS writes (the staging loads return first, in issue order)
     if (tid < nq) qv[tid] = my_q;
@@ -725,7 +815,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
     const int64_t map_env = a.S->map.shared ? 0 : g;
     OuterLookups look;
     look.off_map = true;
-    if (!(a.flags & ((1u << 16) | (1u << 22)))) look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
+    if (!(a.flags & (kAblateNoCollision | kAblateNoClassify))) look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
     const PathWindow win = path_window(P, a.S->path.bbox + (a.S->path.shared ? 0 : g * 8),
                                        a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets)), r.p.x, r.p.y);
     const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
@@ -748,7 +838,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
                                                bcast_i(py, src), words, a.S->map.rows, a.S->map.cols, a.S->map.wpr);
             if (tid == src) hit = h;
         }
-    } else if (cls == kAmbiguous && !(a.flags & (1u << 21))) {
+    } else if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
         // a few undecided lanes: park the pre-verdict state for kernel 2 (load-balanced over the whole GPU) and carry
         // on as if the pose were free, which it is for nearly every parked env
         const int shard = (int)(blockIdx.x % kShards);
@@ -793,9 +883,9 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
         if (idx >= count) break;
         DIAG_STAMP(1);
         const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : g * a.S->map.env_stride);
-        bool hit = (a.flags & (1u << 20)) ? false : classify_inner_hit(a.S->cull, a.S->map.shared ? 0 : g, px, py, c, s);
+        bool hit = (a.flags & kAblateNoInner) ? false : classify_inner_hit(a.S->cull, a.S->map.shared ? 0 : g, px, py, c, s);
         DIAG_STAMP(2);
-        if (!hit && !(a.flags & (1u << 19)))  // (the inner verdict is uniform over the workgroup: no barrier mismatch)
+        if (!hit && !(a.flags & kAblateNoCoop))  // (the inner verdict is uniform over the workgroup: no barrier mismatch)
             hit = coop_collides_quad<WIDE>(P, vqx, vqy, c, s, px, py, words, a.S->map.rows, a.S->map.cols, a.S->map.wpr, wave,
                                            (LdsU32)lds_dyn);
         DIAG_STAMP(3);
@@ -834,6 +924,21 @@ __global__ void reset_kernel(DevState st, DevState init, const uint8_t* __restri
     st.target_idx[i] = init.target_idx[k];
     st.cur_iter[i] = init.cur_iter[k];
     st.collided[i] = init.collided[k];
+    // delays > 0: the restored State exposes the initial pose / robot state; the queues are empty (pushes restart)
+    if (st.pose_seen) {
+        st.pose_seen[0 * n + i] = init.x[k];
+        st.pose_seen[1 * n + i] = init.y[k];
+        st.pose_seen[2 * n + i] = init.angle[k];
+    }
+    if (st.state_seen) {
+        st.state_seen[0 * n + i] = init.x[k];
+        st.state_seen[1 * n + i] = init.y[k];
+        st.state_seen[2 * n + i] = init.angle[k];
+        st.state_seen[3 * n + i] = init.v[k];
+        st.state_seen[4 * n + i] = init.w[k];
+        st.state_seen[5 * n + i] = tri ? init.steer[k] : 0.0;
+        st.state_seen[6 * n + i] = tri ? init.wheel[k] : 0.0;
+    }
 }
 
 __global__ void __launch_bounds__(kBlock) robot_step_kernel(DevParams P, double* __restrict__ st7, int64_t n,
@@ -1466,14 +1571,20 @@ __global__ void goal_n_state_kernel(const StepStatic* __restrict__ S, double wsx
     if (i >= S->n) return;
     const int64_t g = S->geom_of_env ? (int64_t)S->geom_of_env[i] : i;
     const int m = S->path.shared ? S->path.max_len : S->path.lens[g];
-    const int target = S->st.target_idx[i];
+    // Observation.path: the way points still ahead, path[target_idx:] (reward.py:59-64) -- or, for the pure-pursuit
+    // provider, path[:target_idx + 1] (reward.py:118-123), whose first row is always way point 0
+    const int target = S->P.reward_provider == BCP_REWARD_PURE_PURSUIT ? 0 : S->st.target_idx[i];
     float* o = out + i * (3 + n_state);
     if (target > m - 1) {   // nothing left of the path: zeros (egocentric.py:142-150)
         for (int k = 0; k < 3 + n_state; ++k) o[k] = 0.0f;
         return;
     }
     const double* wp = S->path.pts + ((S->path.shared ? 0 : g * (int64_t)S->path.max_len) + target) * 5;
-    const double x = S->st.x[i], y = S->st.y[i], th = S->st.angle[i];
+    const int64_t n = S->n;
+    // Observation.pose / .robot_state are the delayed ones when delays are configured
+    const bool dp = S->P.pose_delay > 0, ds = S->P.state_delay > 0;
+    const double x = dp ? S->st.pose_seen[i] : S->st.x[i], y = dp ? S->st.pose_seen[n + i] : S->st.y[i];
+    const double th = dp ? S->st.pose_seen[2 * n + i] : S->st.angle[i];
     // inverse_transform (coordinate_transformations.py:57-84), then project_poses (:310-328)
     const double c = cos(th), s = sin(th);
     const double tx = -x * c - y * s, ty = x * s - y * c, tt = normalize_angle(-th);
@@ -1484,12 +1595,13 @@ __global__ void goal_n_state_kernel(const StepStatic* __restrict__ S, double wsx
     o[0] = (float)fmin(fmax(ex / wsx, -1.0), 1.0);
     o[1] = (float)fmin(fmax(ey / wsy, -1.0), 1.0);
     o[2] = (float)eth;
-    o[3] = (float)x;                    // robot_state.to_numpy_array(): x, y, angle, v, w (, wheel_angle)
-    o[4] = (float)y;
-    o[5] = (float)th;
-    o[6] = (float)S->st.v[i];
-    o[7] = (float)S->st.w[i];
-    if (n_state > 5) o[8] = (float)S->st.wheel[i];
+    // robot_state.to_numpy_array(): x, y, angle, v, w (, wheel_angle)
+    o[3] = (float)(ds ? S->st.state_seen[i] : S->st.x[i]);
+    o[4] = (float)(ds ? S->st.state_seen[n + i] : S->st.y[i]);
+    o[5] = (float)(ds ? S->st.state_seen[2 * n + i] : S->st.angle[i]);
+    o[6] = (float)(ds ? S->st.state_seen[3 * n + i] : S->st.v[i]);
+    o[7] = (float)(ds ? S->st.state_seen[4 * n + i] : S->st.w[i]);
+    if (n_state > 5) o[8] = (float)(ds ? S->st.state_seen[6 * n + i] : S->st.wheel[i]);
 }
 
 // ------------------------------------------------------------------------------------------------ host API
@@ -1607,6 +1719,10 @@ static void fill_dev_params(bcp_handle* h)
     d.sp_prune = std::nextafter(std::nextafter(p.spatial_precision, INFINITY), INFINITY);
     d.sp2_lo = p.spatial_precision * p.spatial_precision * (1.0 - 1e-13);
     d.sp2_hi = p.spatial_precision * p.spatial_precision * (1.0 + 1e-13);
+    d.reward_provider = p.reward_provider;
+    d.control_delay = p.control_delay;
+    d.pose_delay = p.pose_delay;
+    d.state_delay = p.state_delay;
     const double res = h->resolution > 0 ? h->resolution : 1.0;
     for (int k = 0; k < p.n_verts; ++k) {
         d.qverts[k][0] = p.verts[k][0] / res;  // robot_footprint / map_resolution (path_tools.py:145)
@@ -1636,6 +1752,10 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     if (params->model != BCP_MODEL_TRICYCLE && params->model != BCP_MODEL_DIFFDRIVE)
         return fail(BCP_E_INVALID, "bcp_create: unknown robot model %d", params->model);
     if (!(params->dt > 0)) return fail(BCP_E_INVALID, "bcp_create: dt must be > 0 (path_tools.py:307)");
+    if (params->reward_provider != BCP_REWARD_CONTINUOUS && params->reward_provider != BCP_REWARD_PURE_PURSUIT)
+        return fail(BCP_E_INVALID, "bcp_create: unknown reward provider %d", params->reward_provider);
+    if (params->control_delay < 0 || params->pose_delay < 0 || params->state_delay < 0)
+        return fail(BCP_E_INVALID, "bcp_create: delays must be >= 0");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -1782,7 +1902,6 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
     CullDesc& C = h->cull;
     memset(&C, 0, sizeof(C));
     build_cull_geometry(h->params, resolution, &C);
-    if (const char* dbg = getenv("BCP_DEBUG_MAX_OUT")) C.n_out = std::min(C.n_out, atoi(dbg));  // timing experiments
     if (h->cull_enabled) {
         // shared map: padding wide enough that every sample of a pose whose image touches the map is stored;
         // private maps: a thin margin (samples outside it just cannot clear / convict a pose)
@@ -1887,8 +2006,9 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
 extern "C" int bcp_bind_state(bcp_handle* h, const bcp_state* state)
 {
     if (!h) return fail(BCP_E_INVALID, "bcp_bind_state: null handle");
-    if (!check_state(state, h->params.model == BCP_MODEL_TRICYCLE))
-        return fail(BCP_E_INVALID, "bcp_bind_state: missing state array");
+    if (!check_state(state, h->params.model == BCP_MODEL_TRICYCLE, &h->params))
+        return fail(BCP_E_INVALID, "bcp_bind_state: missing state array (delays > 0 need pose_seen / robot_state_seen "
+                                   "and the queues)");
     h->st = to_dev_state(state);
     h->have_state = true;
     h->static_dirty = true;
@@ -1900,6 +2020,7 @@ extern "C" int bcp_bind_initial_state(bcp_handle* h, const bcp_state* initial)
     if (!h) return fail(BCP_E_INVALID, "bcp_bind_initial_state: null handle");
     if (!check_state(initial, h->params.model == BCP_MODEL_TRICYCLE))
         return fail(BCP_E_INVALID, "bcp_bind_initial_state: missing state array");
+    // (the initial State exposes the initial pose / robot state themselves and has empty queues: nothing more to bind)
     h->init = to_dev_state(initial);
     h->have_init = true;
     h->static_dirty = true;
@@ -1922,7 +2043,12 @@ extern "C" int bcp_reset_masked(bcp_handle* h, const uint8_t* mask, void* stream
 // (re)builds the device-resident StepStatic block; returns whether the two-kernel (deferring) step is in effect
 static bool step_uses_deferral(const bcp_handle* h)
 {
-    return h->defer && h->cull.on && h->exact_mode == 0 && h->pending != nullptr;
+    // delays and the pure-pursuit provider run through the general kernel: the optimistic finalisation of the fast
+    // kernel cannot be redone once a FIFO slot has been overwritten
+    const bcp_params& p = h->params;
+    const bool plain = p.control_delay == 0 && p.pose_delay == 0 && p.state_delay == 0 &&
+                       p.reward_provider == BCP_REWARD_CONTINUOUS;
+    return plain && h->defer && h->cull.on && h->exact_mode == 0 && h->pending != nullptr;
 }
 
 static int upload_step_static(bcp_handle* h, hipStream_t s)
@@ -1947,7 +2073,6 @@ static int upload_step_static(bcp_handle* h, hipStream_t s)
     S.next_geom = h->n_geoms > 0 ? h->next_geom : nullptr;
     S.lds_path_doubles =
         (defer && h->path.shared && h->path.max_len * 5 * sizeof(double) <= 24 * 1024) ? h->path.max_len * 5 : 0;
-    if (getenv("BCP_DEBUG_NO_LDS_PATH")) S.lds_path_doubles = 0;  // timing experiments
     if (!h->dev_static) HIP_TRY(hipMalloc((void**)&h->dev_static, sizeof(StepStatic)));
     // pageable source: the copy is staged before the call returns, so host_static may change afterwards
     HIP_TRY(hipMemcpyAsync(h->dev_static, &S, sizeof(StepStatic), hipMemcpyHostToDevice, s));
@@ -2210,6 +2335,11 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
     a.sx = h->st.x;
     a.sy = h->st.y;
     a.sth = h->st.angle;
+    if (h->params.pose_delay > 0 && h->st.pose_seen) {   // the observation shows State.pose, i.e. the delayed pose
+        a.sx = h->st.pose_seen;
+        a.sy = h->st.pose_seen + h->n;
+        a.sth = h->st.pose_seen + 2 * h->n;
+    }
     a.geom_of_env = h->n_geoms > 0 ? h->geom_of_env : nullptr;
     a.has_window = window_origin != nullptr;
     if (window_origin) {

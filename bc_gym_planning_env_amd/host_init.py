@@ -3,6 +3,7 @@ first step.  Not on the hot path; kept on the host so its float64 results are th
 
   refine_path              utilities/path_tools.py:178-240 (angle_delta=None, as make_initial_state calls it)
   initial_reward_state     envs/base/reward.py:261-288 (ContinuousRewardProvider.generate_initial_state)
+  initial_pure_pursuit_state   envs/base/reward.py:355-371
   time_table               envs/base/env.py:382 (current_time accumulates `+= dt`)
 """
 import numpy as np
@@ -50,6 +51,12 @@ def initial_reward_state(path, reward_params):
     target_idx = last + 1
     goal = path[target_idx]
     return float(np.hypot(goal[0] - path[0][0], goal[1] - path[0][1])), int(target_idx)
+
+
+def initial_pure_pursuit_state(path):
+    """-> (min_spat_dist_so_far, target_idx) of ContinuousRewardPurePursuitProvider.generate_initial_state
+    (envs/base/reward.py:355-371): distance from the first to the LAST way point, look-ahead index 1."""
+    return float(np.hypot(path[-1][0] - path[0][0], path[-1][1] - path[0][1])), 1
 
 
 def time_table(dt, n):

@@ -7,7 +7,8 @@ acceleration limits, front-column P gain 0.16), diff-drive :53-82 (24-vertex moc
 import numpy as np
 
 from . import _lib
-from .api import INDUSTRIAL_DIFFDRIVE_V1, INDUSTRIAL_TRICYCLE_V1
+from .api import (CONTINUOUS_REWARD, CONTINUOUS_REWARD_PURE_PURSUIT, INDUSTRIAL_DIFFDRIVE_V1,
+                  INDUSTRIAL_TRICYCLE_V1)
 
 _TRICYCLE_MM = [
     (1348.35, 0.), (1338.56, 139.75), (1306.71, 280.12), (1224.36, 338.62), (1093.81, 374.64), (-214.37, 374.64),
@@ -68,4 +69,12 @@ def make_bcp_params(env_params, robot_name, noise_parameters, footprint_scale=1.
     p.spatial_precision = float(rp.spatial_precision)
     p.angular_precision = float(rp.angular_precision)
     p.spatial_progress_multiplier = float(rp.spatial_progress_multiplier)
+    providers = {CONTINUOUS_REWARD: _lib.REWARD_CONTINUOUS, CONTINUOUS_REWARD_PURE_PURSUIT: _lib.REWARD_PURE_PURSUIT}
+    if env_params.reward_provider_name not in providers:
+        raise AssertionError("Unknown reward provider: {}. Should be one of {}".format(
+            env_params.reward_provider_name, list(providers)))
+    p.reward_provider = providers[env_params.reward_provider_name]
+    p.control_delay = int(env_params.control_delay)
+    p.pose_delay = int(env_params.pose_delay)
+    p.state_delay = int(env_params.state_delay)
     return p

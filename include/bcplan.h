@@ -32,12 +32,14 @@
 extern "C" {
 #endif
 
-#define BCP_ABI_VERSION 1
+#define BCP_ABI_VERSION 2
 #define BCP_MAX_VERTS 32
 #define BCP_LETHAL 254 /* CostMap2D.LETHAL_OBSTACLE, utilities/costmap_2d.py:20-22 */
 #define BCP_MAX_KERNEL_HALF 127 /* footprint mask is at most 255x255 px (circumscribed radius / resolution) */
 
 enum { BCP_MODEL_TRICYCLE = 0, BCP_MODEL_DIFFDRIVE = 1 };
+/* EnvParams.reward_provider_name (envs/base/reward_provider_examples.py:13-16) */
+enum { BCP_REWARD_CONTINUOUS = 0, BCP_REWARD_PURE_PURSUIT = 1 };
 
 enum {
     BCP_OK = 0,
@@ -84,6 +86,11 @@ typedef struct bcp_params {
     double spatial_precision;       /* RewardParams */
     double angular_precision;
     double spatial_progress_multiplier;
+    int32_t reward_provider;        /* BCP_REWARD_*: ContinuousRewardProvider (reward.py:174-288) or
+                                       ContinuousRewardPurePursuitProvider (reward.py:291-371) */
+    int32_t control_delay;          /* EnvParams.control_delay / pose_delay / state_delay (params.py:28-30): FIFO delays */
+    int32_t pose_delay;             /* of the action, of State.pose and of State.robot_state (env.py:27-49, 363-398) */
+    int32_t state_delay;
 } bcp_params;
 
 /* Struct-of-arrays env state, caller-owned device memory, n_envs elements per array.
@@ -100,6 +107,14 @@ typedef struct bcp_state {
     int32_t *target_idx;              /* reward provider */
     int32_t *current_iter;
     uint8_t *robot_collided;          /* sticky */
+    /* Only with delays > 0 (NULL otherwise).  x/y/angle/... above are always the robot's TRUE state.  The k-th element
+     * pushed into a queue since the last reset (k = current_iter + 1) lives in slot (k - 1) % delay. */
+    double *pose_seen;                /* [3][N] State.pose when pose_delay > 0: what the reward provider and the
+                                         observation see (env.py:377-394) */
+    double *robot_state_seen;         /* [7][N] State.robot_state when state_delay > 0 (field order as above) */
+    double *control_queue;            /* [control_delay][2][N]  State.control_queue */
+    double *poses_queue;              /* [pose_delay][3][N]     State.poses_queue */
+    double *robot_state_queue;        /* [state_delay][7][N]    State.robot_state_queue */
 } bcp_state;
 
 /* per-step inputs/outputs, device pointers, N = n_envs */

@@ -43,7 +43,14 @@ class Params(C.Structure):
         ("spatial_precision", C.c_double),
         ("angular_precision", C.c_double),
         ("spatial_progress_multiplier", C.c_double),
+        ("reward_provider", C.c_int32),
+        ("control_delay", C.c_int32),
+        ("pose_delay", C.c_int32),
+        ("state_delay", C.c_int32),
     ]
+
+
+REWARD_CONTINUOUS, REWARD_PURE_PURSUIT = 0, 1
 
 
 class Batch(C.Structure):
@@ -67,6 +74,7 @@ class Batch(C.Structure):
         ("auto_reset", C.c_int32),
         ("init_st", _f64p * 7), ("init_min_dist", _f64p), ("init_target_idx", _i32p),
         ("geom", _i32p), ("next_geom", _i32p),
+        ("control_q", _f64p), ("pose_q", _f64p), ("state_q", _f64p), ("obs_pose", _f64p), ("obs_state", _f64p),
     ]
 
 
@@ -118,6 +126,9 @@ def lib():
                                              C.c_uint8, _u8p, _i32p, _f64p]
         L.bco_rotate_costmap.argtypes = [_u8p, C.c_int, C.c_int, C.c_double, C.c_uint8, _u8p]
         L.bco_goal_n_state.argtypes = [_f64p, _f64p, C.c_int, _f64p, _f64p, C.c_int, _f32p]
+        L.bco_reward_pure_pursuit.argtypes = [_f64p, _f64p, C.c_int, C.c_int, _f64p, _i32p]
+        L.bco_reward_pure_pursuit.restype = C.c_double
+        L.bco_initial_pure_pursuit_state.argtypes = [_f64p, C.c_int, _f64p, _i32p]
         L.bco_step_batch.argtypes = [C.POINTER(Params), C.POINTER(Batch), C.c_int]
         L.bco_step_batch.restype = C.c_int
         _lib = L
@@ -149,8 +160,11 @@ PLANENV_NOISE = (0.0, 0.0, 1.e-2, 1.e-2, 1.e-3, 1.e-3)  # envs/base/env.py:228-2
 
 def make_params(model="tricycle", dt=0.05, noise=None, iteration_timeout=1200, spatial_precision=1.0,
                 angular_precision=np.pi / 2, spatial_progress_multiplier=0.0, footprint=None, footprint_scale=1.0,
-                dynamic_model=True, model_front_column_pid=True):
+                dynamic_model=True, model_front_column_pid=True, reward_provider=REWARD_CONTINUOUS, control_delay=0,
+                pose_delay=0, state_delay=0):
     p = Params()
+    p.reward_provider = reward_provider
+    p.control_delay, p.pose_delay, p.state_delay = control_delay, pose_delay, state_delay
     p.model = MODEL_TRICYCLE if model == "tricycle" else MODEL_DIFFDRIVE
     fp = footprint if footprint is not None else (TRICYCLE_FOOTPRINT if model == "tricycle" else DIFFDRIVE_FOOTPRINT)
     fp = np.asarray(fp, dtype=np.float64) * footprint_scale
@@ -337,6 +351,14 @@ def reward(params, pose, path, min_dist, target_idx):
     return r, md.value, ti.value
 
 
+def initial_pure_pursuit_state(path):
+    path = _f64(path)
+    md = C.c_double()
+    ti = C.c_int32()
+    lib().bco_initial_pure_pursuit_state(_p(path, _f64p), path.shape[0], C.byref(md), C.byref(ti))
+    return md.value, ti.value
+
+
 def initial_reward_state(path, sp, ap):
     path = _f64(path)
     md = C.c_double()
@@ -387,14 +409,24 @@ class OracleBatch(object):
         self.collided_now = np.zeros(n, dtype=np.uint8)
         self.err = np.zeros(n, dtype=np.int32)
         self.init_st = None
+        # delays > 0: per-env FIFOs (AoS [n][delay][width]) and what State exposes (obs_pose [n,3], obs_state [n,7])
+        cd, pd, sd = params.control_delay, params.pose_delay, params.state_delay
+        self.control_q = np.zeros((n, max(cd, 1), 2)) if cd else None
+        self.pose_q = np.zeros((n, max(pd, 1), 3)) if pd else None
+        self.state_q = np.zeros((n, max(sd, 1), 7)) if sd else None
+        self.obs_pose = np.zeros((n, 3))
+        self.obs_state = np.zeros((n, 7))
 
     def reset_from_paths(self, initial_wheel_angle=0.0):
         """make_initial_state (envs/base/env.py:179-214): pose = path[0], v=w=0, reward state from the path."""
         sp, ap = self.params.spatial_precision, self.params.angular_precision
+        first_state = initial_reward_state
+        if self.params.reward_provider == REWARD_PURE_PURSUIT:
+            first_state = lambda path, _sp, _ap: initial_pure_pursuit_state(path)
         if self.geom is not None:
             # pool mode: one initial state per pool entry; every env starts on its entry's initial state
             g_n = self.paths.shape[0]
-            per = [initial_reward_state(self.paths[g, :self.lens[g]], sp, ap) for g in range(g_n)]
+            per = [first_state(self.paths[g, :self.lens[g]], sp, ap) for g in range(g_n)]
             self.init_st = [np.zeros(g_n) for _ in range(7)]
             for g in range(g_n):
                 self.init_st[0][g], self.init_st[1][g], self.init_st[2][g] = self.paths[g, 0]
@@ -406,7 +438,7 @@ class OracleBatch(object):
         for i in range(self.n):
             path = self.paths if self.shared_path else self.paths[i, :self.lens[i]]
             if i == 0 or not self.shared_path:
-                md, ti = initial_reward_state(path, sp, ap)
+                md, ti = first_state(path, sp, ap)
             self.st[0][i], self.st[1][i], self.st[2][i] = path[0]
             self.min_dist[i], self.target_idx[i] = md, ti
         for f in (3, 4, 5):
@@ -415,6 +447,8 @@ class OracleBatch(object):
         self.cur_iter[:] = 0
         self.cur_time[:] = 0.0
         self.collided[:] = 0
+        self.obs_pose[:] = np.stack(self.st[:3], axis=1)
+        self.obs_state[:] = np.stack(self.st, axis=1)
         self.snapshot_initial()
 
     def reset_all_to_geom(self, advance=False):
@@ -428,6 +462,8 @@ class OracleBatch(object):
         self.cur_iter[:] = 0
         self.cur_time[:] = 0.0
         self.collided[:] = 0
+        self.obs_pose[:] = np.stack(self.st[:3], axis=1)
+        self.obs_state[:] = np.stack(self.st, axis=1)
 
     def snapshot_initial(self):
         self.init_st = [a.copy() for a in self.st]
@@ -468,6 +504,11 @@ class OracleBatch(object):
         b.collided_now = _p(self.collided_now, _u8p)
         b.err = _p(self.err, _i32p)
         b.auto_reset = int(auto_reset)
+        b.control_q = _p(self.control_q, _f64p) if self.control_q is not None else None
+        b.pose_q = _p(self.pose_q, _f64p) if self.pose_q is not None else None
+        b.state_q = _p(self.state_q, _f64p) if self.state_q is not None else None
+        b.obs_pose = _p(self.obs_pose, _f64p)
+        b.obs_state = _p(self.obs_state, _f64p)
         if self.geom is not None:
             b.geom = _p(self.geom, _i32p)
             b.next_geom = _p(self.next_geom, _i32p) if self.next_geom is not None else None

@@ -557,6 +557,104 @@ int bco_env_step(const bco_params *p, double st[7], double *min_dist, int32_t *t
     return err;
 }
 
+/* envs/base/reward.py:125-139, 330-353 */
+double bco_reward_pure_pursuit(const double pose[3], const double *path, int m, int collided, double *min_dist,
+                               int32_t *target_idx)
+{
+    /* update_goal(pose, radius=2.): first way point from target_idx on that is more than 2 m away.
+     * np.linalg.norm of a 2-vector is sqrt(dot(x, x)); numpy's dot runs through OpenBLAS ddot, whose two-element
+     * tail is fma-contracted (same observation as for the footprint rotation, bco_footprint_vertices). */
+    int found = m - 1;
+    for (int i = *target_idx; i < m; ++i) {
+        double dx = path[3 * i] - pose[0], dy = path[3 * i + 1] - pose[1];
+        if (sqrt(fma(dy, dy, dx * dx)) > 2.) {
+            found = i;
+            break;
+        }
+    }
+    *target_idx = found;
+    double reward = -0.05;
+    const double *g = path + 3 * (m - 1); /* current_goal_pose() is the LAST way point (:115-120) */
+    double dist = hypot(g[0] - pose[0], g[1] - pose[1]);
+    reward += *min_dist - dist;
+    *min_dist = dist;
+    if (collided) reward -= 100;
+    return reward;
+}
+
+/* envs/base/reward.py:355-371 */
+void bco_initial_pure_pursuit_state(const double *path, int m, double *min_dist, int32_t *target_idx)
+{
+    const double *g = path + 3 * (m - 1);
+    *target_idx = 1;
+    *min_dist = hypot(g[0] - path[0], g[1] - path[1]);
+}
+
+/* _get_element_from_list_with_delay (env.py:27-49) for the k-th push since reset */
+static void fifo_delay(double *q, int width, int delay, int k, const double *elem, double *out)
+{
+    if (delay <= 0) {
+        for (int c = 0; c < width; ++c) out[c] = elem[c];
+        return;
+    }
+    double first[8];
+    int slot = (k - 1) % delay;
+    if (k <= delay) { /* the list is not longer than `delay` yet: append, hand back element 1 */
+        for (int c = 0; c < width; ++c) q[slot * width + c] = elem[c];
+        for (int c = 0; c < width; ++c) out[c] = q[c];
+    } else { /* pop(0): element k - delay, whose slot the new element takes */
+        for (int c = 0; c < width; ++c) first[c] = q[slot * width + c];
+        for (int c = 0; c < width; ++c) q[slot * width + c] = elem[c];
+        for (int c = 0; c < width; ++c) out[c] = first[c];
+    }
+}
+
+/* envs/base/env.py:334-361 + :363-398 with delays and either reward provider */
+int bco_env_step_ex(const bco_params *p, double st[7], bco_delay_state *d, double *min_dist, int32_t *target_idx,
+                    int32_t *cur_iter, double *cur_time, uint8_t *collided_sticky, const double cmd[2], const double z[3],
+                    const uint8_t *map, int rows, int cols, const double origin[2], double res, const double *path, int m,
+                    double *reward, uint8_t *done, uint8_t *collided_now, int *drawn)
+{
+    const int k = *cur_iter + 1;
+    double action[2], pose[3], seen_pose[3], seen_state[7];
+    fifo_delay(d ? d->control_q : NULL, 2, p->control_delay, k, cmd, action); /* :371 */
+    double old[3] = {st[0], st[1], st[2]};
+    int err = bco_robot_step(p, st, action, z, drawn);
+    int col = bco_pose_collides(st[0], st[1], st[2], &p->verts[0][0], p->n_verts, map, rows, cols, origin, res);
+    if (col) {
+        st[0] = old[0];
+        st[1] = old[1];
+        st[2] = old[2];
+        st[3] = 0.0;
+        st[4] = 0.0;
+    }
+    pose[0] = st[0];
+    pose[1] = st[1];
+    pose[2] = st[2];
+    fifo_delay(d ? d->pose_q : NULL, 3, p->pose_delay, k, pose, seen_pose);  /* :377-380 */
+    *cur_time = *cur_time + p->dt;
+    *cur_iter = *cur_iter + 1;
+    fifo_delay(d ? d->state_q : NULL, 7, p->state_delay, k, st, seen_state); /* :385-389 */
+    *collided_sticky = (uint8_t)(*collided_sticky || col);
+    if (d && d->obs_pose)
+        for (int c = 0; c < 3; ++c) d->obs_pose[c] = seen_pose[c];
+    if (d && d->obs_state)
+        for (int c = 0; c < 7; ++c) d->obs_state[c] = seen_state[c];
+    int goal;
+    if (p->reward_provider == BCO_REWARD_PURE_PURSUIT) {
+        *reward = bco_reward_pure_pursuit(seen_pose, path, m, *collided_sticky, min_dist, target_idx);
+        const double *g = path + 3 * (m - 1); /* done(): within 1 m of the last way point (reward.py:141-150) */
+        goal = hypot(g[0] - seen_pose[0], g[1] - seen_pose[1]) < 1.0;
+    } else {
+        *reward = bco_reward(p, seen_pose, path, m, min_dist, target_idx);
+        goal = *target_idx > m - 1;
+    }
+    int timed_out = *cur_iter >= p->iteration_timeout;
+    *done = (uint8_t)(goal || timed_out || *collided_sticky);
+    if (collided_now) *collided_now = (uint8_t)col;
+    return err;
+}
+
 /* ---- egocentric observation ---------------------------------------------------------------------------- */
 /* cv::getRotationMatrix2D (opencv imgproc imgwarp.cpp) */
 void bco_rotation_matrix_2d(double cx, double cy, double angle_deg, double scale, double M[6])
@@ -714,9 +812,16 @@ static void *batch_worker(void *arg)
         const double *z = b->z ? b->z + 3 * i : NULL;
         double cur_time = b->cur_time ? b->cur_time[i] : 0.0;
         uint8_t cn = 0;
-        int err = bco_env_step(p, st, &b->min_dist[i], &b->target_idx[i], &b->cur_iter[i], &cur_time, &b->collided[i],
-                               cmd, z, map, rows, cols, origin, b->resolution, path, m, &b->reward[i], &b->done[i],
-                               &cn, NULL);
+        bco_delay_state d = {
+            b->control_q ? b->control_q + (size_t)i * p->control_delay * 2 : NULL,
+            b->pose_q ? b->pose_q + (size_t)i * p->pose_delay * 3 : NULL,
+            b->state_q ? b->state_q + (size_t)i * p->state_delay * 7 : NULL,
+            b->obs_pose ? b->obs_pose + (size_t)i * 3 : NULL,
+            b->obs_state ? b->obs_state + (size_t)i * 7 : NULL,
+        };
+        int err = bco_env_step_ex(p, st, &d, &b->min_dist[i], &b->target_idx[i], &b->cur_iter[i], &cur_time,
+                                  &b->collided[i], cmd, z, map, rows, cols, origin, b->resolution, path, m, &b->reward[i],
+                                  &b->done[i], &cn, NULL);
         if (b->collided_now) b->collided_now[i] = cn;
         if (b->err) b->err[i] = err;
         if (b->auto_reset && b->done[i]) {
@@ -730,6 +835,11 @@ static void *batch_worker(void *arg)
             b->cur_iter[i] = 0;
             b->collided[i] = 0;
             cur_time = 0.0;
+            /* the restored State exposes the initial pose / robot state and empty queues (k restarts at 1) */
+            if (b->obs_pose)
+                for (int c = 0; c < 3; ++c) b->obs_pose[(size_t)i * 3 + c] = st[c];
+            if (b->obs_state)
+                for (int c = 0; c < 7; ++c) b->obs_state[(size_t)i * 7 + c] = st[c];
         }
         if (b->cur_time) b->cur_time[i] = cur_time;
         for (int f = 0; f < 7; ++f) b->st[f][i] = st[f];

@@ -63,7 +63,24 @@ typedef struct bco_params {
     double spatial_precision;
     double angular_precision;
     double spatial_progress_multiplier;
+    /* SURVEY 8(f) row 4 */
+    int32_t reward_provider;     /* BCO_REWARD_*: EnvParams.reward_provider_name (params.py:33) */
+    int32_t control_delay;       /* EnvParams.control_delay / pose_delay / state_delay (params.py:28-30) */
+    int32_t pose_delay;
+    int32_t state_delay;
 } bco_params;
+
+enum { BCO_REWARD_CONTINUOUS = 0, BCO_REWARD_PURE_PURSUIT = 1 };
+
+/* Per-env FIFO state of _get_element_from_list_with_delay (env.py:27-49).  The k-th element pushed since the last
+ * reset (k = 1, 2, ...) lives in slot (k - 1) % delay of its queue; k is current_iter + 1 at the time of the push. */
+typedef struct bco_delay_state {
+    double *control_q; /* [control_delay][2] */
+    double *pose_q;    /* [pose_delay][3] */
+    double *state_q;   /* [state_delay][7] */
+    double *obs_pose;  /* [3]  State.pose: what the reward provider and the observation see */
+    double *obs_state; /* [7]  State.robot_state of the observation */
+} bco_delay_state;
 
 /* ---- scalar utilities -------------------------------------------------------------- */
 double bco_normalize_angle(double z);                 /* coordinate_transformations.py:28-36 */
@@ -117,12 +134,25 @@ double bco_reward(const bco_params *p, const double pose[3], const double *path,
 /* ContinuousRewardProvider.generate_initial_state reward.py:261-288. returns 0, or -1 for ValueError */
 int bco_initial_reward_state(const double *path, int m, double sp, double ap, double *min_dist, int32_t *target_idx);
 
+/* ContinuousRewardPurePursuitProvider.reward (reward.py:330-353) incl. update_goal (:125-139); mutates the state */
+double bco_reward_pure_pursuit(const double pose[3], const double *path, int m, int collided, double *min_dist,
+                               int32_t *target_idx);
+/* ContinuousRewardPurePursuitProvider.generate_initial_state (reward.py:355-371) */
+void bco_initial_pure_pursuit_state(const double *path, int m, double *min_dist, int32_t *target_idx);
+
 /* ---- full step --------------------------------------------------------------------- */
 /* One PlanEnv.step (env.py:334-361, delays 0) for ONE env.  Returns BCO_ERR_*. */
 int bco_env_step(const bco_params *p, double st[7], double *min_dist, int32_t *target_idx, int32_t *cur_iter,
                  double *cur_time, uint8_t *collided_sticky, const double cmd[2], const double z[3],
                  const uint8_t *map, int rows, int cols, const double origin[2], double resolution,
                  const double *path, int m, double *reward, uint8_t *done, uint8_t *collided_now, int *drawn);
+
+/* The same with EnvParams' delays and reward provider honoured (p->*_delay, p->reward_provider); `d` may be NULL when
+ * all delays are 0.  st is the robot's TRUE state; d->obs_pose / d->obs_state receive what State exposes. */
+int bco_env_step_ex(const bco_params *p, double st[7], bco_delay_state *d, double *min_dist, int32_t *target_idx,
+                    int32_t *cur_iter, double *cur_time, uint8_t *collided_sticky, const double cmd[2], const double z[3],
+                    const uint8_t *map, int rows, int cols, const double origin[2], double resolution,
+                    const double *path, int m, double *reward, uint8_t *done, uint8_t *collided_now, int *drawn);
 
 /* ---- egocentric observation -------------------------------------------------------- */
 /* cv2.getRotationMatrix2D(center, angle_deg, scale): center is a Point2f (float32), everything else float64. */
@@ -173,6 +203,8 @@ typedef struct bco_batch {
     int32_t auto_reset;
     const double *init_st[7]; const double *init_min_dist; const int32_t *init_target_idx;
     int32_t *geom; const int32_t *next_geom;
+    /* delays > 0 (all optional): AoS per env, [n][delay][width] queues and [n][3] / [n][7] observed pose / state */
+    double *control_q, *pose_q, *state_q, *obs_pose, *obs_state;
 } bco_batch;
 int bco_step_batch(const bco_params *p, const bco_batch *b, int threads);
 

@@ -492,6 +492,73 @@ def gen_mini_geometry():
          init=np.array(init))
 
 
+def record_delayed(env, plan_env, n_steps, action_seed, noise_seed, speed=1.0):
+    """Like record_trajectory, for envs with delays / the pure-pursuit provider: the robot's true state and what the
+    State / Observation expose are recorded separately."""
+    from bc_gym_planning_env.robot_models import differential_drive as dd
+    from bc_gym_planning_env.envs.base import spaces
+    spaces.SPACE_LOCAL_RANDOM_STATE.seed(action_seed)
+    state0 = plan_env.get_state()
+    rec = dict(
+        costmap=state0.costmap.get_data().copy(), origin=np.array(state0.costmap.get_origin()),
+        resolution=np.float64(state0.costmap.get_resolution()),
+        path=np.array(state0.reward_provider_state.path), init_target_idx=np.int32(state0.reward_provider_state.target_idx),
+        init_min_dist=np.float64(state0.reward_provider_state.min_spat_dist_so_far),
+        init_state=tri_state_vec(state0.robot_state),
+    )
+    act, z, true_st, seen_pose, seen_st = [], [], [], [], []
+    rew, done, coll, tidx, mind, plen = [], [], [], [], [], []
+    with SlotTap(dd, noise_seed) as tap:
+        for t in range(n_steps):
+            a = env.action_space.sample()
+            a = type(a)(command=np.array([a.command[0] * speed, a.command[1]]))
+            act.append(np.asarray(a.command, dtype=np.float64))
+            obs, r, d, _ = env.step(a)
+            z.append(tap.take())
+            s = plan_env._state
+            true_st.append(tri_state_vec(plan_env._robot.get_state()))
+            seen_pose.append(np.array(obs.pose, dtype=np.float64))
+            seen_st.append(tri_state_vec(obs.robot_state))
+            assert (np.asarray(s.pose) == obs.pose).all()
+            rew.append(r); done.append(d); coll.append(s.robot_collided)
+            tidx.append(s.reward_provider_state.target_idx)
+            mind.append(s.reward_provider_state.min_spat_dist_so_far)
+            plen.append(len(obs.path))
+    rec.update(actions=np.stack(act), z=np.stack(z), true_states=np.stack(true_st), seen_pose=np.stack(seen_pose),
+               seen_states=np.stack(seen_st), reward=np.array(rew, dtype=np.float64), done=np.array(done, dtype=np.uint8),
+               collided=np.array(coll, dtype=np.uint8), target_idx=np.array(tidx, dtype=np.int32),
+               min_dist=np.array(mind, dtype=np.float64), obs_path_len=np.array(plen, dtype=np.int32))
+    return rec
+
+
+def gen_delays_and_pure_pursuit():
+    """G11: EnvParams delays > 0 (env.py:27-49, 363-398) and the pure-pursuit reward provider (reward.py:78-159, 291-371)."""
+    from bc_gym_planning_env.envs.mini_env import RandomMiniEnv, RandomMiniEnvParams
+    from bc_gym_planning_env.envs.synth_turn_env import AisleTurnEnv, AisleTurnEnvParams
+    from bc_gym_planning_env.envs.base.params import EnvParams
+    cases = [
+        ("delay_p1s1", dict(pose_delay=1, state_delay=1), 2, 1.0),          # the runner scripts' setting
+        ("delay_c2p3s1", dict(control_delay=2, pose_delay=3, state_delay=1), 4, 1.0),
+        ("delay_c1_wall", dict(control_delay=1, pose_delay=2, state_delay=2), 9, 3.0),   # drives into the wall
+    ]
+    for tag, kw, seed, speed in cases:
+        params = RandomMiniEnvParams(env_params=EnvParams(goal_ang_dist=np.pi / 8., goal_spat_dist=0.2, **kw))
+        env = RandomMiniEnv(params=params, rng=np.random.RandomState(seed), draw_new_turn_on_reset=False)
+        rec = record_delayed(env, env._env, 300, 500 + seed, 600 + seed, speed)
+        rec.update(control_delay=np.int32(kw.get("control_delay", 0)), pose_delay=np.int32(kw.get("pose_delay", 0)),
+                   state_delay=np.int32(kw.get("state_delay", 0)), pure_pursuit=np.int32(0))
+        save("g11_traj_%s.npz" % tag, **rec)
+    for tag, kw, speed in (("pp", dict(), 2.0), ("pp_delay", dict(pose_delay=1, control_delay=1), 3.0)):
+        ep = EnvParams(reward_provider_name='continuous_reward_pure_pursuit', **kw)
+        env = AisleTurnEnv(AisleTurnEnvParams(env_params=ep))
+        rec = record_delayed(env, env, 400, 700, 701, speed)
+        rec.update(control_delay=np.int32(kw.get("control_delay", 0)), pose_delay=np.int32(kw.get("pose_delay", 0)),
+                   state_delay=np.int32(kw.get("state_delay", 0)), pure_pursuit=np.int32(1))
+        save("g11_traj_%s.npz" % tag, **rec)
+        print("   %s: reward range %.3f .. %.3f, collided %d, done at %s" % (
+            tag, rec["reward"].min(), rec["reward"].max(), rec["collided"].sum(), np.argmax(rec["done"])))
+
+
 def gen_egocentric():
     """G10: EgocentricCostmap(env).step observations (envs/egocentric.py:102-160) along sampled-action trajectories:
     the 133 x 117 egocentric costmap and the goal_n_state vector, with the state they were computed from."""
@@ -541,6 +608,7 @@ def main():
     gen_kat_collision_table()
     gen_mini_geometry()
     gen_egocentric()
+    gen_delays_and_pure_pursuit()
     gen_diffdrive_trajectories()
     gen_trajectories()
 

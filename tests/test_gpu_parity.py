@@ -27,7 +27,7 @@ def load(name):
 def test_native_library_is_loaded(torch_cuda):
     from bc_gym_planning_env_amd import _lib
     L = _lib.load()
-    assert L.bcp_abi_version() == 1
+    assert L.bcp_abi_version() == _lib.ABI_VERSION == 2
     with open("/proc/self/maps") as f:
         assert "libbcplan.so" in f.read()
 

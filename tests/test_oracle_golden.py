@@ -177,3 +177,36 @@ def test_g10_egocentric_observation(oracle, golden_dir, name):
         rs = np.array([st[0], st[1], st[2], st[3], st[4], st[6]])
         vec = oracle.goal_n_state(st[:3], g["path"][g["target_idx"][t]:], world, rs)
         np.testing.assert_allclose(vec, g["goal_n_state"][t], rtol=0, atol=1e-6)
+
+
+# ---- G11: delays > 0 and the pure-pursuit reward provider (env.py:27-49, 363-398; reward.py:78-159, 291-371) ----
+G11 = ["g11_traj_delay_p1s1.npz", "g11_traj_delay_c2p3s1.npz", "g11_traj_delay_c1_wall.npz", "g11_traj_pp.npz",
+       "g11_traj_pp_delay.npz"]
+
+
+def oracle_env_for_g11(oracle, g, n=1):
+    mini = int(g["pure_pursuit"]) == 0
+    p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE,
+                           spatial_precision=0.2 if mini else 1.0, angular_precision=np.pi / 8 if mini else np.pi / 2,
+                           reward_provider=int(g["pure_pursuit"]), control_delay=int(g["control_delay"]),
+                           pose_delay=int(g["pose_delay"]), state_delay=int(g["state_delay"]))
+    ref = oracle.OracleBatch(p, n, g["costmap"], g["origin"], float(g["resolution"]), g["path"])
+    ref.reset_from_paths()
+    return ref
+
+
+@pytest.mark.parametrize("name", G11)
+def test_g11_delays_and_pure_pursuit(oracle, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name))
+    ref = oracle_env_for_g11(oracle, g)
+    assert ref.target_idx[0] == int(g["init_target_idx"]) and ref.min_dist[0] == float(g["init_min_dist"])
+    assert (np.array([a[0] for a in ref.st]) == g["init_state"]).all()
+    for t in range(len(g["actions"])):
+        z = np.where(np.isnan(g["z"][t]), 1e300, g["z"][t])[None]
+        ref.step(g["actions"][t][None], z)
+        assert (np.array([a[0] for a in ref.st]) == g["true_states"][t]).all(), (name, t)
+        assert (ref.obs_pose[0] == g["seen_pose"][t]).all(), (name, t)
+        assert (ref.obs_state[0] == g["seen_states"][t]).all(), (name, t)
+        assert ref.reward[0] == g["reward"][t], (name, t, ref.reward[0], g["reward"][t])
+        assert ref.done[0] == g["done"][t] and ref.collided[0] == g["collided"][t], (name, t)
+        assert ref.target_idx[0] == g["target_idx"][t] and ref.min_dist[0] == g["min_dist"][t], (name, t)
