@@ -70,6 +70,7 @@ SYMBOLS = {
     "bcp_bind_state": (C.c_int, [_H, C.POINTER(BcpState)]),
     "bcp_bind_initial_state": (C.c_int, [_H, C.POINTER(BcpState)]),
     "bcp_reset_masked": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "bcp_broadcast_state": (C.c_int, [_H, C.c_int64, C.c_void_p, C.c_void_p]),
     "bcp_step": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_void_p]),
     "bcp_robot_step": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcp_pose_collides": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

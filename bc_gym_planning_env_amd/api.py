@@ -19,7 +19,26 @@ import numpy as np
 
 INDUSTRIAL_TRICYCLE_V1 = 'industrial_tricycle_v1'
 INDUSTRIAL_DIFFDRIVE_V1 = 'industrial_diffdrive_v1'
+class Serializable(object):
+    """utilities/serialize.py:8-33: render to / rebuild from a dict of basic types (int, float, np.ndarray, ...)"""
+    VERSION = 1
+
+    @classmethod
+    def deserialize(cls, state):
+        state = dict(state)
+        ver = state.pop('version')
+        assert ver == cls.VERSION
+        return cls(**state)
+
+    def serialize(self):
+        state = attr.asdict(self)
+        state['version'] = self.VERSION
+        return state
+
+
 CONTINUOUS_REWARD = 'continuous_reward'
+CONTINUOUS_REWARD_STATE = 'continuous_reward_state'
+CONTINUOUS_REWARD_PURE_PURSUIT_STATE = 'continuous_reward_pure_pursuit_state'
 CONTINUOUS_REWARD_PURE_PURSUIT = 'continuous_reward_pure_pursuit'
 
 
@@ -90,6 +109,15 @@ class CostMap2D(object):
     def copy(self):
         return CostMap2D(self._data.copy(), self._resolution, self._origin.copy())
 
+    def get_state(self):
+        """utilities/costmap_2d.py:150-160"""
+        return dict(version=1, data=self._data, resolution=self._resolution, origin=self._origin)
+
+    @classmethod
+    def from_state(cls, state):
+        assert state['version'] == 1
+        return cls(state['data'], state['resolution'], state['origin'])
+
     def __eq__(self, other):
         return (isinstance(other, CostMap2D) and self._resolution == other.get_resolution()
                 and (self._origin == other.get_origin()).all() and self._data.shape == other.get_data().shape
@@ -100,7 +128,7 @@ class CostMap2D(object):
 
 
 @attr.s
-class TricycleRobotState(object):
+class TricycleRobotState(Serializable):
     x = attr.ib(default=0.0, type=float)
     y = attr.ib(default=0.0, type=float)
     angle = attr.ib(default=0.0, type=float)
@@ -133,7 +161,7 @@ class TricycleRobotState(object):
 
 
 @attr.s
-class DiffdriveRobotState(object):
+class DiffdriveRobotState(Serializable):
     x = attr.ib(default=0.0, type=float)
     y = attr.ib(default=0.0, type=float)
     angle = attr.ib(default=0.0, type=float)
@@ -161,7 +189,9 @@ class DiffdriveRobotState(object):
 
 
 @attr.s(eq=False)
-class ContinuousRewardProviderState(object):
+class ContinuousRewardProviderState(Serializable):
+    reward_provider_state_type_name = CONTINUOUS_REWARD_STATE
+
     min_spat_dist_so_far = attr.ib(type=float)
     path = attr.ib(type=np.ndarray)
     target_idx = attr.ib(type=int)
@@ -189,7 +219,9 @@ class ContinuousRewardProviderState(object):
 
 
 @attr.s(eq=False)
-class ContinuousRewardPurePursuitProviderState(object):
+class ContinuousRewardPurePursuitProviderState(Serializable):
+    reward_provider_state_type_name = CONTINUOUS_REWARD_PURE_PURSUIT_STATE
+
     """envs/base/reward.py:76-159: the goal is always the last way point, target_idx the look-ahead way point"""
     min_spat_dist_so_far = attr.ib(type=float)
     path = attr.ib(type=np.ndarray)
@@ -223,8 +255,8 @@ class Observation(object):
 
 
 @attr.s(eq=False)
-class State(object):
-    """Full per-env state, field for field the reference's State (delays 0 => the three queues are empty)."""
+class State(Serializable):
+    """Full per-env state, field for field the reference's State (envs/base/env.py:52-176)."""
     reward_provider_state = attr.ib(type=object)
     path = attr.ib(type=np.ndarray)
     original_path = attr.ib(type=np.ndarray)
@@ -242,8 +274,61 @@ class State(object):
     def copy(self):
         return attr.evolve(self, reward_provider_state=self.reward_provider_state.copy(), path=np.copy(self.path),
                            pose=np.copy(self.pose), original_path=np.copy(self.original_path),
-                           costmap=self.costmap.copy(), poses_queue=[], robot_state_queue=[], control_queue=[],
-                           robot_state=self.robot_state.copy())
+                           costmap=self.costmap.copy(), poses_queue=[np.copy(p) for p in self.poses_queue],
+                           robot_state_queue=[r.copy() for r in self.robot_state_queue],
+                           control_queue=list(self.control_queue), robot_state=self.robot_state.copy())
+
+    def serialize(self):
+        """envs/base/env.py:163-176"""
+        resu = attr.asdict(self, recurse=False)
+        resu['version'] = self.VERSION
+        resu['costmap'] = self.costmap.get_state()
+        resu['reward_provider_state_type_name'] = self.reward_provider_state.reward_provider_state_type_name
+        resu['reward_provider_state'] = self.reward_provider_state.serialize()
+        resu['robot_type_name'] = self.robot_state.get_robot_type_name()
+        resu['robot_state'] = self.robot_state.serialize()
+        resu['robot_state_queue'] = [r.serialize() for r in self.robot_state_queue]
+        resu['control_queue'] = [np.asarray(a.command) for a in self.control_queue]
+        return resu
+
+    @classmethod
+    def deserialize(cls, state):
+        """envs/base/env.py:135-161 (the reference writes 'reward_provider_state_type_name' and reads
+        'reward_provider_state_name'; both spellings are accepted here)"""
+        state = dict(state)
+        assert state.pop('version') == cls.VERSION
+        state['costmap'] = CostMap2D.from_state(state['costmap'])
+        kind = state.pop('reward_provider_state_type_name', None) or state.pop('reward_provider_state_name')
+        rp_cls = {CONTINUOUS_REWARD_STATE: ContinuousRewardProviderState,
+                  CONTINUOUS_REWARD_PURE_PURSUIT_STATE: ContinuousRewardPurePursuitProviderState}[kind]
+        state['reward_provider_state'] = rp_cls.deserialize(state['reward_provider_state'])
+        rs_cls = {INDUSTRIAL_TRICYCLE_V1: TricycleRobotState, INDUSTRIAL_DIFFDRIVE_V1: DiffdriveRobotState}[
+            state.pop('robot_type_name')]
+        state['robot_state'] = rs_cls.deserialize(state['robot_state'])
+        state['robot_state_queue'] = [rs_cls.deserialize(r) for r in state['robot_state_queue']]
+        state['control_queue'] = [Action(command=np.asarray(c)) for c in state['control_queue']]
+        return cls(**state)
+
+    def __eq__(self, other):
+        if not isinstance(other, State):
+            return False
+        same_arrays = all((np.asarray(a) == np.asarray(b)).all() and np.shape(a) == np.shape(b) for a, b in (
+            (self.path, other.path), (self.original_path, other.original_path), (self.pose, other.pose)))
+        queues = (len(self.poses_queue) == len(other.poses_queue)
+                  and all((np.asarray(a) == np.asarray(b)).all() for a, b in zip(self.poses_queue, other.poses_queue))
+                  and self.robot_state_queue == other.robot_state_queue
+                  and len(self.control_queue) == len(other.control_queue)
+                  and all((np.asarray(a.command) == np.asarray(b.command)).all()
+                          for a, b in zip(self.control_queue, other.control_queue)))
+        return (same_arrays and queues and self.reward_provider_state == other.reward_provider_state
+                and self.costmap == other.costmap and self.iter_timeout == other.iter_timeout
+                and self.current_time == other.current_time and self.current_iter == other.current_iter
+                and self.robot_collided == other.robot_collided and self.robot_state == other.robot_state)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
 
 
 _SPACE_RNG = np.random.RandomState(0)  # module-level stream seeded 0, as envs/base/spaces.py:9-10

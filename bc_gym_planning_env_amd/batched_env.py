@@ -57,10 +57,27 @@ class BatchedState(object):
         self.poses_queue = poses_queue                  # [pose_delay, 3, N]
         self.robot_state_queue = robot_state_queue      # [state_delay, 7, N]
 
+    FIELDS = ("robot", "min_spat_dist_so_far", "target_idx", "current_iter", "robot_collided") + DELAY_FIELDS
+    VERSION = 1
+
     def copy(self):
         extra = {k: (getattr(self, k).clone() if getattr(self, k) is not None else None) for k in self.DELAY_FIELDS}
         return BatchedState(self.robot.clone(), self.min_spat_dist_so_far.clone(), self.target_idx.clone(),
                             self.current_iter.clone(), self.robot_collided.clone(), **extra)
+
+    def serialize(self):
+        """Basic python types only (dict of numpy arrays + version), as the reference's Serializable objects
+        (utilities/serialize.py): picklable, device independent."""
+        out = {k: (getattr(self, k).cpu().numpy() if getattr(self, k) is not None else None) for k in self.FIELDS}
+        out['version'] = self.VERSION
+        return out
+
+    @classmethod
+    def deserialize(cls, state, device="cpu"):
+        state = dict(state)
+        assert state.pop('version') == cls.VERSION
+        return cls(**{k: (torch.from_numpy(np.ascontiguousarray(v)).to(device) if v is not None else None)
+                      for k, v in state.items()})
 
 
 class BatchedObservation(object):
@@ -484,7 +501,11 @@ class BatchedPlanEnv(object):
         return self._obs
 
     def get_state(self):
-        return self.state.copy()
+        """Snapshot of every env's state (device tensors); with a geometry pool the entries the envs are on ride
+        along as `.geom_of_env`."""
+        snap = self.state.copy()
+        snap.geom_of_env = self.geom_of_env.clone() if self.geom_of_env is not None else None
+        return snap
 
     def set_state(self, state):
         s = self.state
@@ -496,6 +517,18 @@ class BatchedPlanEnv(object):
         for name in BatchedState.DELAY_FIELDS:
             if getattr(s, name) is not None:
                 getattr(s, name).copy_(getattr(state, name))
+        if self.geom_of_env is not None and getattr(state, "geom_of_env", None) is not None:
+            self.geom_of_env.copy_(state.geom_of_env)
+
+    def fan_out(self, src, mask=None):
+        """Monte-Carlo fan-out (reference README, 'Statefullness of the env'): every env (or those with mask[i] != 0)
+        takes over env `src`'s complete state -- the batched `s = env.get_state(); others.set_state(s)`."""
+        ptr = None
+        if mask is not None:
+            mask = mask.to(self.device).to(torch.uint8).contiguous()
+            ptr = mask.data_ptr()
+        _lib.check(self._lib.bcp_broadcast_state(self._h, int(src), ptr, self._stream()))
+        self._last_mask = mask
 
     def step(self, actions, noise_z=None, noise_z_out=None):
         """One tick for every env.  actions: [N,2] (float32 or float64) tensor / array, or a list of Action.

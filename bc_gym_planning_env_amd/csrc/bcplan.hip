@@ -941,6 +941,39 @@ __global__ void reset_kernel(DevState st, DevState init, const uint8_t* __restri
     }
 }
 
+// Monte-Carlo fan-out: env `src`'s complete state copied into every selected env
+__global__ void broadcast_state_kernel(DevState st, int32_t* __restrict__ geom_of_env, const uint8_t* __restrict__ mask,
+                                       int64_t n, int64_t src, int tri, int control_delay, int pose_delay, int state_delay)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || i == src) return;
+    if (mask && !mask[i]) return;
+    st.x[i] = st.x[src];
+    st.y[i] = st.y[src];
+    st.angle[i] = st.angle[src];
+    st.v[i] = st.v[src];
+    st.w[i] = st.w[src];
+    if (tri) {
+        st.steer[i] = st.steer[src];
+        st.wheel[i] = st.wheel[src];
+    }
+    st.min_dist[i] = st.min_dist[src];
+    st.target_idx[i] = st.target_idx[src];
+    st.cur_iter[i] = st.cur_iter[src];
+    st.collided[i] = st.collided[src];
+    if (geom_of_env) geom_of_env[i] = geom_of_env[src];
+    if (st.pose_seen)
+        for (int c = 0; c < 3; ++c) st.pose_seen[c * n + i] = st.pose_seen[c * n + src];
+    if (st.state_seen)
+        for (int c = 0; c < 7; ++c) st.state_seen[c * n + i] = st.state_seen[c * n + src];
+    if (st.control_q)
+        for (int c = 0; c < 2 * control_delay; ++c) st.control_q[c * n + i] = st.control_q[c * n + src];
+    if (st.pose_q)
+        for (int c = 0; c < 3 * pose_delay; ++c) st.pose_q[c * n + i] = st.pose_q[c * n + src];
+    if (st.state_q)
+        for (int c = 0; c < 7 * state_delay; ++c) st.state_q[c * n + i] = st.state_q[c * n + src];
+}
+
 __global__ void __launch_bounds__(kBlock) robot_step_kernel(DevParams P, double* __restrict__ st7, int64_t n,
                                                             const double* __restrict__ actions,
                                                             const double* __restrict__ noise_z, int32_t* __restrict__ err)
@@ -2036,6 +2069,21 @@ extern "C" int bcp_reset_masked(bcp_handle* h, const uint8_t* mask, void* stream
     const int blocks = (int)((h->n + threads - 1) / threads);
     hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, h->st, h->init, mask, h->n,
                        (int)(h->params.model == BCP_MODEL_TRICYCLE), h->geom_of_env, h->next_geom);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+extern "C" int bcp_broadcast_state(bcp_handle* h, int64_t src, const uint8_t* mask, void* stream)
+{
+    if (!h) return fail(BCP_E_INVALID, "bcp_broadcast_state: null handle");
+    if (!h->have_state) return fail(BCP_E_STATE, "bcp_broadcast_state: state not bound");
+    if (src < 0 || src >= h->n) return fail(BCP_E_INVALID, "bcp_broadcast_state: source env %lld of %lld", (long long)src,
+                                            (long long)h->n);
+    HIP_TRY(hipSetDevice(h->device));
+    const bcp_params& p = h->params;
+    hipLaunchKernelGGL(broadcast_state_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->st,
+                       h->n_geoms > 0 ? h->geom_of_env : nullptr, mask, h->n, src, (int)(p.model == BCP_MODEL_TRICYCLE),
+                       p.control_delay, p.pose_delay, p.state_delay);
     HIP_TRY(hipGetLastError());
     return BCP_OK;
 }

@@ -190,6 +190,11 @@ int bcp_bind_initial_state(bcp_handle *h, const bcp_state *initial /*host struct
 /* PlanEnv.reset (env.py:293-303) for every env with mask[i] != 0 (mask NULL = all). */
 int bcp_reset_masked(bcp_handle *h, const uint8_t *mask, void *stream);
 
+/* Monte-Carlo fan-out ("you need to run many rollouts from one state", README.md:45-61): every env with mask[i] != 0
+ * (mask NULL = all) takes over env `src`'s complete state -- robot, reward provider, iteration counter, collision
+ * flag, geometry-pool entry, delay queues.  The batched form of `s = env.get_state(); other.set_state(s)`. */
+int bcp_broadcast_state(bcp_handle *h, int64_t src, const uint8_t *mask, void *stream);
+
 /* ---- the hot path ------------------------------------------------------------------------------------- */
 /* PlanEnv.step (env.py:334-361) for all envs: one fused kernel launch. */
 int bcp_step(bcp_handle *h, const bcp_step_io *io /*host struct*/, uint32_t flags, void *stream);

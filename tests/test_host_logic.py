@@ -121,3 +121,28 @@ def test_env_block_partition():
         blocks = [env_block(n, r, w) for r in range(w)]
         assert sum(c for _, c in blocks) == n
         assert all(blocks[r][0] + blocks[r][1] == blocks[r + 1][0] for r in range(w - 1))
+
+
+def test_state_serialization_round_trip():
+    """State / robot state / reward-provider state / costmap render to basic types and back (envs/base/env.py:135-176,
+    utilities/serialize.py), for both reward providers and with filled delay queues."""
+    import pickle
+    from bc_gym_planning_env_amd import api
+    path = np.arange(12, dtype=np.float64).reshape(4, 3)
+    cm = api.CostMap2D(np.arange(12, dtype=np.uint8).reshape(3, 4), 0.05, np.array([1.0, -2.0]))
+    for rps in (api.ContinuousRewardProviderState(min_spat_dist_so_far=0.5, path=path, target_idx=2),
+                api.ContinuousRewardPurePursuitProviderState(min_spat_dist_so_far=1.5, path=path, target_idx=1)):
+        rs = api.TricycleRobotState(1., 2., 3., 0.1, 0.2, 0.3, 0.4)
+        st = api.State(reward_provider_state=rps, path=rps.current_path(), original_path=path.copy(), costmap=cm,
+                       iter_timeout=1200, current_time=0.35, current_iter=7, robot_collided=True,
+                       poses_queue=[np.array([1., 2., 3.]), np.array([4., 5., 6.])],
+                       robot_state_queue=[api.TricycleRobotState(9., 8., 7.)],
+                       control_queue=[api.Action(command=np.array([0.2, 0.1]))], pose=np.array([1., 2., 3.]), robot_state=rs)
+        blob = pickle.dumps(st.serialize())
+        back = api.State.deserialize(pickle.loads(blob))
+        assert back == st and back is not st
+        assert type(back.reward_provider_state) is type(rps) and back.costmap == cm
+        cp = st.copy()
+        assert cp == st and cp.poses_queue[0] is not st.poses_queue[0]
+        cp.poses_queue[0][0] = 99.0
+        assert cp != st
