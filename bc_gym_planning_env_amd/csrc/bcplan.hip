@@ -559,10 +559,15 @@ __device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const
 
 // Everything of PlanEnv.step() that follows pose_collides(): rollback (env.py:458-459), bookkeeping and delay queues
 // (:377-396), reward (:352), done (:407-419), outputs, optional reset, state write-back.  Runs on one lane for env i.
+// PLAIN = true (the two-kernel step: no delays, continuous reward provider -- see step_uses_deferral) compiles the
+// delay queues and the pure-pursuit branch out.
+template <bool PLAIN>
 __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
                                              const PathWindow* free_window = nullptr)
 {
     const DevParams& P = a.S->P;
+    const int pose_delay = PLAIN ? 0 : P.pose_delay, state_delay = PLAIN ? 0 : P.state_delay;
+    const bool pure_pursuit = !PLAIN && P.reward_provider == BCP_REWARD_PURE_PURSUIT;
     const bool tri = P.model == BCP_MODEL_TRICYCLE;
     const int64_t n = a.S->n;
     Robot& r = q.r;
@@ -578,8 +583,8 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     // State.pose / State.robot_state: what the reward provider and the observation see (env.py:377-394)
     double seen[3] = {r.p.x, r.p.y, r.p.th};
     double seen_rs[7] = {r.p.x, r.p.y, r.p.th, r.v, r.w, r.steer, r.wheel};
-    if (P.pose_delay) fifo_delay<3>(a.S->st.pose_q, P.pose_delay, n, i, iter, seen);
-    if (P.state_delay) fifo_delay<7>(a.S->st.state_q, P.state_delay, n, i, iter, seen_rs);
+    if (pose_delay) fifo_delay<3>(a.S->st.pose_q, pose_delay, n, i, iter, seen);
+    if (state_delay) fifo_delay<7>(a.S->st.state_q, state_delay, n, i, iter, seen_rs);
 
     // shared path: uniform pointers (scalar cache); private paths: per-lane pointers
     double rew = 0.0;
@@ -588,7 +593,7 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     const int64_t g = slot_of(a.S, i, q);
     const double* pts = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
     m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
-    if (P.reward_provider == BCP_REWARD_PURE_PURSUIT) {
+    if (pure_pursuit) {
         if (!(a.flags & kAblateNoReward)) rew = reward_pure_pursuit(pts, m, seen[0], seen[1], collided, min_dist, target);
         goal = hypot(pts[5 * (m - 1)] - seen[0], pts[5 * (m - 1) + 1] - seen[1]) < 1.0;   // done(), reward.py:141-150
     } else {
@@ -597,7 +602,7 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
             const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : g * 8);
             const int16_t* index = a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
             const PathWindow w =
-                (free_window && !hit && !P.pose_delay) ? *free_window : path_window(P, bbox, index, seen[0], seen[1]);
+                (free_window && !hit && !pose_delay) ? *free_window : path_window(P, bbox, index, seen[0], seen[1]);
             if (lds_path && a.S->path.shared)  // way points staged in LDS by the step kernel
                 rew = reward_step(P, lds_path, w, m, seen[0], seen[1], seen[2], min_dist, target);
             else
@@ -667,17 +672,18 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     a.S->st.target_idx[i] = target;
     a.S->st.cur_iter[i] = iter;
     a.S->st.collided[i] = (uint8_t)collided;
-    if (P.pose_delay) {
+    if (pose_delay) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) a.S->st.pose_seen[c * n + i] = seen[c];
     }
-    if (P.state_delay) {
+    if (state_delay) {
 #pragma unroll
         for (int c = 0; c < 7; ++c) a.S->st.state_seen[c * n + i] = seen_rs[c];
     }
 }
 
 // ---- loads shared by the step kernels ------------------------------------------------------------------------
+template <bool PLAIN>
 __device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, bool active, Pending& q, double& cmd0, double& cmd1)
 {
     const DevParams& P = a.S->P;
@@ -704,7 +710,7 @@ __device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, bool acti
         cmd0 = c.x;
         cmd1 = c.y;
     }
-    if (P.control_delay && active) {   // the robot executes the command given control_delay steps ago (env.py:371-373)
+    if (!PLAIN && P.control_delay && active) {   // the robot executes the command given control_delay steps ago (env.py:371-373)
         double cmd[2] = {cmd0, cmd1};
         fifo_delay<2>(a.S->st.control_q, P.control_delay, a.S->n, i, q.iter + 1, cmd);
         cmd0 = cmd[0];
@@ -736,7 +742,7 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     const CollisionLds L = collision_lds_setup(P, a.S->map, tid);
     Pending q;
     double cmd0, cmd1;
-    load_env(a, i, active, q, cmd0, cmd1);
+    load_env<false>(a, i, active, q, cmd0, cmd1);
 
     // ---- _env_step (envs/base/env.py:442-461)
     q.old = q.r.p;
@@ -747,7 +753,7 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
         hit = collides_wave(P, a.S->map, a.S->cull, L, a.S->exact_mode, a.S->dense_threshold, a.S->wide != 0, active,
                             slot_of(a.S, i, q), q.r.p.x, q.r.p.y, q.r.p.th);
     if (!active) return;
-    finalize_env(a, i, q, hit);
+    finalize_env<false>(a, i, q, hit);
 }
 
 
@@ -780,7 +786,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
     // (2) ... then state, action, noise (the first-touch lines of this step): all of it is in flight together
     Pending q;
     double cmd0, cmd1;
-    load_env(a, i, active, q, cmd0, cmd1);
+    load_env<true>(a, i, active, q, cmd0, cmd1);
     if (gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
     // (3) LDS writes (the staging loads return first, in issue order)
     if (tid < nq) qv[tid] = my_q;
@@ -853,7 +859,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
     }
     DIAG1_STAMP(4);
     if (!active) return;
-    finalize_env(a, i, q, hit, lds_path, &win);
+    finalize_env<true>(a, i, q, hit, lds_path, &win);
     DIAG1_STAMP(7);
 }
 
@@ -894,7 +900,7 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
         // kernel 1 already finished this env as "free"; only a collision changes anything
         if (hit && threadIdx.x == 0) {
             Pending q = *e;
-            finalize_env(a, i, q, true);
+            finalize_env<true>(a, i, q, true);
         }
     }
 }

@@ -68,6 +68,41 @@ def cpu_baseline(g, envs=16384, budget_s=12.0):
                       % (envs, steps, threads, dt)}
 
 
+def aux_measurements(env, pool, n):
+    """Informational, rank 0 at N=1 only (NOT the metric): the neighbours of the step path built per SURVEY 8(f),
+    measured on the same steady-state batch with HIP events on the launch stream."""
+    import torch
+    from bc_gym_planning_env_amd.egocentric import BatchedEgocentricCostmap
+    out = {}
+    stream = torch.cuda.current_stream(env.device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    wrap = BatchedEgocentricCostmap(env)
+    for k in range(3):
+        wrap.observation()
+    reps = 20
+    e0.record(stream)
+    for k in range(reps):
+        wrap.observation()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    img_bytes = wrap.images.numel()
+    e0.record(stream)
+    for k in range(reps):
+        wrap.step(pool[k % 16])
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms_both = e0.elapsed_time(e1) / reps
+    out["egocentric_observation"] = {
+        "what": "EgocentricCostmap.observation for every env: %d x %d px uint8 + goal_n_state (envs/egocentric.py:102-160)"
+                % wrap.image_shape,
+        "kernel": "ego_costmap_kernel", "ms_per_call": ms, "bytes_written_per_call": img_bytes,
+        "roofline": {"bound": "hbm", "achieved": img_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": img_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "step_plus_observation_ms": ms_both, "env_steps_per_s_with_observation": n / (ms_both * 1e-3)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the informational egocentric-observation timing")
     args = ap.parse_args()
 
     import torch
@@ -178,6 +214,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g)
+        if world == 1 and not args.no_aux:
+            out["aux"] = aux_measurements(env, pool, n)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
