@@ -65,10 +65,12 @@ __device__ __forceinline__ int classify_outer(const CullDesc& C, int64_t env, in
         const bool stored = i < C.n_out && (unsigned)x < (unsigned)C.width && (unsigned)y < (unsigned)C.height;
         idx[i] = stored ? y * C.width + x : -1;
     }
+    // a sample outside the stored (padded) rectangle is more than `pad` px away from every cell of the map
+    const int not_stored = min(C.pad + 1, 255);
     int val[kMaxSamples];
 #pragma unroll
-    for (int i = 0; i < kMaxSamples; ++i) val[i] = idx[i] >= 0 ? (int)field[idx[i]] : (i < C.n_out ? 0 : 255);
-    int near_out = 0;  // a sample that is not stored cannot clear the pose
+    for (int i = 0; i < kMaxSamples; ++i) val[i] = idx[i] >= 0 ? (int)field[idx[i]] : (i < C.n_out ? not_stored : 255);
+    int near_out = 0;
 #pragma unroll
     for (int i = 0; i < kMaxSamples; ++i) near_out |= val[i] < C.t_out;
     return near_out ? kAmbiguous : kFree;
@@ -87,12 +89,14 @@ __device__ __forceinline__ OuterLookups outer_lookups_issue(const CullDesc& C, i
     L.off_map = px + C.reach < 0 || px - C.reach >= cols || py + C.reach < 0 || py - C.reach >= rows;
     const double ay_c = C.axis_y * c, ay_s = C.axis_y * s;
     const uint8_t* field = C.edt + env * C.env_stride;
+    // a sample outside the stored (padded) rectangle is more than `pad` px away from every cell of the map
+    const int not_stored = min(C.pad + 1, 255);
 #pragma unroll
     for (int i = 0; i < kMaxSamples; ++i) {
         const int du = (int)rint(C.out_x[i] * c - ay_s), dv = (int)rint(C.out_x[i] * s + ay_c);
         const int x = px + C.pad + du, y = py + C.pad + dv;
         const bool stored = !L.off_map && i < C.n_out && (unsigned)x < (unsigned)C.width && (unsigned)y < (unsigned)C.height;
-        L.val[i] = stored ? (int)field[y * C.width + x] : (i < C.n_out ? 0 : 255);  // not stored: cannot clear
+        L.val[i] = stored ? (int)field[y * C.width + x] : (i < C.n_out ? not_stored : 255);
     }
     return L;
 }

@@ -1943,8 +1943,9 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
     build_cull_geometry(h->params, resolution, &C);
     if (h->cull_enabled) {
         // shared map: padding wide enough that every sample of a pose whose image touches the map is stored;
-        // private maps: a thin margin (samples outside it just cannot clear / convict a pose)
-        if (!shared) C.pad = 8;
+        // private maps: just enough that a sample outside the stored rectangle (more than `pad` px away from every
+        // cell of the map) is known to clear the outer test
+        if (!shared) C.pad = std::max(8, C.t_out);
         const int clamp = std::min(255, std::max(C.t_out + 1, 2));
         const int W = cols + 2 * C.pad, H = rows + 2 * C.pad;
         const size_t cells = (size_t)n_maps * W * H;
