@@ -104,6 +104,12 @@ struct StepArgs {
     int32_t* err;
     int32_t* pending_count;    // [kShards] this step's counters of parked envs (one per shard: no hot atomic)
     int32_t* pending_next;     // [kShards] the next step's counters (the two sets alternate); kernel 1 zeroes them
+    // adaptive split between "settle in place" and "park for kernel 2" (nullptr: S->dense_threshold is used as is):
+    // kernel 2 of step t counts the undecided poses of step t and picks the threshold of step t + 1
+    const int32_t* threshold_now;
+    int32_t* threshold_next;
+    int32_t* inplace_count;    // undecided poses settled inside kernel 1 this step (the parked ones are in pending_count)
+    int32_t* inplace_next;     // next step's counter; kernel 1 zeroes it
     uint64_t seed, step_counter;
     uint32_t flags;
 };
@@ -154,6 +160,8 @@ struct bcp_handle {
     int32_t defer;            // settle undecided envs in a second kernel (shared map with distance field)
     int32_t exact_mode;       // 0 auto, 1 cooperative only, 2 per-thread only
     int32_t dense_threshold;  // auto: more ambiguous lanes than this in a wave -> per-thread rasteriser
+    int32_t adaptive;         // the threshold above is only the fallback: kernel 2 re-decides every step
+    int32_t* adapt;           // owned: [2] thresholds + [2] in-place counters, alternating by step parity
     int32_t cull_enabled;
     int32_t wide;             // kernel image may exceed 96 px: 8-word row masks in the cooperative path
     int32_t* ego_bins;        // owned: [2][bins] image counts / first slots per map entry (egocentric views)
@@ -788,6 +796,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
     double cmd0, cmd1;
     load_env<true>(a, i, active, q, cmd0, cmd1);
     if (gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
+    if (gi == 0 && a.inplace_next) *a.inplace_next = 0;
     // (3) LDS writes (the staging loads return first, in issue order)
     if (tid < nq) qv[tid] = my_q;
 #pragma unroll
@@ -829,8 +838,11 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
 
     bool hit = false;
     const uint64_t amb = __ballot(cls == kAmbiguous);
-    if ((int)__popcll(amb) > a.S->dense_threshold) {
+    const int n_amb = (int)__popcll(amb);
+    const int threshold = a.threshold_now ? *a.threshold_now : a.S->dense_threshold;
+    if (n_amb > threshold) {
         // many undecided lanes in this wave: settle them in place, one pose at a time by the whole wave
+        if (tid == 0 && a.inplace_count) atomicAdd(a.inplace_count, n_amb);
         const bool inner = cls == kAmbiguous && classify_inner_hit(a.S->cull, map_env, px, py, c, s);
         hit = inner;
         uint64_t todo = __ballot(cls == kAmbiguous && !inner);
@@ -868,6 +880,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
 // the env's finalisation from the parked state.  The first entry is fetched speculatively, together with the
 // counter that says whether it exists, so the two round trips overlap.
 constexpr int kPendingWaves = 4;  // wave = 2 * (row-chunk slot) + (edge slot)
+constexpr int kParkCapacity = 8192;  // undecided poses per step that kernel 2 takes without the waves' help
 
 template <bool WIDE>
 __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(const StepArgs a)
@@ -880,6 +893,15 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
     const Pending* slots = a.S->pending + shard;
     const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
     const int count = a.pending_count[shard];
+    if (blockIdx.x == 0 && a.threshold_next && threadIdx.x < kShards) {
+        // Undecided poses of this step, parked + settled in place.  Few of them: kernel 2 absorbs them all in one or
+        // two rounds, so the next step parks everything (no wave is held up by its own unlucky lanes).  Many (robots
+        // hugging walls everywhere): kernel 2 would need dozens of rounds, the waves settle their own instead.
+        int total = a.pending_count[threadIdx.x];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+        if (threadIdx.x == 0) *a.threshold_next = total + *a.inplace_count <= kParkCapacity ? 64 : a.S->dense_threshold;
+    }
     for (int idx = blockIdx.x / kShards; idx < a.S->pending_cap; idx += stride) {
         const Pending* e = slots + (int64_t)idx * kShards;   // in bounds whatever `count` says
         const double c = e->c, s = e->s;
@@ -1812,6 +1834,7 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->seed = 0;
     h->exact_mode = 0;
     h->dense_threshold = 6;
+    h->adaptive = 1;
     h->cull_enabled = 1;
     h->defer = 1;
     h->static_dirty = true;
@@ -1832,6 +1855,7 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->edt_col) (void)hipFree(h->edt_col);
     if (h->pending) (void)hipFree(h->pending);
     if (h->pending_count) (void)hipFree(h->pending_count);
+    if (h->adapt) (void)hipFree(h->adapt);
     if (h->dev_static) (void)hipFree(h->dev_static);
     if (h->ego_bins) (void)hipFree(h->ego_bins);
     if (h->ego_order) (void)hipFree(h->ego_order);
@@ -1874,6 +1898,7 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
             return BCP_OK;
         case BCP_TUNE_DENSE_THRESHOLD:
             h->dense_threshold = value;
+            h->adaptive = 0;   // an explicit threshold is taken as is
             return BCP_OK;
         case BCP_TUNE_DEFER:
             h->defer = value ? 1 : 0;
@@ -1980,6 +2005,10 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
             HIP_TRY(hipMalloc(&h->pending, (size_t)kShards * h->pending_cap * sizeof(Pending)));
             HIP_TRY(hipMalloc((void**)&h->pending_count, 2 * kShards * sizeof(int32_t)));
             HIP_TRY(hipMemsetAsync(h->pending_count, 0, 2 * kShards * sizeof(int32_t), s));
+            HIP_TRY(hipMalloc((void**)&h->adapt, 4 * sizeof(int32_t)));
+            const int32_t init[4] = {h->dense_threshold, h->dense_threshold, 0, 0};
+            HIP_TRY(hipMemcpyAsync(h->adapt, init, sizeof(init), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));   // (`init` is on the stack)
         }
     }
     h->have_map = true;
@@ -2156,6 +2185,11 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     a.step_counter = h->step_counter;
     a.pending_count = h->pending_count + (h->step_counter & 1) * kShards;
     a.pending_next = h->pending_count + ((h->step_counter + 1) & 1) * kShards;
+    const bool adapt = h->adaptive && h->adapt && S.pending && S.dense_threshold >= 0;
+    a.threshold_now = adapt ? h->adapt + (h->step_counter & 1) : nullptr;
+    a.threshold_next = adapt ? h->adapt + ((h->step_counter + 1) & 1) : nullptr;
+    a.inplace_count = adapt ? h->adapt + 2 + (h->step_counter & 1) : nullptr;
+    a.inplace_next = adapt ? h->adapt + 2 + ((h->step_counter + 1) & 1) : nullptr;
     const int blocks = (int)((h->n + kBlock - 1) / kBlock);
     if (S.pending) {
         // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest
