@@ -120,7 +120,6 @@ enum : uint32_t {
     kAblateNoCollision = 1u << 16,   // skip pose_collides altogether
     kAblateNoReward = 1u << 17,      // skip the reward scan
     kAblateNoCoop = 1u << 19,        // kernel 2: skip the cooperative rasteriser
-    kAblateNoInner = 1u << 20,       // kernel 2: skip the inner distance-field test
     kAblateNoPark = 1u << 21,        // kernel 1: do not park undecided envs
     kAblateNoClassify = 1u << 22     // kernel 1: skip the distance-field lookups
 };
@@ -875,7 +874,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
     DIAG1_STAMP(7);
 }
 
-// Kernel 2 of a step: kPendingWaves wavefronts per parked env.  Inner distance-field test, then the lanes rasterise
+// Kernel 2 of a step: kPendingWaves wavefronts per parked env: the lanes rasterise
 // the footprint together (coop_collides, wave w takes the row chunks w, w+2, ...); on a collision thread 0 redoes
 // the env's finalisation from the parked state.  The first entry is fetched speculatively, together with the
 // counter that says whether it exists, so the two round trips overlap.
@@ -911,9 +910,11 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
         if (idx >= count) break;
         DIAG_STAMP(1);
         const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : g * a.S->map.env_stride);
-        bool hit = (a.flags & kAblateNoInner) ? false : classify_inner_hit(a.S->cull, a.S->map.shared ? 0 : g, px, py, c, s);
+        // (no inner distance-field test here: nearly every parked pose is free, so the test would cost a dependent
+        //  round trip per pose and almost never spare the rasteriser)
+        bool hit = false;
         DIAG_STAMP(2);
-        if (!hit && !(a.flags & kAblateNoCoop))  // (the inner verdict is uniform over the workgroup: no barrier mismatch)
+        if (!(a.flags & kAblateNoCoop))
             hit = coop_collides_quad<WIDE>(P, vqx, vqy, c, s, px, py, words, a.S->map.rows, a.S->map.cols, a.S->map.wpr, wave,
                                            (LdsU32)lds_dyn);
         DIAG_STAMP(3);

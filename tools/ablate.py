@@ -12,8 +12,7 @@ for k in range(1200):
 torch.cuda.synchronize()
 st = env.get_state()
 for name, fl in [('full', 0), ('no_park', 1 << 21), ('no_classify', 1 << 22), ('no_collision', 1 << 16),
-                 ('no_reward', 1 << 17), ('neither', 3 << 16), ('k2_no_inner', 1 << 20), ('k2_no_coop', 1 << 19),
-                 ('k2_neither', 3 << 19)]:
+                 ('no_reward', 1 << 17), ('neither', 3 << 16), ('k2_no_coop', 1 << 19)]:
     env.set_state(st)
     env._debug_flags = fl
     ms = [env.time_steps(pool[i % 16], 20) for i in range(5)]
