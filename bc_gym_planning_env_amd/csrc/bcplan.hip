@@ -2196,7 +2196,7 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
         // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest
         const size_t lds1 = ((size_t)h->params.n_verts * 2 + S.lds_path_doubles) * sizeof(double);
         const size_t lds2 = (size_t)2 * 4 * (S.wide ? 8 : 3) * 64 * sizeof(uint32_t);
-        const int waves = 1024;  // a multiple of kShards: 16 blocks per shard
+        const int waves = 2048;  // a multiple of kShards: 32 teams per shard, so that a shard rarely needs a second round
         const bool second = !first_only && S.dense_threshold >= 0;  // (threshold < 0: everything settled in place)
         if (S.wide) {
             hipLaunchKernelGGL(step_fast_kernel<true>, dim3(blocks), dim3(kBlock), lds1, s, a);
