@@ -530,9 +530,11 @@ class BatchedPlanEnv(object):
         _lib.check(self._lib.bcp_broadcast_state(self._h, int(src), ptr, self._stream()))
         self._last_mask = mask
 
-    def step(self, actions, noise_z=None, noise_z_out=None):
+    def step(self, actions, noise_z=None, noise_z_out=None, done_out=None):
         """One tick for every env.  actions: [N,2] (float32 or float64) tensor / array, or a list of Action.
         noise_z: optional [N,3] float64 standard normals (slot order) replacing the on-device RNG.
+        done_out: optional uint8 [N] device tensor that receives the done mask instead of `self.done` (e.g. a row of
+        a ring buffer that is all-gathered every few steps).
         Returns (BatchedObservation, reward float64[N], done uint8[N], {}) -- device tensors, no sync."""
         # fast path: a device tensor of the right shape and dtype goes straight to the library
         if not (isinstance(actions, torch.Tensor) and actions.device == self.device and actions.is_contiguous()
@@ -554,11 +556,16 @@ class BatchedPlanEnv(object):
             io.noise_z_out = noise_z_out.data_ptr()
         else:
             io.noise_z_out = None
+        done = self.done
+        if done_out is not None:
+            assert done_out.dtype == torch.uint8 and done_out.numel() == self.n_envs and done_out.is_contiguous()
+            done = done_out
+        io.done = done.data_ptr()
         rc = self._bcp_step(self._h, self._io_ref, flags, torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _lib.check(rc)
-        self._last_inputs = (actions, z)  # keep inputs alive until the stream has consumed them
-        return self._obs, self.reward, self.done, self._info
+        self._last_inputs = (actions, z, done)  # keep inputs alive until the stream has consumed them
+        return self._obs, self.reward, done, self._info
 
     def check_errors(self):
         """Raise what the reference would have raised during the last step (synchronises)."""

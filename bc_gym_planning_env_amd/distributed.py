@@ -1,6 +1,6 @@
 """Sharding the env batch over the GPUs of one node: one process per GPU, envs split by contiguous index blocks,
-nothing crosses GPUs on the data path except ONE all-gather of the uint8 done mask per step (RCCL over xGMI when the
-backend is "nccl"; "gloo" on CPU for tests).  The reference has no counterpart: its envs are independent objects.
+nothing crosses GPUs on the data path except the all-gather of the uint8 done mask (RCCL over xGMI when the backend is
+"nccl"; "gloo" on CPU for tests) -- per step, or of a ring of the last K masks every K steps (bench.py).  The reference has no counterpart: its envs are independent objects.
 """
 import os
 
