@@ -94,3 +94,20 @@ def test_fan_out_carries_the_geometry_entry(torch_cuda):
     assert (env.geom_of_env.cpu().numpy() == pool.next_geom[g[5]]).all()
     env.set_state(snap)
     assert (env.geom_of_env.cpu().numpy() == g[5]).all()
+
+
+def test_done_out_ring(torch_cuda):
+    """step(..., done_out=row) stores the done mask straight into a caller-owned buffer (the multi-GPU ring)"""
+    torch = torch_cuda
+    n = 256
+    a, b = _env(torch, n, iteration_timeout=6), _env(torch, n, iteration_timeout=6)
+    ring = torch.full((4, n), 7, dtype=torch.uint8, device="cuda")
+    rng = np.random.RandomState(3)
+    for t in range(8):
+        act = a.action_space.sample_batch(n, rng)
+        z = rng.normal(size=(n, 3))
+        _o, _r, d_a, _ = a.step(act, noise_z=z)
+        _o, _r, d_b, _ = b.step(act, noise_z=z, done_out=ring[t % 4])
+        assert d_b.data_ptr() == ring[t % 4].data_ptr()
+        assert (d_a == ring[t % 4]).all()
+    assert int(ring[1].sum()) == n      # step 6 (t = 5) timed every env out
