@@ -1,0 +1,448 @@
+// bcp_ego.h -- device code of the egocentric observation: extract_egocentric_costmap
+// (utilities/costmap_utils.py:25-75 = cv2.getRotationMatrix2D + cv2.warpAffine with INTER_NEAREST) for every env at
+// once, plus the kernels that group images by map entry for private / pooled maps.  Included by bcplan.hip, which holds
+// the host entry points (bcp_egocentric_costmaps, bcp_goal_n_state).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "bcp_coop.h"   // bcast_i / bcast_d
+
+namespace bcp {
+
+extern __shared__ uint32_t ego_lds[];
+
+// extract_egocentric_costmap (utilities/costmap_utils.py:25-75) = cv2.getRotationMatrix2D + cv2.warpAffine with
+// INTER_NEAREST for every env at once.  OpenCV's nearest-neighbour warp works in 22.10 fixed point:
+//   X(x, y) = (sat_int((M1*y + M2)*1024) + 512 + sat_int(M0*x*1024)) >> 10      (and likewise Y with M4, M5, M3)
+// with M the float64 inverse of the 2x3 transform; a destination pixel copies src[Y][X] or takes the border value.
+struct EgoArgs {
+    const uint8_t* data;         // raw costmaps: [rows][cols] shared or one per map entry
+    int64_t map_stride;          // bytes per map entry (0 when shared)
+    const int32_t* valid_rows;   // per-entry true shape (optional)
+    const int32_t* valid_cols;
+    int32_t rows, cols;          // allocation shape of one map
+    const double* origins;       // per-entry origins or nullptr
+    double ox, oy, res, inv_res;
+    const double* poses;         // [n,3] or nullptr: the bound state
+    const double *sx, *sy, *sth;
+    const int32_t* geom_of_env;
+    int32_t shared;
+    int32_t has_window;
+    double win_ox, win_oy;
+    int32_t drows, dcols;        // output shape
+    uint32_t cols_magic;         // floor(2^32 / cols) + 1: idx / cols == umulhi(idx, magic) for idx * cols < 2^32
+    int32_t stage_map;           // shared map is copied to LDS (rows * cols bytes)
+    int32_t border;
+    int64_t n_envs;              // image i shows the costmap of env i % n_envs
+    int64_t n_images;
+    uint8_t* out;                // [n][drows][dcols]
+};
+
+__device__ __forceinline__ int sat_int(double v)   // cv::saturate_cast<int>(double): nearest-even, saturating
+{
+    const double r = rint(v);
+    return r >= 2147483647.0 ? 2147483647 : (r <= -2147483648.0 ? (-2147483647 - 1) : (int)r);
+}
+
+// clamp(v, lo, hi) as ONE instruction (the compiler emits v_max + v_min for min(max()))
+__device__ __forceinline__ int clamp_med3(int v, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+
+// byte at a raw LDS address (no symbol base is added: the caller folds the base into the address)
+__device__ __forceinline__ uint32_t lds_byte_at(uint32_t addr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t) * (__attribute__((address_space(3))) const uint8_t*)addr;
+#else
+    (void)addr;
+    return 0;
+#endif
+}
+
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+// ---- building blocks ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) int* LdsI32;
+typedef __attribute__((address_space(3))) uint8_t* LdsU8;
+constexpr int kRowOff = -2147483647 - 1;   // row-table X0 of a row that lies off the map (real X0 are >= INT_MIN + 512)
+
+struct EgoXform {
+    double M[6];   // dst -> src, as cv::warpAffine uses it
+    int vrows, vcols;
+    int g_lo, g_hi;   // map entry
+};
+
+// cv2.getRotationMatrix2D(world_to_pixel(pose), 180*theta/pi, 1), the window shift, and warpAffine's inversion
+__device__ __forceinline__ EgoXform ego_transform(const EgoArgs& a, int64_t img)
+{
+    EgoXform T;
+    const int64_t me = img % a.n_envs;
+    const int64_t g = a.shared ? 0 : (a.geom_of_env ? (int64_t)a.geom_of_env[me] : me);
+    double ox = a.ox, oy = a.oy;
+    if (a.origins) {
+        ox = a.origins[2 * g];
+        oy = a.origins[2 * g + 1];
+    }
+    double px, py, th;
+    if (a.poses) {
+        px = a.poses[3 * img];
+        py = a.poses[3 * img + 1];
+        th = a.poses[3 * img + 2];
+    } else {
+        px = a.sx[img];
+        py = a.sy[img];
+        th = a.sth[img];
+    }
+    double* M = T.M;
+    const float cx = (float)rint((px - ox) * a.inv_res), cy = (float)rint((py - oy) * a.inv_res);   // Point2f centre
+    const double angle = (180 * th / M_PI) * (M_PI / 180);
+    const double alpha = cos(angle), beta = sin(angle);
+    M[0] = alpha;
+    M[1] = beta;
+    M[2] = (1 - alpha) * cx - beta * cy;
+    M[3] = -beta;
+    M[4] = alpha;
+    M[5] = beta * cx + (1 - alpha) * cy;
+    if (a.has_window) {
+        // shift so that the window origin lands on output pixel (0, 0); composed in float32 (costmap_utils.py:50-64)
+        const double dsx = rint((a.win_ox - (ox - px)) * a.inv_res), dsy = rint((a.win_oy - (oy - py)) * a.inv_res);
+        float t[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = (float)M[k];
+        t[2] = t[2] + (-(float)dsx);
+        t[5] = t[5] + (-(float)dsy);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) M[k] = (double)t[k];
+    }
+    {   // cv::warpAffine inverts the transform in float64
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0 ? 1. / D : 0;
+        const double A11 = M[4] * D, A22 = M[0] * D;
+        M[0] = A11;
+        M[1] *= -D;
+        M[3] *= -D;
+        M[4] = A22;
+        const double b1 = -M[0] * M[2] - M[1] * M[5];
+        const double b2 = -M[3] * M[2] - M[4] * M[5];
+        M[2] = b1;
+        M[5] = b2;
+    }
+    T.vrows = a.valid_rows ? a.valid_rows[g] : a.rows;
+    T.vcols = a.valid_cols ? a.valid_cols[g] : a.cols;
+    T.g_lo = (int)(uint32_t)g;
+    T.g_hi = (int)(g >> 32);
+    return T;
+}
+
+// lane k's transform, broadcast to the whole wave (scalar registers)
+struct EgoImage {
+    double m0, m1, m2, m3, m4, m5;
+    int vr, vc;
+    int64_t g;
+};
+
+__device__ __forceinline__ EgoImage ego_broadcast(const EgoXform& T, int k)
+{
+    EgoImage I;
+    I.m0 = bcast_d(T.M[0], k);
+    I.m1 = bcast_d(T.M[1], k);
+    I.m2 = bcast_d(T.M[2], k);
+    I.m3 = bcast_d(T.M[3], k);
+    I.m4 = bcast_d(T.M[4], k);
+    I.m5 = bcast_d(T.M[5], k);
+    I.vr = bcast_i(T.vrows, k);
+    I.vc = bcast_i(T.vcols, k);
+    I.g = ((int64_t)bcast_i(T.g_hi, k) << 32) | (uint32_t)bcast_i(T.g_lo, k);
+    return I;
+}
+
+// LDS copy of one costmap with a one-cell ring of the border value.  Whole workgroup; ends with a barrier.
+// The map is fetched as aligned dwords, eight independent loads in flight per thread (a cold map costs a few memory
+// round trips instead of one per row), and scattered into the ringed layout byte by byte.
+__device__ __forceinline__ void ego_stage_map(const EgoArgs& a, const uint8_t* __restrict__ src, int vr, int vc, LdsU8 lmap,
+                                              int pitch, int map_bytes)
+{
+    __attribute__((address_space(3))) uint32_t* l32 = (__attribute__((address_space(3))) uint32_t*)lmap;
+    for (int k = threadIdx.x; k < map_bytes / 4; k += 256) l32[k] = (uint32_t)a.border * 0x01010101u;
+    __syncthreads();
+    const int total = a.rows * a.cols;
+    const int off = (int)((uintptr_t)src & 3);   // the map entry need not start on a dword boundary
+    const uint32_t* __restrict__ w32 = reinterpret_cast<const uint32_t*>(src - off);
+    const int n_words = (off + total + 3) >> 2;
+    for (int w0 = threadIdx.x; w0 < n_words; w0 += 8 * 256) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int w = w0 + u * 256;
+            v[u] = w < n_words ? w32[w] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int w = w0 + u * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = 4 * w + j - off;                       // linear index into the map entry
+                if (idx >= 0 && idx < total) {
+                    const int r = (int)__umulhi((uint32_t)idx, a.cols_magic), c = idx - r * a.cols;
+                    if (r < vr && c < vc) lmap[(r + 1) * pitch + 1 + c] = (uint8_t)(v[u] >> (8 * j));
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// per-row terms of one image (rounding term included; staged sampling: ring offset and LDS base folded in) and the
+// off-map flag of each row, for rows t0, t0 + tstep, ...
+template <bool STAGED>
+__device__ __forceinline__ void ego_row_terms(const EgoArgs& a, const EgoImage& I, int x_shift, LdsI32 row_tab, int t0,
+                                              int tstep)
+{
+    const int last_cx = sat_int(I.m0 * (a.dcols - 1) * 1024), last_cy = sat_int(I.m3 * (a.dcols - 1) * 1024);
+    for (int y = t0; y < a.drows; y += tstep) {
+        const int rx = sat_int((I.m1 * y + I.m2) * 1024) + 512, ry = sat_int((I.m4 * y + I.m5) * 1024) + 512;
+        const int xa = rx >> 10, xb = (rx + last_cx) >> 10, ya = ry >> 10, yb = (ry + last_cy) >> 10;
+        const bool off = (xa < 0 && xb < 0) || (xa >= I.vc && xb >= I.vc) || (ya < 0 && yb < 0) || (ya >= I.vr && yb >= I.vr);
+        row_tab[2 * y] = off ? kRowOff : (STAGED ? rx + x_shift * 1024 : rx);
+        row_tab[2 * y + 1] = STAGED ? ry + 1024 : ry;
+    }
+}
+
+// the pixels of rows r0, r0 + rstep, ... for this lane's column groups.  Pixel groups are PX columns wide; the last
+// group of a row is shifted left so that it ends at the last column (it recomputes a few pixels of its neighbour
+// instead of needing a narrower store).
+template <bool STAGED, int PX>
+__device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, int x_shift, int pitch,
+                                           const uint8_t* __restrict__ src, LdsI32 row_tab, uint8_t* __restrict__ image,
+                                           int cg, int r0, int rstep)
+{
+    const uint32_t border = (uint32_t)a.border;
+    const uint64_t border8 = (uint64_t)border * 0x0101010101010101ull;
+    const int x_lo = x_shift - 1, x_hi = x_shift + I.vc, y_lo = 0, y_hi = I.vr + 1;   // ring coordinates (staged sampling)
+    for (int xg = PX * cg; xg < a.dcols; xg += 128) {
+        const int x0 = min(xg, a.dcols - PX);
+        int ccx[PX], ccy[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {   // cv::hal::warpAffine's adelta / bdelta for this lane's columns
+            ccx[j] = sat_int(I.m0 * (x0 + j) * 1024);
+            ccy[j] = sat_int(I.m3 * (x0 + j) * 1024);
+        }
+        for (int y = r0; y < a.drows; y += rstep) {
+            const int rx = row_tab[2 * y], ry = row_tab[2 * y + 1];
+            uint64_t packed = border8;
+            if (rx != kRowOff) {
+                uint32_t half[2] = {0, 0};
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    // (saturate_cast<short> never bites: |X|, |Y| < 2^21 and maps are < 2^15)
+                    const int X = (rx + ccx[j]) >> 10, Y = (ry + ccy[j]) >> 10;
+                    uint32_t val;
+                    if (STAGED) {   // clamp onto the border ring of the LDS copy: every address is valid
+                        const int xc = clamp_med3(X, x_lo, x_hi), yc = clamp_med3(Y, y_lo, y_hi);
+                        val = lds_byte_at((uint32_t)(__mul24(yc, pitch) + xc));
+                    } else {        // global gather: only the in-map lanes issue a load
+                        val = border;
+                        if ((unsigned)X < (unsigned)I.vc && (unsigned)Y < (unsigned)I.vr)
+                            val = (uint32_t)src[(uint32_t)__mul24(Y, a.cols) + (uint32_t)X];
+                    }
+                    half[j >> 2] |= val << (8 * (j & 3));
+                }
+                packed = ((uint64_t)half[1] << 32) | half[0];
+            }
+            uint8_t* const p = image + (int64_t)y * a.dcols + x0;
+            if (PX == 8)
+                *reinterpret_cast<u64_unaligned*>(p) = packed;
+            else
+                *reinterpret_cast<u32_unaligned*>(p) = (uint32_t)packed;
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One WAVEFRONT per image, persistent workgroups of 4 waves that stage a shared costmap in LDS once and then walk
+// over images.
+//   * transforms: lane l of a wave prepares the (inverted) warp matrix of the wave's l-th image, so the float64
+//     sin / cos / inversion work is done once per image by one lane; the wave then takes the images one by one and
+//     broadcasts that lane's matrix (v_readlane -> scalar registers).
+//   * pixels: lane = (row mod 4, group of 8 consecutive columns).  The column terms of a lane's 8 pixels stay in
+//     registers, the per-row terms come from a small per-wave LDS table, and the 8 pixels leave as one 64-bit store
+//     (image rows are dcols bytes apart, so these stores are generally unaligned).
+//   * rows whose source segment lies entirely off the map are filled with the border value without sampling: the
+//     source coordinates are monotone in x, so it is enough to look at the row's two ends.
+//   * shared map: the LDS copy carries a one-cell ring of the border value and the source coordinates are clamped
+//     onto it (v_med3), so a pixel is add, add, shift, shift, clamp, clamp, multiply-add, LDS byte read, pack --
+//     no bounds compare and no select.  The ring offset and the LDS base address ride in the per-row terms.
+// LDS: [shared map + ring, dword padded] [4 waves x drows x {X0 (kRowOff = row is off the map), Y0}]
+// STAGED = false: maps that do not fit LDS are sampled straight from global memory.
+template <bool STAGED, int PX>
+__global__ void __launch_bounds__(256) ego_costmap_kernel(const EgoArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pitch = a.cols + 2;
+    const int map_bytes = STAGED ? (((a.rows + 2) * pitch + 3) & ~3) : 0;
+    const LdsU8 lmap = (LdsU8)ego_lds;
+    const LdsI32 row_tab = (LdsI32)(lmap + map_bytes) + wave * (2 * a.drows);
+    if (STAGED)
+        ego_stage_map(a, a.data, a.valid_rows ? a.valid_rows[0] : a.rows, a.valid_cols ? a.valid_cols[0] : a.cols, lmap,
+                      pitch, map_bytes);
+    // staged sampling: X' = X + x_shift and Y' = Y + 1 index the ringed copy directly (raw LDS byte address)
+    const int x_shift = 1 + (int)(uint32_t)(uintptr_t)lmap;
+    constexpr int kGroups = 128 / PX, kRows = 64 / kGroups;   // lanes of a wave: kRows image rows x kGroups pixel groups
+    const int cg = lane % kGroups, rl = lane / kGroups;
+    const int64_t P = (int64_t)a.drows * a.dcols;
+    const int64_t first = (int64_t)blockIdx.x * 4 + wave, stride = (int64_t)gridDim.x * 4;
+    for (int64_t base = first; base < a.n_images; base += 64 * stride) {
+        EgoXform T;
+        memset(&T, 0, sizeof(T));
+        const int64_t mine = base + lane * stride;   // lane l: transform of the wave's l-th image of this batch
+        if (mine < a.n_images) T = ego_transform(a, mine);
+        const int64_t left = (a.n_images - base + stride - 1) / stride;
+        const int count = (int)(left < 64 ? left : 64);
+        for (int k = 0; k < count; ++k) {            // the wave's images, one at a time
+            const int64_t img = base + k * stride;
+            const EgoImage I = ego_broadcast(T, k);
+            ego_row_terms<STAGED>(a, I, x_shift, row_tab, lane, 64);
+            wave_lds_sync();
+            ego_pixels<STAGED, PX>(a, I, x_shift, pitch, a.data + I.g * a.map_stride, row_tab, a.out + img * P, cg, rl, kRows);
+            wave_lds_sync();   // the table is rewritten for the next image
+        }
+    }
+}
+
+// Private / pooled costmaps that fit LDS: images are first grouped by map entry (ego_bin_* kernels below); every
+// workgroup then takes an equal slice of that grouped list and walks through it run by run (a run = consecutive
+// images of one map entry): stage the entry (with the border ring), produce the run's images four at a time, one per
+// wavefront exactly like the shared-map kernel, and let the 4 waves share each of the up to three left-over images --
+// wave w takes every 4th slice of rows -- so that nobody idles (private maps: every run is a single image).
+// LDS: [map + ring] [4 row tables].
+template <int PX>
+__global__ void __launch_bounds__(256) ego_costmap_binned_kernel(const EgoArgs a, const int32_t* __restrict__ bin_start,
+                                                                 const int32_t* __restrict__ bin_count,
+                                                                 const int32_t* __restrict__ order)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pitch = a.cols + 2;
+    const int map_bytes = ((a.rows + 2) * pitch + 3) & ~3;
+    const LdsU8 lmap = (LdsU8)ego_lds;
+    const LdsI32 tables = (LdsI32)(lmap + map_bytes);
+    const LdsI32 wave_tab = tables + wave * (2 * a.drows);
+    const int x_shift = 1 + (int)(uint32_t)(uintptr_t)lmap;
+    constexpr int kGroups = 128 / PX, kRows = 64 / kGroups;
+    const int cg = lane % kGroups, rl = lane / kGroups;
+    const int64_t P = (int64_t)a.drows * a.dcols;
+    const int64_t chunk = (a.n_images + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = blockIdx.x * chunk, hi = min(lo + chunk, a.n_images);
+    for (int64_t pos = lo; pos < hi;) {
+        const int64_t me = (int64_t)order[pos] % a.n_envs;
+        const int64_t g = a.geom_of_env ? (int64_t)a.geom_of_env[me] : me;
+        const int64_t run_end = min(hi, (int64_t)bin_start[g] + bin_count[g]);
+        const int run = (int)(run_end - pos);   // (uniform over the workgroup)
+        __syncthreads();                        // everyone is done with the previous map
+        ego_stage_map(a, a.data + g * a.map_stride, a.valid_rows ? a.valid_rows[g] : a.rows,
+                      a.valid_cols ? a.valid_cols[g] : a.cols, lmap, pitch, map_bytes);
+        const int whole = run & ~3;
+        // ---- one image per wavefront: wave w takes the run's images w, w + 4, ...; lane l prepares the l-th of them
+        for (int base = wave; base < whole; base += 256) {
+            EgoXform T;
+            memset(&T, 0, sizeof(T));
+            int my_img = 0;
+            if (base + 4 * lane < whole) {
+                my_img = order[pos + base + 4 * lane];
+                T = ego_transform(a, my_img);
+            }
+            const int batch = min(64, (whole - base + 3) / 4);
+            for (int k = 0; k < batch; ++k) {
+                const int64_t img = (uint32_t)bcast_i(my_img, k);
+                const EgoImage I = ego_broadcast(T, k);
+                ego_row_terms<true>(a, I, x_shift, wave_tab, lane, 64);
+                wave_lds_sync();
+                ego_pixels<true, PX>(a, I, x_shift, pitch, nullptr, wave_tab, a.out + img * P, cg, rl, kRows);
+                wave_lds_sync();
+            }
+        }
+        // ---- the left-over images: the four waves share each of them (one row table, two barriers per image)
+        if (run > whole) {
+            int my_img = 0;
+            EgoXform T;
+            memset(&T, 0, sizeof(T));
+            if (whole + lane < run) {
+                my_img = order[pos + whole + lane];
+                T = ego_transform(a, my_img);
+            }
+            for (int k = 0; k < run - whole; ++k) {
+                const int64_t img = (uint32_t)bcast_i(my_img, k);
+                const EgoImage I = ego_broadcast(T, k);
+                __syncthreads();   // the table is free (earlier images are finished)
+                ego_row_terms<true>(a, I, x_shift, tables, threadIdx.x, 256);
+                __syncthreads();
+                ego_pixels<true, PX>(a, I, x_shift, pitch, nullptr, tables, a.out + img * P, cg, wave * kRows + rl, 4 * kRows);
+            }
+        }
+        pos = run_end;
+    }
+}
+
+// ---- grouping images by map entry: count -> exclusive scan -> scatter ------------------------------------------
+__global__ void ego_bin_count_kernel(const int32_t* __restrict__ geom_of_env, int64_t n_envs, int64_t n_images,
+                                     int32_t* __restrict__ bin_count, int32_t* __restrict__ rank)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_images) return;
+    const int64_t me = i % n_envs;
+    const int64_t g = geom_of_env ? (int64_t)geom_of_env[me] : me;
+    rank[i] = atomicAdd(bin_count + g, 1);
+}
+
+__global__ void __launch_bounds__(1024) ego_bin_scan_kernel(const int32_t* __restrict__ bin_count, int64_t n_bins,
+                                                            int32_t* __restrict__ bin_start)
+{
+    __shared__ int32_t part[1024];
+    __shared__ int32_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_bins; base += 1024) {
+        const int64_t i = base + tid;
+        const int32_t v = i < n_bins ? bin_count[i] : 0;
+        part[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan
+            const int32_t t = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += t;
+            __syncthreads();
+        }
+        if (i < n_bins) bin_start[i] = carry + part[tid] - v;
+        __syncthreads();
+        if (tid == 1023) carry += part[1023];
+        __syncthreads();
+    }
+}
+
+__global__ void ego_bin_scatter_kernel(const int32_t* __restrict__ geom_of_env, int64_t n_envs, int64_t n_images,
+                                       const int32_t* __restrict__ bin_start, const int32_t* __restrict__ rank,
+                                       int32_t* __restrict__ order)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_images) return;
+    const int64_t me = i % n_envs;
+    const int64_t g = geom_of_env ? (int64_t)geom_of_env[me] : me;
+    order[bin_start[g] + rank[i]] = (int32_t)i;
+}
+
+}  // namespace bcp

@@ -1,0 +1,820 @@
+// bcp_step.h -- device code of the batched PlanEnv.step(): the parameter blocks shared with the host, the one-time
+// path kernels, the reward providers, the delay queues, and the step kernels (general / fast / pending).  Included by
+// bcplan.hip, which holds the handle and the C entry points.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "bcp_device.h"
+#include "bcp_raster.h"
+#include "bcp_coop.h"
+
+using namespace bcp;
+
+struct DevState {
+    double *x, *y, *angle, *v, *w, *steer, *wheel, *min_dist;
+    int32_t *target_idx, *cur_iter;
+    uint8_t* collided;
+    double *pose_seen, *state_seen;         // [3][n] / [7][n], delays > 0 only
+    double *control_q, *pose_q, *state_q;   // [delay][width][n]
+};
+
+struct MapDesc {
+    const uint32_t* bits;  // lethal bitmap, [rows][wpr] shared or [N][rows][wpr]
+    int32_t rows, cols, wpr;
+    int32_t shared;
+    int32_t in_lds;        // shared bitmap small enough to be staged in LDS
+    int64_t env_stride;    // words per env (0 when shared)
+    const double* origins; // device [N,2] when per-env, else NULL
+    double ox, oy, inv_res;
+};
+
+struct PathDesc {
+    const double* pts;   // [len][5] = x, y, theta, cos(theta), sin(theta); shared or [N][max_len][5]
+    const double* bbox;  // [8] = xmin, xmax, ymin, ymax of the way points, then the bucket grid x0, 1/wx, y0, 1/wy
+    const int16_t* index; // [2 axes][kPathBuckets][2] = first / last way point index that can be reached from a bucket
+    const int32_t* lens;
+    int32_t max_len, shared;
+};
+
+struct Pending;
+
+// Everything a step needs that only changes when the caller re-binds something.  It lives in DEVICE memory (uploaded
+// when dirty) and the kernels get a pointer: kernel arguments sit in host memory on this platform, and a kernel that
+// takes kilobytes of arguments by value pays a PCIe-latency scalar load every time it touches a new field.
+struct StepStatic {
+    DevParams P;
+    MapDesc map;
+    CullDesc cull;
+    PathDesc path;
+    DevState st, init;
+    int64_t n;
+    int64_t env_id_base;
+    int32_t exact_mode, dense_threshold, wide;
+    int32_t pending_cap;       // slots per shard
+    int32_t lds_path_doubles;  // > 0: the shared path (max_len * 5 doubles) is staged in LDS by the fast step kernel
+    struct Pending* pending;   // [kShards][pending_cap] parking slots for undecided envs (nullptr: no second kernel)
+    // geometry pool (bcp_set_geometry_pool): env i uses entry geom_of_env[i] of the non-shared map / path / initial
+    // state arrays; a reset moves it to next_geom[entry].  nullptr: env i uses entry i.
+    int32_t* geom_of_env;
+    const int32_t* next_geom;
+};
+
+// Per-launch kernel arguments (small).
+struct StepArgs {
+    const StepStatic* S;
+    const void* actions;
+    const double* noise_z;
+    double* noise_z_out;
+    double* reward;
+    uint8_t* done;
+    uint8_t* collided_now;
+    int32_t* err;
+    int32_t* pending_count;    // [kShards] this step's counters of parked envs (one per shard: no hot atomic)
+    int32_t* pending_next;     // [kShards] the next step's counters (the two sets alternate); kernel 1 zeroes them
+    // adaptive split between "settle in place" and "park for kernel 2" (nullptr: S->dense_threshold is used as is):
+    // kernel 2 of step t counts the undecided poses of step t and picks the threshold of step t + 1
+    const int32_t* threshold_now;
+    int32_t* threshold_next;
+    int32_t* inplace_count;    // undecided poses settled inside kernel 1 this step (the parked ones are in pending_count)
+    int32_t* inplace_next;     // next step's counter; kernel 1 zeroes it
+    uint64_t seed, step_counter;
+    uint32_t flags;
+};
+
+// Ablation switches in the upper half of the step flags (tools/ablate*.py time the step with stages removed; results
+// are then WRONG by construction).  Not part of the ABI: bcplan.h only defines bits 0-1.
+enum : uint32_t {
+    kAblateNoCollision = 1u << 16,   // skip pose_collides altogether
+    kAblateNoReward = 1u << 17,      // skip the reward scan
+    kAblateNoCoop = 1u << 19,        // kernel 2: skip the cooperative rasteriser
+    kAblateNoPark = 1u << 21,        // kernel 1: do not park undecided envs
+    kAblateNoClassify = 1u << 22     // kernel 1: skip the distance-field lookups
+};
+
+
+constexpr int kBlock = 64;  // one wavefront per workgroup
+
+// uint8 costmap -> 1-bit lethal mask.  One thread per 32-bit output word.
+__global__ void pack_bitmap_kernel(const uint8_t* __restrict__ data, uint32_t* __restrict__ bits, int64_t n_maps,
+                                   int rows, int cols, int wpr, const int32_t* __restrict__ valid_rows,
+                                   const int32_t* __restrict__ valid_cols)
+{
+    const int64_t total = n_maps * rows * wpr;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(idx % wpr);
+        const int64_t t = idx / wpr;
+        const int r = (int)(t % rows);
+        const int64_t m = t / rows;
+        const int vr = valid_rows ? valid_rows[m] : rows;
+        const int vc = valid_cols ? valid_cols[m] : cols;
+        uint32_t word = 0;
+        if (r < vr) {
+            const uint8_t* src = data + (m * rows + r) * (int64_t)cols + (int64_t)w * 32;
+            const int lim = min(32, vc - w * 32);
+            for (int b = 0; b < lim; ++b) word |= (uint32_t)(src[b] == BCP_LETHAL) << b;
+        }
+        bits[idx] = word;
+    }
+}
+
+// path [.,3] -> [.,5] with cos/sin of the heading (utilities/path_tools.py:405)
+__global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restrict__ out, int64_t total)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const double th = xyt[3 * i + 2];
+        out[5 * i + 0] = xyt[3 * i + 0];
+        out[5 * i + 1] = xyt[3 * i + 1];
+        out[5 * i + 2] = th;
+        out[5 * i + 3] = cos(th);
+        out[5 * i + 4] = sin(th);
+    }
+}
+
+constexpr int kPathBuckets = 64;
+
+// Per path: bounding box of the way points and a 1-D bucket grid per axis over [min - sp, max + sp].
+__global__ void path_bbox_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
+                                 int64_t n_paths, double sp_prune, double* __restrict__ bbox)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_paths) return;
+    const int m = lens ? lens[p] : max_len;
+    const double* q = xyt + p * (int64_t)max_len * 3;
+    double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    for (int j = 0; j < m; ++j) {
+        x0 = fmin(x0, q[3 * j]);
+        x1 = fmax(x1, q[3 * j]);
+        y0 = fmin(y0, q[3 * j + 1]);
+        y1 = fmax(y1, q[3 * j + 1]);
+    }
+    double* o = bbox + 8 * p;
+    o[0] = x0;
+    o[1] = x1;
+    o[2] = y0;
+    o[3] = y1;
+    const double wx = fmax((x1 - x0 + 2.0 * sp_prune) / kPathBuckets, 1e-9);
+    const double wy = fmax((y1 - y0 + 2.0 * sp_prune) / kPathBuckets, 1e-9);
+    o[4] = x0 - sp_prune;
+    o[5] = 1.0 / wx;
+    o[6] = y0 - sp_prune;
+    o[7] = 1.0 / wy;
+}
+
+// index[p][axis][b] = {first, last} way point whose coordinate lies within sp of bucket b (widened by a guard band
+// that swallows the rounding of the bucket computation); {32767, -1} when there is none.  Any way point with
+// |x_j - x| <= sp_prune for a query x that falls into bucket b is inside [first, last].
+__global__ void path_index_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
+                                  int64_t n_paths, double sp_prune, const double* __restrict__ bbox,
+                                  int16_t* __restrict__ index)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_paths * 2 * kPathBuckets) return;
+    const int b = (int)(t % kPathBuckets);
+    const int axis = (int)((t / kPathBuckets) % 2);
+    const int64_t p = t / (2 * kPathBuckets);
+    const int m = lens ? lens[p] : max_len;
+    const double* q = xyt + p * (int64_t)max_len * 3;
+    const double o = bbox[8 * p + 4 + 2 * axis], w = 1.0 / bbox[8 * p + 5 + 2 * axis];
+    const double guard = 1e-6 * w + 1e-12;
+    const double lo = o + b * w - sp_prune - guard, hi = o + (b + 1) * w + sp_prune + guard;
+    int first = 32767, last = -1;
+    for (int j = 0; j < m; ++j) {
+        const double v = q[3 * j + axis];
+        if (v >= lo && v <= hi) {
+            first = min(first, j);
+            last = j;
+        }
+    }
+    index[2 * t] = (int16_t)first;
+    index[2 * t + 1] = (int16_t)last;
+}
+
+// find_last_reached restricted to j >= target (utilities/path_tools.py:408-448): the reward only asks whether the
+// LAST reached index is >= target_idx (envs/base/reward.py:234), so indices below target never matter.
+// A way point can only be reached when |x_j - x| and |y_j - y| are both below spatial_precision, so the scan is
+// confined to the index window the two bucket tables allow for this pose (usually a handful of way points).
+// index window [lo, hi] of the way points that can be within spatial_precision of (x, y); empty when lo > hi
+struct PathWindow {
+    int lo, hi;
+};
+
+__device__ __forceinline__ PathWindow path_window(const DevParams& P, const double* __restrict__ bbox,
+                                                  const int16_t* __restrict__ index, double x, double y)
+{
+    PathWindow w;
+    w.lo = 0;
+    w.hi = -1;
+    if (x < bbox[0] - P.sp_prune || x > bbox[1] + P.sp_prune || y < bbox[2] - P.sp_prune || y > bbox[3] + P.sp_prune)
+        return w;  // farther than spatial_precision from the bounding box of the whole path
+    const int bx = min(max((int)floor((x - bbox[4]) * bbox[5]), 0), kPathBuckets - 1);
+    const int by = min(max((int)floor((y - bbox[6]) * bbox[7]), 0), kPathBuckets - 1);
+    const int16_t* ix = index + 2 * bx;
+    const int16_t* iy = index + 2 * (kPathBuckets + by);
+    w.lo = max((int)ix[0], (int)iy[0]);
+    w.hi = min((int)ix[1], (int)iy[1]);
+    return w;
+}
+
+template <typename PathPtr>
+__device__ __forceinline__ int last_reached_from(const DevParams& P, PathPtr path, PathWindow w, int m, int target,
+                                                 double x, double y, double th)
+{
+    if (target > m - 1) return -1;
+    const int lo = max(w.lo, target);
+    const int hi = min(w.hi, m - 1);
+    for (int j = hi; j >= lo; --j) {
+        const PathPtr s = path + 5 * j;
+        // all five values of the way point are fetched up front (one latency instead of three dependent ones)
+        const double sx = s[0], sy = s[1], sth = s[2], sc = s[3], ss = s[4];
+        const double dx = sx - x, dy = sy - y;
+        // the three reach conditions are independent predicates; evaluate the cheap ones first
+        if (fabs(dx) > P.sp_prune || fabs(dy) > P.sp_prune) continue;   // then hypot(dx,dy) >= sp
+        const double par = sc * (x - sx) + ss * (y - sy);               // path_tools.py:405
+        if (!(par >= P.par_thr)) continue;
+        const double q = dx * dx + dy * dy;
+        bool near = q < P.sp2_lo;
+        if (!near && q <= P.sp2_hi) near = hypot(dx, dy) < P.sp;        // too close to call from q
+        if (!near) continue;
+        if (fabs(normalize_angle(th - sth)) < P.ap) return j;
+    }
+    return -1;
+}
+
+// ContinuousRewardProvider.reward (envs/base/reward.py:214-259)
+template <typename PathPtr>
+__device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path, PathWindow w, int m, double x, double y,
+                                              double th, double& min_dist, int& target)
+{
+    if (target > m - 1) return 0.0;
+    const int last = last_reached_from(P, path, w, m, target, x, y, th);
+    if (last >= 0) {
+        target = last + 1;
+        if (!(target > m - 1)) {
+            const PathPtr g = path + 5 * target;
+            min_dist = hypot(g[0] - x, g[1] - y);
+        } else {
+            min_dist = 0.0;
+        }
+        return 1.0;
+    }
+    const PathPtr g = path + 5 * target;
+    const double d = hypot(g[0] - x, g[1] - y);
+    if (d < min_dist) {
+        const double r = min_dist - d;
+        min_dist = d;
+        return r * P.progress_mult;
+    }
+    return 0.0;
+}
+
+// ContinuousRewardPurePursuitProvider.reward (envs/base/reward.py:330-353) with update_goal (:125-139): the target is
+// the first way point from target_idx on that is more than 2 m away (np.linalg.norm = sqrt of an fma-contracted
+// 2-term dot product, like every 2-element np.dot in this code base), the goal is always the LAST way point.
+template <typename PathPtr>
+__device__ __forceinline__ double reward_pure_pursuit(PathPtr path, int m, double x, double y, bool collided,
+                                                      double& min_dist, int& target)
+{
+    int found = m - 1;
+    for (int i = target; i < m; ++i) {
+        const double dx = path[5 * i] - x, dy = path[5 * i + 1] - y;
+        if (sqrt(fma(dy, dy, dx * dx)) > 2.) {
+            found = i;
+            break;
+        }
+    }
+    target = found;
+    const PathPtr g = path + 5 * (m - 1);
+    const double dist = hypot(g[0] - x, g[1] - y);
+    double reward = -0.05;
+    reward += min_dist - dist;
+    min_dist = dist;
+    if (collided) reward -= 100;
+    return reward;
+}
+
+// _get_element_from_list_with_delay (envs/base/env.py:27-49) for the k-th push since the last reset: queue q is
+// [delay][W][n]; element k lives in slot (k - 1) % delay.  `v` holds the new element on entry, the delayed one on exit.
+template <int W>
+__device__ __forceinline__ void fifo_delay(double* __restrict__ q, int delay, int64_t n, int64_t i, int k, double (&v)[W])
+{
+    if (delay <= 0) return;
+    const int slot = (k - 1) % delay;
+    double* cell = q + ((int64_t)slot * W) * n + i;
+    if (k <= delay) {   // the list is not longer than `delay` yet: append, hand back the first element
+#pragma unroll
+        for (int c = 0; c < W; ++c) cell[c * n] = v[c];
+        if (k > 1) {
+#pragma unroll
+            for (int c = 0; c < W; ++c) v[c] = q[c * n + i];
+        }
+    } else {            // pop(0): element k - delay, whose slot the new element takes
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            const double first = cell[c * n];
+            cell[c * n] = v[c];
+            v[c] = first;
+        }
+    }
+}
+
+#ifdef BCP_DIAG
+__device__ unsigned long long g_diag[1024 * 8];
+__device__ unsigned long long g_diag1[1024 * 8];
+#define DIAG1_STAMP(k) do { if (threadIdx.x == 0) g_diag1[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DIAG_STAMP(k) do { if (threadIdx.x == 0) g_diag[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int bcp_diag_read(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(g_diag));
+}
+extern "C" int bcp_diag1_read(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag1), sizeof(g_diag1));
+}
+#else
+#define DIAG_STAMP(k) do { } while (0)
+#define DIAG1_STAMP(k) do { } while (0)
+#endif
+
+constexpr int kShards = 64;  // a wave parks into shard (block index % kShards)
+
+// dynamic LDS of the collision kernels:
+//   [lethal bitmap words (when the shared map is staged)] [qverts: n_verts * 2 doubles] [vertex scratch of the
+//   per-thread rasteriser: n_verts * 2 * kBlock words]
+extern __shared__ uint32_t lds_dyn[];
+
+struct CollisionLds {
+    bool staged;      // the shared lethal bitmap sits at LDS offset 0
+    LdsWords bits;
+    LdsF64 qverts;
+    VertLds scratch;
+};
+
+__device__ __forceinline__ CollisionLds collision_lds_setup(const DevParams& P, const MapDesc& map, int tid)
+{
+    CollisionLds L;
+    const int map_words = map.in_lds ? map.rows * map.wpr : 0;
+    const LdsU32 lds = (LdsU32)lds_dyn;
+    for (int k = tid; k < map_words; k += kBlock) lds[k] = map.bits[k];
+    const int q_off = (map_words + 1) & ~1;  // 8-byte alignment for the doubles
+    __attribute__((address_space(3))) double* q = (__attribute__((address_space(3))) double*)(lds + q_off);
+    for (int k = tid; k < 2 * P.n_verts; k += kBlock) q[k] = P.qverts[k >> 1][k & 1];
+    L.staged = map.in_lds != 0;
+    L.bits = lds;
+    L.qverts = q;
+    L.scratch.base = lds + q_off + 4 * P.n_verts + tid;
+    L.scratch.stride = kBlock;
+    __syncthreads();
+    return L;
+}
+
+static size_t collision_lds_bytes(int n_verts, int in_lds, int rows, int wpr)
+{
+    size_t words = in_lds ? (size_t)rows * wpr : 0;
+    words = (words + 1) & ~(size_t)1;
+    words += 4 * (size_t)n_verts;            // qverts (doubles)
+    words += 2 * (size_t)n_verts * kBlock;   // per-thread vertex scratch
+    return words * sizeof(uint32_t);
+}
+
+// pose_collides (envs/base/env.py:464-489) for the pose held by each lane.  EVERY lane of the wave must call this
+// (inactive lanes pass active = false): ambiguous poses are settled one at a time by the whole wave.
+__device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc& map, const CullDesc& cull,
+                                              const CollisionLds& L, int exact_mode, int dense_threshold, bool wide,
+                                              bool active, int64_t env, double x, double y, double th)
+{
+    double ox = map.ox, oy = map.oy;
+    if (map.origins) {
+        ox = map.origins[2 * env + 0];
+        oy = map.origins[2 * env + 1];
+    }
+    const int px = (int)rint((x - ox) * map.inv_res);   // world_to_pixel, coordinate_transformations.py:185-205
+    const int py = (int)rint((y - oy) * map.inv_res);
+    const double c = cos(th), s = sin(th);
+    int cls = active ? classify(cull, map.shared ? 0 : env, map.rows, map.cols, px, py, c, s) : kFree;
+    bool hit = cls == kHit;
+    uint64_t amb = __ballot(cls == kAmbiguous);
+    if (amb == 0) return hit;
+    const bool dense = exact_mode == 2 || (exact_mode == 0 && (int)__popcll(amb) > dense_threshold);
+    if (dense) {
+        // many undecided lanes: one per-thread rasteriser pass settles them all at once
+        if (cls == kAmbiguous) {
+            if (L.staged) {
+                CollisionSink<LdsWords> sink{L.bits, map.rows, map.cols, map.wpr, px, py};
+                hit = raster_runs(P, c, s, L.scratch, sink);
+            } else {
+                const uint32_t* words = map.bits + (map.shared ? 0 : env * map.env_stride);
+                CollisionSink<const uint32_t*> sink{words, map.rows, map.cols, map.wpr, px, py};
+                hit = raster_runs(P, c, s, L.scratch, sink);
+            }
+        }
+        return hit;
+    }
+    // few undecided lanes: the wave rasterises them cooperatively, one pose at a time
+    const int ln = lane_id();
+    const double vqx = ln < P.n_verts ? L.qverts[2 * ln] : 0.0, vqy = ln < P.n_verts ? L.qverts[2 * ln + 1] : 0.0;
+    while (amb) {
+        const int src = __ffsll((unsigned long long)amb) - 1;
+        amb &= amb - 1;
+        const double c_ = bcast_d(c, src), s_ = bcast_d(s, src);
+        const int px_ = bcast_i(px, src), py_ = bcast_i(py, src);
+        bool h;
+        if (L.staged) {
+            h = coop_collides(P, vqx, vqy, c_, s_, px_, py_, L.bits, map.rows, map.cols, map.wpr, wide);
+        } else {
+            const int64_t env_ = ((int64_t)bcast_i((int)(env >> 32), src) << 32) | (uint32_t)bcast_i((int)env, src);
+            const uint32_t* words = map.bits + (map.shared ? 0 : env_ * map.env_stride);
+            h = coop_collides(P, vqx, vqy, c_, s_, px_, py_, words, map.rows, map.cols, map.wpr, wide);
+        }
+        if (lane_id() == src) hit = h;
+    }
+    return hit;
+}
+
+// One env's state after the robot model ran, before the collision verdict is known.
+struct Pending {
+    double c, s;        // cos / sin of the new heading (as used by the classification)
+    int32_t px, py;     // world_to_pixel of the new position
+    Robot r;            // after robot.step()
+    Pose old;           // pose before the step (rollback target)
+    double min_dist;
+    double z[3];
+    int32_t target, iter, err, drawn;
+    int32_t collided;   // sticky flag before this step
+    int32_t env_lo, env_hi;
+    int32_t geom;       // geometry-pool entry of the env during this step (pool mode only)
+};
+
+// entry of the non-shared map / path arrays that env i uses
+__device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const Pending& q)
+{
+    return S->geom_of_env ? (int64_t)q.geom : i;
+}
+
+// Everything of PlanEnv.step() that follows pose_collides(): rollback (env.py:458-459), bookkeeping and delay queues
+// (:377-396), reward (:352), done (:407-419), outputs, optional reset, state write-back.  Runs on one lane for env i.
+// PLAIN = true (the two-kernel step: no delays, continuous reward provider -- see step_uses_deferral) compiles the
+// delay queues and the pure-pursuit branch out.
+template <bool PLAIN>
+__device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
+                                             const PathWindow* free_window = nullptr)
+{
+    const DevParams& P = a.S->P;
+    const int pose_delay = PLAIN ? 0 : P.pose_delay, state_delay = PLAIN ? 0 : P.state_delay;
+    const bool pure_pursuit = !PLAIN && P.reward_provider == BCP_REWARD_PURE_PURSUIT;
+    const bool tri = P.model == BCP_MODEL_TRICYCLE;
+    const int64_t n = a.S->n;
+    Robot& r = q.r;
+    if (hit) {  // robot.set_pose(*old_position): pose restored, v = w = 0 (tricycle_model.py:471-476)
+        r.p = q.old;
+        r.v = 0.0;
+        r.w = 0.0;
+    }
+    int iter = q.iter + 1;
+    bool collided = q.collided != 0 || hit;
+    double min_dist = q.min_dist;
+    int target = q.target;
+    // State.pose / State.robot_state: what the reward provider and the observation see (env.py:377-394)
+    double seen[3] = {r.p.x, r.p.y, r.p.th};
+    double seen_rs[7] = {r.p.x, r.p.y, r.p.th, r.v, r.w, r.steer, r.wheel};
+    if (pose_delay) fifo_delay<3>(a.S->st.pose_q, pose_delay, n, i, iter, seen);
+    if (state_delay) fifo_delay<7>(a.S->st.state_q, state_delay, n, i, iter, seen_rs);
+
+    // shared path: uniform pointers (scalar cache); private paths: per-lane pointers
+    double rew = 0.0;
+    int m;
+    bool goal;
+    const int64_t g = slot_of(a.S, i, q);
+    const double* pts = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
+    m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
+    if (pure_pursuit) {
+        if (!(a.flags & kAblateNoReward)) rew = reward_pure_pursuit(pts, m, seen[0], seen[1], collided, min_dist, target);
+        goal = hypot(pts[5 * (m - 1)] - seen[0], pts[5 * (m - 1) + 1] - seen[1]) < 1.0;   // done(), reward.py:141-150
+    } else {
+        if (!(a.flags & kAblateNoReward)) {
+            // way-point window of the pose: the caller may have looked it up already for the un-rolled-back pose
+            const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : g * 8);
+            const int16_t* index = a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
+            const PathWindow w =
+                (free_window && !hit && !pose_delay) ? *free_window : path_window(P, bbox, index, seen[0], seen[1]);
+            if (lds_path && a.S->path.shared)  // way points staged in LDS by the step kernel
+                rew = reward_step(P, lds_path, w, m, seen[0], seen[1], seen[2], min_dist, target);
+            else
+                rew = reward_step(P, pts, w, m, seen[0], seen[1], seen[2], min_dist, target);
+        }
+        goal = target > m - 1;
+    }
+    const bool done = goal || (iter >= P.iteration_timeout) || collided;
+    if (free_window) DIAG1_STAMP(5);
+
+    a.reward[i] = rew;
+    a.done[i] = (uint8_t)done;
+    if (a.collided_now) a.collided_now[i] = (uint8_t)hit;
+    if (a.err) a.err[i] = q.err;
+    if (a.noise_z_out) {
+        const double nan = __builtin_nan("");
+        a.noise_z_out[3 * i + 0] = (q.drawn & 1) ? q.z[0] : nan;
+        a.noise_z_out[3 * i + 1] = (q.drawn & 2) ? q.z[1] : nan;
+        a.noise_z_out[3 * i + 2] = (q.drawn & 4) ? q.z[2] : nan;
+    }
+
+    if (done && (a.flags & BCP_STEP_AUTO_RESET)) {  // PlanEnv.reset(): set_state(initial_state) (env.py:293-303)
+        int64_t k = i;
+        if (a.S->geom_of_env) {  // RandomMiniEnv.reset(): the env moves on to its next geometry (mini_env.py:469-481).
+            // Computed from the entry the step started with, so kernel 2 redoing an env that kernel 1 already reset
+            // lands on the same geometry (a hit always ends the episode, so both reset or neither does).
+            k = a.S->next_geom ? a.S->next_geom[g] : g;
+            a.S->geom_of_env[i] = (int32_t)k;
+        }
+        r.p.x = a.S->init.x[k];
+        r.p.y = a.S->init.y[k];
+        r.p.th = a.S->init.angle[k];
+        r.v = a.S->init.v[k];
+        r.w = a.S->init.w[k];
+        if (tri) {
+            r.steer = a.S->init.steer[k];
+            r.wheel = a.S->init.wheel[k];
+        }
+        min_dist = a.S->init.min_dist[k];
+        target = a.S->init.target_idx[k];
+        iter = a.S->init.cur_iter[k];
+        collided = a.S->init.collided[k] != 0;
+        // the restored State exposes the initial pose / robot state; its queues are empty (pushes restart at k = 1)
+        seen[0] = r.p.x;
+        seen[1] = r.p.y;
+        seen[2] = r.p.th;
+        seen_rs[0] = r.p.x;
+        seen_rs[1] = r.p.y;
+        seen_rs[2] = r.p.th;
+        seen_rs[3] = r.v;
+        seen_rs[4] = r.w;
+        seen_rs[5] = r.steer;
+        seen_rs[6] = r.wheel;
+    }
+
+    if (free_window) DIAG1_STAMP(6);
+    a.S->st.x[i] = r.p.x;
+    a.S->st.y[i] = r.p.y;
+    a.S->st.angle[i] = r.p.th;
+    a.S->st.v[i] = r.v;
+    a.S->st.w[i] = r.w;
+    if (tri) {
+        a.S->st.steer[i] = r.steer;
+        a.S->st.wheel[i] = r.wheel;
+    }
+    a.S->st.min_dist[i] = min_dist;
+    a.S->st.target_idx[i] = target;
+    a.S->st.cur_iter[i] = iter;
+    a.S->st.collided[i] = (uint8_t)collided;
+    if (pose_delay) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.S->st.pose_seen[c * n + i] = seen[c];
+    }
+    if (state_delay) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) a.S->st.state_seen[c * n + i] = seen_rs[c];
+    }
+}
+
+// ---- loads shared by the step kernels ------------------------------------------------------------------------
+template <bool PLAIN>
+__device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, bool active, Pending& q, double& cmd0, double& cmd1)
+{
+    const DevParams& P = a.S->P;
+    Robot& r = q.r;
+    r.p.x = a.S->st.x[i];
+    r.p.y = a.S->st.y[i];
+    r.p.th = a.S->st.angle[i];
+    r.v = a.S->st.v[i];
+    r.w = a.S->st.w[i];
+    const bool tri = P.model == BCP_MODEL_TRICYCLE;
+    r.steer = tri ? a.S->st.steer[i] : 0.0;
+    r.wheel = tri ? a.S->st.wheel[i] : 0.0;
+    q.min_dist = a.S->st.min_dist[i];
+    q.target = a.S->st.target_idx[i];
+    q.iter = a.S->st.cur_iter[i];
+    q.collided = a.S->st.collided[i] != 0;
+    q.geom = a.S->geom_of_env ? a.S->geom_of_env[i] : 0;
+    if (a.flags & BCP_STEP_ACTIONS_F32) {
+        const float2 c = reinterpret_cast<const float2*>(a.actions)[i];
+        cmd0 = (double)c.x;
+        cmd1 = (double)c.y;
+    } else {
+        const double2 c = reinterpret_cast<const double2*>(a.actions)[i];
+        cmd0 = c.x;
+        cmd1 = c.y;
+    }
+    if (!PLAIN && P.control_delay && active) {   // the robot executes the command given control_delay steps ago (env.py:371-373)
+        double cmd[2] = {cmd0, cmd1};
+        fifo_delay<2>(a.S->st.control_q, P.control_delay, a.S->n, i, q.iter + 1, cmd);
+        cmd0 = cmd[0];
+        cmd1 = cmd[1];
+    }
+    q.z[0] = q.z[1] = q.z[2] = 0.0;
+    if (P.noise_on) {
+        if (a.noise_z) {
+            q.z[0] = a.noise_z[3 * i + 0];
+            q.z[1] = a.noise_z[3 * i + 1];
+            q.z[2] = a.noise_z[3 * i + 2];
+        } else {
+            device_normals(a.seed, (uint64_t)(a.S->env_id_base + i), a.step_counter, q.z);
+        }
+    }
+}
+
+// General step kernel: robot model, collision settled in place by collides_wave (distance-field classification when
+// there is one, then the cooperative / per-thread exact rasterisers), reward, done, write-back.  Used when there
+// is no distance field, when the batch is too small to need load balancing, or when a mode is forced.
+__global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
+{
+    const DevParams& P = a.S->P;
+    const int tid = threadIdx.x;
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
+    const bool active = gi < a.S->n;
+    const int64_t i = active ? gi : a.S->n - 1;  // inactive lanes of the last wave shadow env n-1 and never store
+
+    const CollisionLds L = collision_lds_setup(P, a.S->map, tid);
+    Pending q;
+    double cmd0, cmd1;
+    load_env<false>(a, i, active, q, cmd0, cmd1);
+
+    // ---- _env_step (envs/base/env.py:442-461)
+    q.old = q.r.p;
+    q.drawn = 0;
+    q.err = robot_step(P, q.r, cmd0, cmd1, q.z, q.drawn);
+    bool hit = false;
+    if (!(a.flags & kAblateNoCollision))
+        hit = collides_wave(P, a.S->map, a.S->cull, L, a.S->exact_mode, a.S->dense_threshold, a.S->wide != 0, active,
+                            slot_of(a.S, i, q), q.r.p.x, q.r.p.y, q.r.p.th);
+    if (!active) return;
+    finalize_env<false>(a, i, q, hit);
+}
+
+
+// Fast step kernel (kernel 1 of the two-kernel step; needs a distance field).  A pose is cleared in O(1) by the
+// outer test; the few envs it cannot clear are finished optimistically ("free") AND parked in `pending`, and kernel 2
+// redoes those that really collide.  Waves with many undecided lanes (robots hugging walls) settle them in place.
+// Memory operations are grouped so that independent round trips overlap: every wave runs alone on its SIMD, so an
+// exposed L2 / HBM latency is pure stall.
+template <bool WIDE>
+__global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
+{
+    const DevParams& P = a.S->P;
+    const int tid = threadIdx.x;
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
+    const bool active = gi < a.S->n;
+    const int64_t i = active ? gi : a.S->n - 1;
+    DIAG1_STAMP(0);
+
+    // (1) loads for the LDS staging of the scaled footprint and of the shared path (up to 8 doubles per lane per
+    //     round), issued first ...
+    __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
+    const int nq = 2 * P.n_verts;
+    const double my_q = tid < nq ? P.qverts[tid >> 1][tid & 1] : 0.0;
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = u * kBlock + tid;
+        t[u] = k < a.S->lds_path_doubles ? a.S->path.pts[k] : 0.0;
+    }
+    // (2) ... then state, action, noise (the first-touch lines of this step): all of it is in flight together
+    Pending q;
+    double cmd0, cmd1;
+    load_env<true>(a, i, active, q, cmd0, cmd1);
+    if (gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
+    if (gi == 0 && a.inplace_next) *a.inplace_next = 0;
+    // (3) LDS writes (the staging loads return first, in issue order)
+    if (tid < nq) qv[tid] = my_q;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = u * kBlock + tid;
+        if (k < a.S->lds_path_doubles) qv[nq + k] = t[u];
+    }
+    for (int k = 8 * kBlock + tid; k < a.S->lds_path_doubles; k += kBlock) qv[nq + k] = a.S->path.pts[k];  // long paths
+    __syncthreads();
+    DIAG1_STAMP(1);
+    const LdsF64 lds_path = a.S->lds_path_doubles ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
+
+    // ---- _env_step (envs/base/env.py:442-461)
+    Robot& r = q.r;
+    q.old = r.p;
+    q.drawn = 0;
+    q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
+    DIAG1_STAMP(2);
+
+    // (3) everything that depends only on the new pose is looked up together: distance-field samples and the
+    //     way-point window of the reward
+    const int64_t g = slot_of(a.S, i, q);
+    double ox = a.S->map.ox, oy = a.S->map.oy;
+    if (a.S->map.origins) {
+        ox = a.S->map.origins[2 * g + 0];
+        oy = a.S->map.origins[2 * g + 1];
+    }
+    const int px = (int)rint((r.p.x - ox) * a.S->map.inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
+    const int py = (int)rint((r.p.y - oy) * a.S->map.inv_res);
+    const double c = cos(r.p.th), s = sin(r.p.th);
+    const int64_t map_env = a.S->map.shared ? 0 : g;
+    OuterLookups look;
+    look.off_map = true;
+    if (!(a.flags & (kAblateNoCollision | kAblateNoClassify))) look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
+    const PathWindow win = path_window(P, a.S->path.bbox + (a.S->path.shared ? 0 : g * 8),
+                                       a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets)), r.p.x, r.p.y);
+    const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
+    DIAG1_STAMP(3);
+
+    bool hit = false;
+    const uint64_t amb = __ballot(cls == kAmbiguous);
+    const int n_amb = (int)__popcll(amb);
+    const int threshold = a.threshold_now ? *a.threshold_now : a.S->dense_threshold;
+    if (n_amb > threshold) {
+        // many undecided lanes in this wave: settle them in place, one pose at a time by the whole wave
+        if (tid == 0 && a.inplace_count) atomicAdd(a.inplace_count, n_amb);
+        const bool inner = cls == kAmbiguous && classify_inner_hit(a.S->cull, map_env, px, py, c, s);
+        hit = inner;
+        uint64_t todo = __ballot(cls == kAmbiguous && !inner);
+        const double vqx = tid < P.n_verts ? qv[2 * tid] : 0.0, vqy = tid < P.n_verts ? qv[2 * tid + 1] : 0.0;
+        while (todo) {
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const int64_t env_ = ((int64_t)bcast_i((int)(g >> 32), src) << 32) | (uint32_t)bcast_i((int)g, src);
+            const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : env_ * a.S->map.env_stride);
+            const bool h = coop_collides<WIDE>(P, vqx, vqy, bcast_d(c, src), bcast_d(s, src), bcast_i(px, src),
+                                               bcast_i(py, src), words, a.S->map.rows, a.S->map.cols, a.S->map.wpr);
+            if (tid == src) hit = h;
+        }
+    } else if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
+        // a few undecided lanes: park the pre-verdict state for kernel 2 (load-balanced over the whole GPU) and carry
+        // on as if the pose were free, which it is for nearly every parked env
+        const int shard = (int)(blockIdx.x % kShards);
+        const int slot = atomicAdd(a.pending_count + shard, 1);
+        q.c = c;
+        q.s = s;
+        q.px = px;
+        q.py = py;
+        q.env_lo = (int32_t)(uint32_t)i;
+        q.env_hi = (int32_t)(i >> 32);
+        a.S->pending[(int64_t)slot * kShards + shard] = q;  // interleaved: the used slots stay in a few pages
+    }
+    DIAG1_STAMP(4);
+    if (!active) return;
+    finalize_env<true>(a, i, q, hit, lds_path, &win);
+    DIAG1_STAMP(7);
+}
+
+// Kernel 2 of a step: kPendingWaves wavefronts per parked env: the lanes rasterise
+// the footprint together (coop_collides, wave w takes the row chunks w, w+2, ...); on a collision thread 0 redoes
+// the env's finalisation from the parked state.  The first entry is fetched speculatively, together with the
+// counter that says whether it exists, so the two round trips overlap.
+constexpr int kPendingWaves = 4;  // wave = 2 * (row-chunk slot) + (edge slot)
+constexpr int kParkCapacity = 8192;  // undecided poses per step that kernel 2 takes without the waves' help
+
+template <bool WIDE>
+__global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(const StepArgs a)
+{
+    DIAG_STAMP(0);
+    const DevParams& P = a.S->P;
+    const int lane = threadIdx.x % kBlock, wave = threadIdx.x / kBlock;
+    const int shard = (int)(blockIdx.x % kShards);
+    const int stride = gridDim.x / kShards;
+    const Pending* slots = a.S->pending + shard;
+    const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
+    const int count = a.pending_count[shard];
+    if (blockIdx.x == 0 && a.threshold_next && threadIdx.x < kShards) {
+        // Undecided poses of this step, parked + settled in place.  Few of them: kernel 2 absorbs them all in one or
+        // two rounds, so the next step parks everything (no wave is held up by its own unlucky lanes).  Many (robots
+        // hugging walls everywhere): kernel 2 would need dozens of rounds, the waves settle their own instead.
+        int total = a.pending_count[threadIdx.x];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+        if (threadIdx.x == 0) *a.threshold_next = total + *a.inplace_count <= kParkCapacity ? 64 : a.S->dense_threshold;
+    }
+    for (int idx = blockIdx.x / kShards; idx < a.S->pending_cap; idx += stride) {
+        const Pending* e = slots + (int64_t)idx * kShards;   // in bounds whatever `count` says
+        const double c = e->c, s = e->s;
+        const int px = e->px, py = e->py;
+        const int64_t i = ((int64_t)e->env_hi << 32) | (uint32_t)e->env_lo;
+        const int64_t g = a.S->geom_of_env ? (int64_t)e->geom : i;
+        if (idx >= count) break;
+        DIAG_STAMP(1);
+        const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : g * a.S->map.env_stride);
+        // (no inner distance-field test here: nearly every parked pose is free, so the test would cost a dependent
+        //  round trip per pose and almost never spare the rasteriser)
+        bool hit = false;
+        DIAG_STAMP(2);
+        if (!(a.flags & kAblateNoCoop))
+            hit = coop_collides_quad<WIDE>(P, vqx, vqy, c, s, px, py, words, a.S->map.rows, a.S->map.cols, a.S->map.wpr, wave,
+                                           (LdsU32)lds_dyn);
+        DIAG_STAMP(3);
+        hit = __syncthreads_or(hit);  // wave-uniform verdicts of the block's waves
+        DIAG_STAMP(4);
+        // kernel 1 already finished this env as "free"; only a collision changes anything
+        if (hit && threadIdx.x == 0) {
+            Pending q = *e;
+            finalize_env<true>(a, i, q, true);
+        }
+    }
+}
+

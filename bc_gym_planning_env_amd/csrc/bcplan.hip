@@ -1,8 +1,9 @@
 // bcplan.hip -- libbcplan.so: batched PlanEnv.step() for MI355X (gfx950).  C ABI in include/bcplan.h.
 //
-// One fused kernel advances every env by one tick:
-//   load SoA state -> robot model (fp64) -> footprint rasterise + lethal-bit test -> rollback on collision
-//   -> ContinuousRewardProvider -> done -> (auto-reset) -> store SoA state.
+// This file holds the handle, the set-up kernels (lethal bitmap, distance transform, path tables), the operator
+// seams and every C entry point.  The step itself lives in bcp_step.h (robot model -> collision classification /
+// exact rasteriser -> rollback -> reward provider -> done -> optional reset -> state write-back; device code in
+// bcp_device.h, bcp_raster.h, bcp_coop.h), the egocentric observation in bcp_ego.h.
 // Compiled with -ffp-contract=off (numpy rounds every product and sum separately).  No CPU path exists here.
 #include <hip/hip_runtime.h>
 
@@ -18,6 +19,8 @@
 #include "bcp_device.h"
 #include "bcp_raster.h"
 #include "bcp_coop.h"
+#include "bcp_step.h"
+#include "bcp_ego.h"
 
 using namespace bcp;
 
@@ -43,87 +46,6 @@ extern "C" const char* bcp_last_error(void) { return g_err; }
 extern "C" int bcp_abi_version(void) { return BCP_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------------------------ handle
-struct DevState {
-    double *x, *y, *angle, *v, *w, *steer, *wheel, *min_dist;
-    int32_t *target_idx, *cur_iter;
-    uint8_t* collided;
-    double *pose_seen, *state_seen;         // [3][n] / [7][n], delays > 0 only
-    double *control_q, *pose_q, *state_q;   // [delay][width][n]
-};
-
-struct MapDesc {
-    const uint32_t* bits;  // lethal bitmap, [rows][wpr] shared or [N][rows][wpr]
-    int32_t rows, cols, wpr;
-    int32_t shared;
-    int32_t in_lds;        // shared bitmap small enough to be staged in LDS
-    int64_t env_stride;    // words per env (0 when shared)
-    const double* origins; // device [N,2] when per-env, else NULL
-    double ox, oy, inv_res;
-};
-
-struct PathDesc {
-    const double* pts;   // [len][5] = x, y, theta, cos(theta), sin(theta); shared or [N][max_len][5]
-    const double* bbox;  // [8] = xmin, xmax, ymin, ymax of the way points, then the bucket grid x0, 1/wx, y0, 1/wy
-    const int16_t* index; // [2 axes][kPathBuckets][2] = first / last way point index that can be reached from a bucket
-    const int32_t* lens;
-    int32_t max_len, shared;
-};
-
-struct Pending;
-
-// Everything a step needs that only changes when the caller re-binds something.  It lives in DEVICE memory (uploaded
-// when dirty) and the kernels get a pointer: kernel arguments sit in host memory on this platform, and a kernel that
-// takes kilobytes of arguments by value pays a PCIe-latency scalar load every time it touches a new field.
-struct StepStatic {
-    DevParams P;
-    MapDesc map;
-    CullDesc cull;
-    PathDesc path;
-    DevState st, init;
-    int64_t n;
-    int64_t env_id_base;
-    int32_t exact_mode, dense_threshold, wide;
-    int32_t pending_cap;       // slots per shard
-    int32_t lds_path_doubles;  // > 0: the shared path (max_len * 5 doubles) is staged in LDS by the fast step kernel
-    struct Pending* pending;   // [kShards][pending_cap] parking slots for undecided envs (nullptr: no second kernel)
-    // geometry pool (bcp_set_geometry_pool): env i uses entry geom_of_env[i] of the non-shared map / path / initial
-    // state arrays; a reset moves it to next_geom[entry].  nullptr: env i uses entry i.
-    int32_t* geom_of_env;
-    const int32_t* next_geom;
-};
-
-// Per-launch kernel arguments (small).
-struct StepArgs {
-    const StepStatic* S;
-    const void* actions;
-    const double* noise_z;
-    double* noise_z_out;
-    double* reward;
-    uint8_t* done;
-    uint8_t* collided_now;
-    int32_t* err;
-    int32_t* pending_count;    // [kShards] this step's counters of parked envs (one per shard: no hot atomic)
-    int32_t* pending_next;     // [kShards] the next step's counters (the two sets alternate); kernel 1 zeroes them
-    // adaptive split between "settle in place" and "park for kernel 2" (nullptr: S->dense_threshold is used as is):
-    // kernel 2 of step t counts the undecided poses of step t and picks the threshold of step t + 1
-    const int32_t* threshold_now;
-    int32_t* threshold_next;
-    int32_t* inplace_count;    // undecided poses settled inside kernel 1 this step (the parked ones are in pending_count)
-    int32_t* inplace_next;     // next step's counter; kernel 1 zeroes it
-    uint64_t seed, step_counter;
-    uint32_t flags;
-};
-
-// Ablation switches in the upper half of the step flags (tools/ablate*.py time the step with stages removed; results
-// are then WRONG by construction).  Not part of the ABI: bcplan.h only defines bits 0-1.
-enum : uint32_t {
-    kAblateNoCollision = 1u << 16,   // skip pose_collides altogether
-    kAblateNoReward = 1u << 17,      // skip the reward scan
-    kAblateNoCoop = 1u << 19,        // kernel 2: skip the cooperative rasteriser
-    kAblateNoPark = 1u << 21,        // kernel 1: do not park undecided envs
-    kAblateNoClassify = 1u << 22     // kernel 1: skip the distance-field lookups
-};
-
 struct bcp_handle {
     bcp_params params;
     DevParams dev;
@@ -204,730 +126,7 @@ static int check_state(const bcp_state* s, int tricycle, const bcp_params* p = n
     return 1;
 }
 
-// ------------------------------------------------------------------------------------------------ kernels
-constexpr int kBlock = 64;  // one wavefront per workgroup
-
-// uint8 costmap -> 1-bit lethal mask.  One thread per 32-bit output word.
-__global__ void pack_bitmap_kernel(const uint8_t* __restrict__ data, uint32_t* __restrict__ bits, int64_t n_maps,
-                                   int rows, int cols, int wpr, const int32_t* __restrict__ valid_rows,
-                                   const int32_t* __restrict__ valid_cols)
-{
-    const int64_t total = n_maps * rows * wpr;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int w = (int)(idx % wpr);
-        const int64_t t = idx / wpr;
-        const int r = (int)(t % rows);
-        const int64_t m = t / rows;
-        const int vr = valid_rows ? valid_rows[m] : rows;
-        const int vc = valid_cols ? valid_cols[m] : cols;
-        uint32_t word = 0;
-        if (r < vr) {
-            const uint8_t* src = data + (m * rows + r) * (int64_t)cols + (int64_t)w * 32;
-            const int lim = min(32, vc - w * 32);
-            for (int b = 0; b < lim; ++b) word |= (uint32_t)(src[b] == BCP_LETHAL) << b;
-        }
-        bits[idx] = word;
-    }
-}
-
-// path [.,3] -> [.,5] with cos/sin of the heading (utilities/path_tools.py:405)
-__global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restrict__ out, int64_t total)
-{
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const double th = xyt[3 * i + 2];
-        out[5 * i + 0] = xyt[3 * i + 0];
-        out[5 * i + 1] = xyt[3 * i + 1];
-        out[5 * i + 2] = th;
-        out[5 * i + 3] = cos(th);
-        out[5 * i + 4] = sin(th);
-    }
-}
-
-constexpr int kPathBuckets = 64;
-
-// Per path: bounding box of the way points and a 1-D bucket grid per axis over [min - sp, max + sp].
-__global__ void path_bbox_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
-                                 int64_t n_paths, double sp_prune, double* __restrict__ bbox)
-{
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_paths) return;
-    const int m = lens ? lens[p] : max_len;
-    const double* q = xyt + p * (int64_t)max_len * 3;
-    double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
-    for (int j = 0; j < m; ++j) {
-        x0 = fmin(x0, q[3 * j]);
-        x1 = fmax(x1, q[3 * j]);
-        y0 = fmin(y0, q[3 * j + 1]);
-        y1 = fmax(y1, q[3 * j + 1]);
-    }
-    double* o = bbox + 8 * p;
-    o[0] = x0;
-    o[1] = x1;
-    o[2] = y0;
-    o[3] = y1;
-    const double wx = fmax((x1 - x0 + 2.0 * sp_prune) / kPathBuckets, 1e-9);
-    const double wy = fmax((y1 - y0 + 2.0 * sp_prune) / kPathBuckets, 1e-9);
-    o[4] = x0 - sp_prune;
-    o[5] = 1.0 / wx;
-    o[6] = y0 - sp_prune;
-    o[7] = 1.0 / wy;
-}
-
-// index[p][axis][b] = {first, last} way point whose coordinate lies within sp of bucket b (widened by a guard band
-// that swallows the rounding of the bucket computation); {32767, -1} when there is none.  Any way point with
-// |x_j - x| <= sp_prune for a query x that falls into bucket b is inside [first, last].
-__global__ void path_index_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
-                                  int64_t n_paths, double sp_prune, const double* __restrict__ bbox,
-                                  int16_t* __restrict__ index)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_paths * 2 * kPathBuckets) return;
-    const int b = (int)(t % kPathBuckets);
-    const int axis = (int)((t / kPathBuckets) % 2);
-    const int64_t p = t / (2 * kPathBuckets);
-    const int m = lens ? lens[p] : max_len;
-    const double* q = xyt + p * (int64_t)max_len * 3;
-    const double o = bbox[8 * p + 4 + 2 * axis], w = 1.0 / bbox[8 * p + 5 + 2 * axis];
-    const double guard = 1e-6 * w + 1e-12;
-    const double lo = o + b * w - sp_prune - guard, hi = o + (b + 1) * w + sp_prune + guard;
-    int first = 32767, last = -1;
-    for (int j = 0; j < m; ++j) {
-        const double v = q[3 * j + axis];
-        if (v >= lo && v <= hi) {
-            first = min(first, j);
-            last = j;
-        }
-    }
-    index[2 * t] = (int16_t)first;
-    index[2 * t + 1] = (int16_t)last;
-}
-
-// find_last_reached restricted to j >= target (utilities/path_tools.py:408-448): the reward only asks whether the
-// LAST reached index is >= target_idx (envs/base/reward.py:234), so indices below target never matter.
-// A way point can only be reached when |x_j - x| and |y_j - y| are both below spatial_precision, so the scan is
-// confined to the index window the two bucket tables allow for this pose (usually a handful of way points).
-// index window [lo, hi] of the way points that can be within spatial_precision of (x, y); empty when lo > hi
-struct PathWindow {
-    int lo, hi;
-};
-
-__device__ __forceinline__ PathWindow path_window(const DevParams& P, const double* __restrict__ bbox,
-                                                  const int16_t* __restrict__ index, double x, double y)
-{
-    PathWindow w;
-    w.lo = 0;
-    w.hi = -1;
-    if (x < bbox[0] - P.sp_prune || x > bbox[1] + P.sp_prune || y < bbox[2] - P.sp_prune || y > bbox[3] + P.sp_prune)
-        return w;  // farther than spatial_precision from the bounding box of the whole path
-    const int bx = min(max((int)floor((x - bbox[4]) * bbox[5]), 0), kPathBuckets - 1);
-    const int by = min(max((int)floor((y - bbox[6]) * bbox[7]), 0), kPathBuckets - 1);
-    const int16_t* ix = index + 2 * bx;
-    const int16_t* iy = index + 2 * (kPathBuckets + by);
-    w.lo = max((int)ix[0], (int)iy[0]);
-    w.hi = min((int)ix[1], (int)iy[1]);
-    return w;
-}
-
-template <typename PathPtr>
-__device__ __forceinline__ int last_reached_from(const DevParams& P, PathPtr path, PathWindow w, int m, int target,
-                                                 double x, double y, double th)
-{
-    if (target > m - 1) return -1;
-    const int lo = max(w.lo, target);
-    const int hi = min(w.hi, m - 1);
-    for (int j = hi; j >= lo; --j) {
-        const PathPtr s = path + 5 * j;
-        // all five values of the way point are fetched up front (one latency instead of three dependent ones)
-        const double sx = s[0], sy = s[1], sth = s[2], sc = s[3], ss = s[4];
-        const double dx = sx - x, dy = sy - y;
-        // the three reach conditions are independent predicates; evaluate the cheap ones first
-        if (fabs(dx) > P.sp_prune || fabs(dy) > P.sp_prune) continue;   // then hypot(dx,dy) >= sp
-        const double par = sc * (x - sx) + ss * (y - sy);               // path_tools.py:405
-        if (!(par >= P.par_thr)) continue;
-        const double q = dx * dx + dy * dy;
-        bool near = q < P.sp2_lo;
-        if (!near && q <= P.sp2_hi) near = hypot(dx, dy) < P.sp;        // too close to call from q
-        if (!near) continue;
-        if (fabs(normalize_angle(th - sth)) < P.ap) return j;
-    }
-    return -1;
-}
-
-// ContinuousRewardProvider.reward (envs/base/reward.py:214-259)
-template <typename PathPtr>
-__device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path, PathWindow w, int m, double x, double y,
-                                              double th, double& min_dist, int& target)
-{
-    if (target > m - 1) return 0.0;
-    const int last = last_reached_from(P, path, w, m, target, x, y, th);
-    if (last >= 0) {
-        target = last + 1;
-        if (!(target > m - 1)) {
-            const PathPtr g = path + 5 * target;
-            min_dist = hypot(g[0] - x, g[1] - y);
-        } else {
-            min_dist = 0.0;
-        }
-        return 1.0;
-    }
-    const PathPtr g = path + 5 * target;
-    const double d = hypot(g[0] - x, g[1] - y);
-    if (d < min_dist) {
-        const double r = min_dist - d;
-        min_dist = d;
-        return r * P.progress_mult;
-    }
-    return 0.0;
-}
-
-// ContinuousRewardPurePursuitProvider.reward (envs/base/reward.py:330-353) with update_goal (:125-139): the target is
-// the first way point from target_idx on that is more than 2 m away (np.linalg.norm = sqrt of an fma-contracted
-// 2-term dot product, like every 2-element np.dot in this code base), the goal is always the LAST way point.
-template <typename PathPtr>
-__device__ __forceinline__ double reward_pure_pursuit(PathPtr path, int m, double x, double y, bool collided,
-                                                      double& min_dist, int& target)
-{
-    int found = m - 1;
-    for (int i = target; i < m; ++i) {
-        const double dx = path[5 * i] - x, dy = path[5 * i + 1] - y;
-        if (sqrt(fma(dy, dy, dx * dx)) > 2.) {
-            found = i;
-            break;
-        }
-    }
-    target = found;
-    const PathPtr g = path + 5 * (m - 1);
-    const double dist = hypot(g[0] - x, g[1] - y);
-    double reward = -0.05;
-    reward += min_dist - dist;
-    min_dist = dist;
-    if (collided) reward -= 100;
-    return reward;
-}
-
-// _get_element_from_list_with_delay (envs/base/env.py:27-49) for the k-th push since the last reset: queue q is
-// [delay][W][n]; element k lives in slot (k - 1) % delay.  `v` holds the new element on entry, the delayed one on exit.
-template <int W>
-__device__ __forceinline__ void fifo_delay(double* __restrict__ q, int delay, int64_t n, int64_t i, int k, double (&v)[W])
-{
-    if (delay <= 0) return;
-    const int slot = (k - 1) % delay;
-    double* cell = q + ((int64_t)slot * W) * n + i;
-    if (k <= delay) {   // the list is not longer than `delay` yet: append, hand back the first element
-#pragma unroll
-        for (int c = 0; c < W; ++c) cell[c * n] = v[c];
-        if (k > 1) {
-#pragma unroll
-            for (int c = 0; c < W; ++c) v[c] = q[c * n + i];
-        }
-    } else {            // pop(0): element k - delay, whose slot the new element takes
-#pragma unroll
-        for (int c = 0; c < W; ++c) {
-            const double first = cell[c * n];
-            cell[c * n] = v[c];
-            v[c] = first;
-        }
-    }
-}
-
-#ifdef BCP_DIAG
-__device__ unsigned long long g_diag[1024 * 8];
-__device__ unsigned long long g_diag1[1024 * 8];
-#define DIAG1_STAMP(k) do { if (threadIdx.x == 0) g_diag1[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define DIAG_STAMP(k) do { if (threadIdx.x == 0) g_diag[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int bcp_diag_read(unsigned long long* out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(g_diag));
-}
-extern "C" int bcp_diag1_read(unsigned long long* out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag1), sizeof(g_diag1));
-}
-#else
-#define DIAG_STAMP(k) do { } while (0)
-#define DIAG1_STAMP(k) do { } while (0)
-#endif
-
-constexpr int kShards = 64;  // a wave parks into shard (block index % kShards)
-
-// dynamic LDS of the collision kernels:
-//   [lethal bitmap words (when the shared map is staged)] [qverts: n_verts * 2 doubles] [vertex scratch of the
-//   per-thread rasteriser: n_verts * 2 * kBlock words]
-extern __shared__ uint32_t lds_dyn[];
-
-struct CollisionLds {
-    bool staged;      // the shared lethal bitmap sits at LDS offset 0
-    LdsWords bits;
-    LdsF64 qverts;
-    VertLds scratch;
-};
-
-__device__ __forceinline__ CollisionLds collision_lds_setup(const DevParams& P, const MapDesc& map, int tid)
-{
-    CollisionLds L;
-    const int map_words = map.in_lds ? map.rows * map.wpr : 0;
-    const LdsU32 lds = (LdsU32)lds_dyn;
-    for (int k = tid; k < map_words; k += kBlock) lds[k] = map.bits[k];
-    const int q_off = (map_words + 1) & ~1;  // 8-byte alignment for the doubles
-    __attribute__((address_space(3))) double* q = (__attribute__((address_space(3))) double*)(lds + q_off);
-    for (int k = tid; k < 2 * P.n_verts; k += kBlock) q[k] = P.qverts[k >> 1][k & 1];
-    L.staged = map.in_lds != 0;
-    L.bits = lds;
-    L.qverts = q;
-    L.scratch.base = lds + q_off + 4 * P.n_verts + tid;
-    L.scratch.stride = kBlock;
-    __syncthreads();
-    return L;
-}
-
-static size_t collision_lds_bytes(int n_verts, int in_lds, int rows, int wpr)
-{
-    size_t words = in_lds ? (size_t)rows * wpr : 0;
-    words = (words + 1) & ~(size_t)1;
-    words += 4 * (size_t)n_verts;            // qverts (doubles)
-    words += 2 * (size_t)n_verts * kBlock;   // per-thread vertex scratch
-    return words * sizeof(uint32_t);
-}
-
-// pose_collides (envs/base/env.py:464-489) for the pose held by each lane.  EVERY lane of the wave must call this
-// (inactive lanes pass active = false): ambiguous poses are settled one at a time by the whole wave.
-__device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc& map, const CullDesc& cull,
-                                              const CollisionLds& L, int exact_mode, int dense_threshold, bool wide,
-                                              bool active, int64_t env, double x, double y, double th)
-{
-    double ox = map.ox, oy = map.oy;
-    if (map.origins) {
-        ox = map.origins[2 * env + 0];
-        oy = map.origins[2 * env + 1];
-    }
-    const int px = (int)rint((x - ox) * map.inv_res);   // world_to_pixel, coordinate_transformations.py:185-205
-    const int py = (int)rint((y - oy) * map.inv_res);
-    const double c = cos(th), s = sin(th);
-    int cls = active ? classify(cull, map.shared ? 0 : env, map.rows, map.cols, px, py, c, s) : kFree;
-    bool hit = cls == kHit;
-    uint64_t amb = __ballot(cls == kAmbiguous);
-    if (amb == 0) return hit;
-    const bool dense = exact_mode == 2 || (exact_mode == 0 && (int)__popcll(amb) > dense_threshold);
-    if (dense) {
-        // many undecided lanes: one per-thread rasteriser pass settles them all at once
-        if (cls == kAmbiguous) {
-            if (L.staged) {
-                CollisionSink<LdsWords> sink{L.bits, map.rows, map.cols, map.wpr, px, py};
-                hit = raster_runs(P, c, s, L.scratch, sink);
-            } else {
-                const uint32_t* words = map.bits + (map.shared ? 0 : env * map.env_stride);
-                CollisionSink<const uint32_t*> sink{words, map.rows, map.cols, map.wpr, px, py};
-                hit = raster_runs(P, c, s, L.scratch, sink);
-            }
-        }
-        return hit;
-    }
-    // few undecided lanes: the wave rasterises them cooperatively, one pose at a time
-    const int ln = lane_id();
-    const double vqx = ln < P.n_verts ? L.qverts[2 * ln] : 0.0, vqy = ln < P.n_verts ? L.qverts[2 * ln + 1] : 0.0;
-    while (amb) {
-        const int src = __ffsll((unsigned long long)amb) - 1;
-        amb &= amb - 1;
-        const double c_ = bcast_d(c, src), s_ = bcast_d(s, src);
-        const int px_ = bcast_i(px, src), py_ = bcast_i(py, src);
-        bool h;
-        if (L.staged) {
-            h = coop_collides(P, vqx, vqy, c_, s_, px_, py_, L.bits, map.rows, map.cols, map.wpr, wide);
-        } else {
-            const int64_t env_ = ((int64_t)bcast_i((int)(env >> 32), src) << 32) | (uint32_t)bcast_i((int)env, src);
-            const uint32_t* words = map.bits + (map.shared ? 0 : env_ * map.env_stride);
-            h = coop_collides(P, vqx, vqy, c_, s_, px_, py_, words, map.rows, map.cols, map.wpr, wide);
-        }
-        if (lane_id() == src) hit = h;
-    }
-    return hit;
-}
-
-// One env's state after the robot model ran, before the collision verdict is known.
-struct Pending {
-    double c, s;        // cos / sin of the new heading (as used by the classification)
-    int32_t px, py;     // world_to_pixel of the new position
-    Robot r;            // after robot.step()
-    Pose old;           // pose before the step (rollback target)
-    double min_dist;
-    double z[3];
-    int32_t target, iter, err, drawn;
-    int32_t collided;   // sticky flag before this step
-    int32_t env_lo, env_hi;
-    int32_t geom;       // geometry-pool entry of the env during this step (pool mode only)
-};
-
-// entry of the non-shared map / path arrays that env i uses
-__device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const Pending& q)
-{
-    return S->geom_of_env ? (int64_t)q.geom : i;
-}
-
-// Everything of PlanEnv.step() that follows pose_collides(): rollback (env.py:458-459), bookkeeping and delay queues
-// (:377-396), reward (:352), done (:407-419), outputs, optional reset, state write-back.  Runs on one lane for env i.
-// PLAIN = true (the two-kernel step: no delays, continuous reward provider -- see step_uses_deferral) compiles the
-// delay queues and the pure-pursuit branch out.
-template <bool PLAIN>
-__device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
-                                             const PathWindow* free_window = nullptr)
-{
-    const DevParams& P = a.S->P;
-    const int pose_delay = PLAIN ? 0 : P.pose_delay, state_delay = PLAIN ? 0 : P.state_delay;
-    const bool pure_pursuit = !PLAIN && P.reward_provider == BCP_REWARD_PURE_PURSUIT;
-    const bool tri = P.model == BCP_MODEL_TRICYCLE;
-    const int64_t n = a.S->n;
-    Robot& r = q.r;
-    if (hit) {  // robot.set_pose(*old_position): pose restored, v = w = 0 (tricycle_model.py:471-476)
-        r.p = q.old;
-        r.v = 0.0;
-        r.w = 0.0;
-    }
-    int iter = q.iter + 1;
-    bool collided = q.collided != 0 || hit;
-    double min_dist = q.min_dist;
-    int target = q.target;
-    // State.pose / State.robot_state: what the reward provider and the observation see (env.py:377-394)
-    double seen[3] = {r.p.x, r.p.y, r.p.th};
-    double seen_rs[7] = {r.p.x, r.p.y, r.p.th, r.v, r.w, r.steer, r.wheel};
-    if (pose_delay) fifo_delay<3>(a.S->st.pose_q, pose_delay, n, i, iter, seen);
-    if (state_delay) fifo_delay<7>(a.S->st.state_q, state_delay, n, i, iter, seen_rs);
-
-    // shared path: uniform pointers (scalar cache); private paths: per-lane pointers
-    double rew = 0.0;
-    int m;
-    bool goal;
-    const int64_t g = slot_of(a.S, i, q);
-    const double* pts = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
-    m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
-    if (pure_pursuit) {
-        if (!(a.flags & kAblateNoReward)) rew = reward_pure_pursuit(pts, m, seen[0], seen[1], collided, min_dist, target);
-        goal = hypot(pts[5 * (m - 1)] - seen[0], pts[5 * (m - 1) + 1] - seen[1]) < 1.0;   // done(), reward.py:141-150
-    } else {
-        if (!(a.flags & kAblateNoReward)) {
-            // way-point window of the pose: the caller may have looked it up already for the un-rolled-back pose
-            const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : g * 8);
-            const int16_t* index = a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
-            const PathWindow w =
-                (free_window && !hit && !pose_delay) ? *free_window : path_window(P, bbox, index, seen[0], seen[1]);
-            if (lds_path && a.S->path.shared)  // way points staged in LDS by the step kernel
-                rew = reward_step(P, lds_path, w, m, seen[0], seen[1], seen[2], min_dist, target);
-            else
-                rew = reward_step(P, pts, w, m, seen[0], seen[1], seen[2], min_dist, target);
-        }
-        goal = target > m - 1;
-    }
-    const bool done = goal || (iter >= P.iteration_timeout) || collided;
-    if (free_window) DIAG1_STAMP(5);
-
-    a.reward[i] = rew;
-    a.done[i] = (uint8_t)done;
-    if (a.collided_now) a.collided_now[i] = (uint8_t)hit;
-    if (a.err) a.err[i] = q.err;
-    if (a.noise_z_out) {
-        const double nan = __builtin_nan("");
-        a.noise_z_out[3 * i + 0] = (q.drawn & 1) ? q.z[0] : nan;
-        a.noise_z_out[3 * i + 1] = (q.drawn & 2) ? q.z[1] : nan;
-        a.noise_z_out[3 * i + 2] = (q.drawn & 4) ? q.z[2] : nan;
-    }
-
-    if (done && (a.flags & BCP_STEP_AUTO_RESET)) {  // PlanEnv.reset(): set_state(initial_state) (env.py:293-303)
-        int64_t k = i;
-        if (a.S->geom_of_env) {  // RandomMiniEnv.reset(): the env moves on to its next geometry (mini_env.py:469-481).
-            // Computed from the entry the step started with, so kernel 2 redoing an env that kernel 1 already reset
-            // lands on the same geometry (a hit always ends the episode, so both reset or neither does).
-            k = a.S->next_geom ? a.S->next_geom[g] : g;
-            a.S->geom_of_env[i] = (int32_t)k;
-        }
-        r.p.x = a.S->init.x[k];
-        r.p.y = a.S->init.y[k];
-        r.p.th = a.S->init.angle[k];
-        r.v = a.S->init.v[k];
-        r.w = a.S->init.w[k];
-        if (tri) {
-            r.steer = a.S->init.steer[k];
-            r.wheel = a.S->init.wheel[k];
-        }
-        min_dist = a.S->init.min_dist[k];
-        target = a.S->init.target_idx[k];
-        iter = a.S->init.cur_iter[k];
-        collided = a.S->init.collided[k] != 0;
-        // the restored State exposes the initial pose / robot state; its queues are empty (pushes restart at k = 1)
-        seen[0] = r.p.x;
-        seen[1] = r.p.y;
-        seen[2] = r.p.th;
-        seen_rs[0] = r.p.x;
-        seen_rs[1] = r.p.y;
-        seen_rs[2] = r.p.th;
-        seen_rs[3] = r.v;
-        seen_rs[4] = r.w;
-        seen_rs[5] = r.steer;
-        seen_rs[6] = r.wheel;
-    }
-
-    if (free_window) DIAG1_STAMP(6);
-    a.S->st.x[i] = r.p.x;
-    a.S->st.y[i] = r.p.y;
-    a.S->st.angle[i] = r.p.th;
-    a.S->st.v[i] = r.v;
-    a.S->st.w[i] = r.w;
-    if (tri) {
-        a.S->st.steer[i] = r.steer;
-        a.S->st.wheel[i] = r.wheel;
-    }
-    a.S->st.min_dist[i] = min_dist;
-    a.S->st.target_idx[i] = target;
-    a.S->st.cur_iter[i] = iter;
-    a.S->st.collided[i] = (uint8_t)collided;
-    if (pose_delay) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) a.S->st.pose_seen[c * n + i] = seen[c];
-    }
-    if (state_delay) {
-#pragma unroll
-        for (int c = 0; c < 7; ++c) a.S->st.state_seen[c * n + i] = seen_rs[c];
-    }
-}
-
-// ---- loads shared by the step kernels ------------------------------------------------------------------------
-template <bool PLAIN>
-__device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, bool active, Pending& q, double& cmd0, double& cmd1)
-{
-    const DevParams& P = a.S->P;
-    Robot& r = q.r;
-    r.p.x = a.S->st.x[i];
-    r.p.y = a.S->st.y[i];
-    r.p.th = a.S->st.angle[i];
-    r.v = a.S->st.v[i];
-    r.w = a.S->st.w[i];
-    const bool tri = P.model == BCP_MODEL_TRICYCLE;
-    r.steer = tri ? a.S->st.steer[i] : 0.0;
-    r.wheel = tri ? a.S->st.wheel[i] : 0.0;
-    q.min_dist = a.S->st.min_dist[i];
-    q.target = a.S->st.target_idx[i];
-    q.iter = a.S->st.cur_iter[i];
-    q.collided = a.S->st.collided[i] != 0;
-    q.geom = a.S->geom_of_env ? a.S->geom_of_env[i] : 0;
-    if (a.flags & BCP_STEP_ACTIONS_F32) {
-        const float2 c = reinterpret_cast<const float2*>(a.actions)[i];
-        cmd0 = (double)c.x;
-        cmd1 = (double)c.y;
-    } else {
-        const double2 c = reinterpret_cast<const double2*>(a.actions)[i];
-        cmd0 = c.x;
-        cmd1 = c.y;
-    }
-    if (!PLAIN && P.control_delay && active) {   // the robot executes the command given control_delay steps ago (env.py:371-373)
-        double cmd[2] = {cmd0, cmd1};
-        fifo_delay<2>(a.S->st.control_q, P.control_delay, a.S->n, i, q.iter + 1, cmd);
-        cmd0 = cmd[0];
-        cmd1 = cmd[1];
-    }
-    q.z[0] = q.z[1] = q.z[2] = 0.0;
-    if (P.noise_on) {
-        if (a.noise_z) {
-            q.z[0] = a.noise_z[3 * i + 0];
-            q.z[1] = a.noise_z[3 * i + 1];
-            q.z[2] = a.noise_z[3 * i + 2];
-        } else {
-            device_normals(a.seed, (uint64_t)(a.S->env_id_base + i), a.step_counter, q.z);
-        }
-    }
-}
-
-// General step kernel: robot model, collision settled in place by collides_wave (distance-field classification when
-// there is one, then the cooperative / per-thread exact rasterisers), reward, done, write-back.  Used when there
-// is no distance field, when the batch is too small to need load balancing, or when a mode is forced.
-__global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
-{
-    const DevParams& P = a.S->P;
-    const int tid = threadIdx.x;
-    const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
-    const bool active = gi < a.S->n;
-    const int64_t i = active ? gi : a.S->n - 1;  // inactive lanes of the last wave shadow env n-1 and never store
-
-    const CollisionLds L = collision_lds_setup(P, a.S->map, tid);
-    Pending q;
-    double cmd0, cmd1;
-    load_env<false>(a, i, active, q, cmd0, cmd1);
-
-    // ---- _env_step (envs/base/env.py:442-461)
-    q.old = q.r.p;
-    q.drawn = 0;
-    q.err = robot_step(P, q.r, cmd0, cmd1, q.z, q.drawn);
-    bool hit = false;
-    if (!(a.flags & kAblateNoCollision))
-        hit = collides_wave(P, a.S->map, a.S->cull, L, a.S->exact_mode, a.S->dense_threshold, a.S->wide != 0, active,
-                            slot_of(a.S, i, q), q.r.p.x, q.r.p.y, q.r.p.th);
-    if (!active) return;
-    finalize_env<false>(a, i, q, hit);
-}
-
-
-// Fast step kernel (kernel 1 of the two-kernel step; needs a distance field).  A pose is cleared in O(1) by the
-// outer test; the few envs it cannot clear are finished optimistically ("free") AND parked in `pending`, and kernel 2
-// redoes those that really collide.  Waves with many undecided lanes (robots hugging walls) settle them in place.
-// Memory operations are grouped so that independent round trips overlap: every wave runs alone on its SIMD, so an
-// exposed L2 / HBM latency is pure stall.
-template <bool WIDE>
-__global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
-{
-    const DevParams& P = a.S->P;
-    const int tid = threadIdx.x;
-    const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
-    const bool active = gi < a.S->n;
-    const int64_t i = active ? gi : a.S->n - 1;
-    DIAG1_STAMP(0);
-
-    // (1) loads for the LDS staging of the scaled footprint and of the shared path (up to 8 doubles per lane per
-    //     round), issued first ...
-    __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
-    const int nq = 2 * P.n_verts;
-    const double my_q = tid < nq ? P.qverts[tid >> 1][tid & 1] : 0.0;
-    double t[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int k = u * kBlock + tid;
-        t[u] = k < a.S->lds_path_doubles ? a.S->path.pts[k] : 0.0;
-    }
-    // (2) ... then state, action, noise (the first-touch lines of this step): all of it is in flight together
-    Pending q;
-    double cmd0, cmd1;
-    load_env<true>(a, i, active, q, cmd0, cmd1);
-    if (gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
-    if (gi == 0 && a.inplace_next) *a.inplace_next = 0;
-    // (3) LDS writes (the staging loads return first, in issue order)
-    if (tid < nq) qv[tid] = my_q;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int k = u * kBlock + tid;
-        if (k < a.S->lds_path_doubles) qv[nq + k] = t[u];
-    }
-    for (int k = 8 * kBlock + tid; k < a.S->lds_path_doubles; k += kBlock) qv[nq + k] = a.S->path.pts[k];  // long paths
-    __syncthreads();
-    DIAG1_STAMP(1);
-    const LdsF64 lds_path = a.S->lds_path_doubles ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
-
-    // ---- _env_step (envs/base/env.py:442-461)
-    Robot& r = q.r;
-    q.old = r.p;
-    q.drawn = 0;
-    q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
-    DIAG1_STAMP(2);
-
-    // (3) everything that depends only on the new pose is looked up together: distance-field samples and the
-    //     way-point window of the reward
-    const int64_t g = slot_of(a.S, i, q);
-    double ox = a.S->map.ox, oy = a.S->map.oy;
-    if (a.S->map.origins) {
-        ox = a.S->map.origins[2 * g + 0];
-        oy = a.S->map.origins[2 * g + 1];
-    }
-    const int px = (int)rint((r.p.x - ox) * a.S->map.inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
-    const int py = (int)rint((r.p.y - oy) * a.S->map.inv_res);
-    const double c = cos(r.p.th), s = sin(r.p.th);
-    const int64_t map_env = a.S->map.shared ? 0 : g;
-    OuterLookups look;
-    look.off_map = true;
-    if (!(a.flags & (kAblateNoCollision | kAblateNoClassify))) look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
-    const PathWindow win = path_window(P, a.S->path.bbox + (a.S->path.shared ? 0 : g * 8),
-                                       a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets)), r.p.x, r.p.y);
-    const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
-    DIAG1_STAMP(3);
-
-    bool hit = false;
-    const uint64_t amb = __ballot(cls == kAmbiguous);
-    const int n_amb = (int)__popcll(amb);
-    const int threshold = a.threshold_now ? *a.threshold_now : a.S->dense_threshold;
-    if (n_amb > threshold) {
-        // many undecided lanes in this wave: settle them in place, one pose at a time by the whole wave
-        if (tid == 0 && a.inplace_count) atomicAdd(a.inplace_count, n_amb);
-        const bool inner = cls == kAmbiguous && classify_inner_hit(a.S->cull, map_env, px, py, c, s);
-        hit = inner;
-        uint64_t todo = __ballot(cls == kAmbiguous && !inner);
-        const double vqx = tid < P.n_verts ? qv[2 * tid] : 0.0, vqy = tid < P.n_verts ? qv[2 * tid + 1] : 0.0;
-        while (todo) {
-            const int src = __ffsll((unsigned long long)todo) - 1;
-            todo &= todo - 1;
-            const int64_t env_ = ((int64_t)bcast_i((int)(g >> 32), src) << 32) | (uint32_t)bcast_i((int)g, src);
-            const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : env_ * a.S->map.env_stride);
-            const bool h = coop_collides<WIDE>(P, vqx, vqy, bcast_d(c, src), bcast_d(s, src), bcast_i(px, src),
-                                               bcast_i(py, src), words, a.S->map.rows, a.S->map.cols, a.S->map.wpr);
-            if (tid == src) hit = h;
-        }
-    } else if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
-        // a few undecided lanes: park the pre-verdict state for kernel 2 (load-balanced over the whole GPU) and carry
-        // on as if the pose were free, which it is for nearly every parked env
-        const int shard = (int)(blockIdx.x % kShards);
-        const int slot = atomicAdd(a.pending_count + shard, 1);
-        q.c = c;
-        q.s = s;
-        q.px = px;
-        q.py = py;
-        q.env_lo = (int32_t)(uint32_t)i;
-        q.env_hi = (int32_t)(i >> 32);
-        a.S->pending[(int64_t)slot * kShards + shard] = q;  // interleaved: the used slots stay in a few pages
-    }
-    DIAG1_STAMP(4);
-    if (!active) return;
-    finalize_env<true>(a, i, q, hit, lds_path, &win);
-    DIAG1_STAMP(7);
-}
-
-// Kernel 2 of a step: kPendingWaves wavefronts per parked env: the lanes rasterise
-// the footprint together (coop_collides, wave w takes the row chunks w, w+2, ...); on a collision thread 0 redoes
-// the env's finalisation from the parked state.  The first entry is fetched speculatively, together with the
-// counter that says whether it exists, so the two round trips overlap.
-constexpr int kPendingWaves = 4;  // wave = 2 * (row-chunk slot) + (edge slot)
-constexpr int kParkCapacity = 8192;  // undecided poses per step that kernel 2 takes without the waves' help
-
-template <bool WIDE>
-__global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(const StepArgs a)
-{
-    DIAG_STAMP(0);
-    const DevParams& P = a.S->P;
-    const int lane = threadIdx.x % kBlock, wave = threadIdx.x / kBlock;
-    const int shard = (int)(blockIdx.x % kShards);
-    const int stride = gridDim.x / kShards;
-    const Pending* slots = a.S->pending + shard;
-    const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
-    const int count = a.pending_count[shard];
-    if (blockIdx.x == 0 && a.threshold_next && threadIdx.x < kShards) {
-        // Undecided poses of this step, parked + settled in place.  Few of them: kernel 2 absorbs them all in one or
-        // two rounds, so the next step parks everything (no wave is held up by its own unlucky lanes).  Many (robots
-        // hugging walls everywhere): kernel 2 would need dozens of rounds, the waves settle their own instead.
-        int total = a.pending_count[threadIdx.x];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-        if (threadIdx.x == 0) *a.threshold_next = total + *a.inplace_count <= kParkCapacity ? 64 : a.S->dense_threshold;
-    }
-    for (int idx = blockIdx.x / kShards; idx < a.S->pending_cap; idx += stride) {
-        const Pending* e = slots + (int64_t)idx * kShards;   // in bounds whatever `count` says
-        const double c = e->c, s = e->s;
-        const int px = e->px, py = e->py;
-        const int64_t i = ((int64_t)e->env_hi << 32) | (uint32_t)e->env_lo;
-        const int64_t g = a.S->geom_of_env ? (int64_t)e->geom : i;
-        if (idx >= count) break;
-        DIAG_STAMP(1);
-        const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : g * a.S->map.env_stride);
-        // (no inner distance-field test here: nearly every parked pose is free, so the test would cost a dependent
-        //  round trip per pose and almost never spare the rasteriser)
-        bool hit = false;
-        DIAG_STAMP(2);
-        if (!(a.flags & kAblateNoCoop))
-            hit = coop_collides_quad<WIDE>(P, vqx, vqy, c, s, px, py, words, a.S->map.rows, a.S->map.cols, a.S->map.wpr, wave,
-                                           (LdsU32)lds_dyn);
-        DIAG_STAMP(3);
-        hit = __syncthreads_or(hit);  // wave-uniform verdicts of the block's waves
-        DIAG_STAMP(4);
-        // kernel 1 already finished this env as "free"; only a collision changes anything
-        if (hit && threadIdx.x == 0) {
-            Pending q = *e;
-            finalize_env<true>(a, i, q, true);
-        }
-    }
-}
-
+// ------------------------------------------------------------------------------------------------ kernels (one-time, operator seams)
 __global__ void reset_kernel(DevState st, DevState init, const uint8_t* __restrict__ mask, int64_t n, int tri,
                              int32_t* __restrict__ geom_of_env, const int32_t* __restrict__ next_geom)
 {
@@ -1192,437 +391,6 @@ __global__ void world_to_pixel_kernel(const double* __restrict__ xy, int64_t n, 
     if (i >= n) return;
     out[2 * i] = (int64_t)rint((xy[2 * i] - ox) * inv_res);
     out[2 * i + 1] = (int64_t)rint((xy[2 * i + 1] - oy) * inv_res);
-}
-
-// ---- egocentric observation ------------------------------------------------------------
-// extract_egocentric_costmap (utilities/costmap_utils.py:25-75) = cv2.getRotationMatrix2D + cv2.warpAffine with
-// INTER_NEAREST for every env at once.  OpenCV's nearest-neighbour warp works in 22.10 fixed point:
-//   X(x, y) = (sat_int((M1*y + M2)*1024) + 512 + sat_int(M0*x*1024)) >> 10      (and likewise Y with M4, M5, M3)
-// with M the float64 inverse of the 2x3 transform; a destination pixel copies src[Y][X] or takes the border value.
-struct EgoArgs {
-    const uint8_t* data;         // raw costmaps: [rows][cols] shared or one per map entry
-    int64_t map_stride;          // bytes per map entry (0 when shared)
-    const int32_t* valid_rows;   // per-entry true shape (optional)
-    const int32_t* valid_cols;
-    int32_t rows, cols;          // allocation shape of one map
-    const double* origins;       // per-entry origins or nullptr
-    double ox, oy, res, inv_res;
-    const double* poses;         // [n,3] or nullptr: the bound state
-    const double *sx, *sy, *sth;
-    const int32_t* geom_of_env;
-    int32_t shared;
-    int32_t has_window;
-    double win_ox, win_oy;
-    int32_t drows, dcols;        // output shape
-    uint32_t cols_magic;         // floor(2^32 / cols) + 1: idx / cols == umulhi(idx, magic) for idx * cols < 2^32
-    int32_t stage_map;           // shared map is copied to LDS (rows * cols bytes)
-    int32_t border;
-    int64_t n_envs;              // image i shows the costmap of env i % n_envs
-    int64_t n_images;
-    uint8_t* out;                // [n][drows][dcols]
-};
-
-__device__ __forceinline__ int sat_int(double v)   // cv::saturate_cast<int>(double): nearest-even, saturating
-{
-    const double r = rint(v);
-    return r >= 2147483647.0 ? 2147483647 : (r <= -2147483648.0 ? (-2147483647 - 1) : (int)r);
-}
-
-// clamp(v, lo, hi) as ONE instruction (the compiler emits v_max + v_min for min(max()))
-__device__ __forceinline__ int clamp_med3(int v, int lo, int hi)
-{
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
-    return r;
-}
-
-// byte at a raw LDS address (no symbol base is added: the caller folds the base into the address)
-__device__ __forceinline__ uint32_t lds_byte_at(uint32_t addr)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t) * (__attribute__((address_space(3))) const uint8_t*)addr;
-#else
-    (void)addr;
-    return 0;
-#endif
-}
-
-typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-
-// ---- building blocks ------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) int* LdsI32;
-typedef __attribute__((address_space(3))) uint8_t* LdsU8;
-constexpr int kRowOff = -2147483647 - 1;   // row-table X0 of a row that lies off the map (real X0 are >= INT_MIN + 512)
-
-struct EgoXform {
-    double M[6];   // dst -> src, as cv::warpAffine uses it
-    int vrows, vcols;
-    int g_lo, g_hi;   // map entry
-};
-
-// cv2.getRotationMatrix2D(world_to_pixel(pose), 180*theta/pi, 1), the window shift, and warpAffine's inversion
-__device__ __forceinline__ EgoXform ego_transform(const EgoArgs& a, int64_t img)
-{
-    EgoXform T;
-    const int64_t me = img % a.n_envs;
-    const int64_t g = a.shared ? 0 : (a.geom_of_env ? (int64_t)a.geom_of_env[me] : me);
-    double ox = a.ox, oy = a.oy;
-    if (a.origins) {
-        ox = a.origins[2 * g];
-        oy = a.origins[2 * g + 1];
-    }
-    double px, py, th;
-    if (a.poses) {
-        px = a.poses[3 * img];
-        py = a.poses[3 * img + 1];
-        th = a.poses[3 * img + 2];
-    } else {
-        px = a.sx[img];
-        py = a.sy[img];
-        th = a.sth[img];
-    }
-    double* M = T.M;
-    const float cx = (float)rint((px - ox) * a.inv_res), cy = (float)rint((py - oy) * a.inv_res);   // Point2f centre
-    const double angle = (180 * th / M_PI) * (M_PI / 180);
-    const double alpha = cos(angle), beta = sin(angle);
-    M[0] = alpha;
-    M[1] = beta;
-    M[2] = (1 - alpha) * cx - beta * cy;
-    M[3] = -beta;
-    M[4] = alpha;
-    M[5] = beta * cx + (1 - alpha) * cy;
-    if (a.has_window) {
-        // shift so that the window origin lands on output pixel (0, 0); composed in float32 (costmap_utils.py:50-64)
-        const double dsx = rint((a.win_ox - (ox - px)) * a.inv_res), dsy = rint((a.win_oy - (oy - py)) * a.inv_res);
-        float t[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) t[k] = (float)M[k];
-        t[2] = t[2] + (-(float)dsx);
-        t[5] = t[5] + (-(float)dsy);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) M[k] = (double)t[k];
-    }
-    {   // cv::warpAffine inverts the transform in float64
-        double D = M[0] * M[4] - M[1] * M[3];
-        D = D != 0 ? 1. / D : 0;
-        const double A11 = M[4] * D, A22 = M[0] * D;
-        M[0] = A11;
-        M[1] *= -D;
-        M[3] *= -D;
-        M[4] = A22;
-        const double b1 = -M[0] * M[2] - M[1] * M[5];
-        const double b2 = -M[3] * M[2] - M[4] * M[5];
-        M[2] = b1;
-        M[5] = b2;
-    }
-    T.vrows = a.valid_rows ? a.valid_rows[g] : a.rows;
-    T.vcols = a.valid_cols ? a.valid_cols[g] : a.cols;
-    T.g_lo = (int)(uint32_t)g;
-    T.g_hi = (int)(g >> 32);
-    return T;
-}
-
-// lane k's transform, broadcast to the whole wave (scalar registers)
-struct EgoImage {
-    double m0, m1, m2, m3, m4, m5;
-    int vr, vc;
-    int64_t g;
-};
-
-__device__ __forceinline__ EgoImage ego_broadcast(const EgoXform& T, int k)
-{
-    EgoImage I;
-    I.m0 = bcast_d(T.M[0], k);
-    I.m1 = bcast_d(T.M[1], k);
-    I.m2 = bcast_d(T.M[2], k);
-    I.m3 = bcast_d(T.M[3], k);
-    I.m4 = bcast_d(T.M[4], k);
-    I.m5 = bcast_d(T.M[5], k);
-    I.vr = bcast_i(T.vrows, k);
-    I.vc = bcast_i(T.vcols, k);
-    I.g = ((int64_t)bcast_i(T.g_hi, k) << 32) | (uint32_t)bcast_i(T.g_lo, k);
-    return I;
-}
-
-// LDS copy of one costmap with a one-cell ring of the border value.  Whole workgroup; ends with a barrier.
-// The map is fetched as aligned dwords, eight independent loads in flight per thread (a cold map costs a few memory
-// round trips instead of one per row), and scattered into the ringed layout byte by byte.
-__device__ __forceinline__ void ego_stage_map(const EgoArgs& a, const uint8_t* __restrict__ src, int vr, int vc, LdsU8 lmap,
-                                              int pitch, int map_bytes)
-{
-    __attribute__((address_space(3))) uint32_t* l32 = (__attribute__((address_space(3))) uint32_t*)lmap;
-    for (int k = threadIdx.x; k < map_bytes / 4; k += 256) l32[k] = (uint32_t)a.border * 0x01010101u;
-    __syncthreads();
-    const int total = a.rows * a.cols;
-    const int off = (int)((uintptr_t)src & 3);   // the map entry need not start on a dword boundary
-    const uint32_t* __restrict__ w32 = reinterpret_cast<const uint32_t*>(src - off);
-    const int n_words = (off + total + 3) >> 2;
-    for (int w0 = threadIdx.x; w0 < n_words; w0 += 8 * 256) {
-        uint32_t v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int w = w0 + u * 256;
-            v[u] = w < n_words ? w32[w] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int w = w0 + u * 256;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int idx = 4 * w + j - off;                       // linear index into the map entry
-                if (idx >= 0 && idx < total) {
-                    const int r = (int)__umulhi((uint32_t)idx, a.cols_magic), c = idx - r * a.cols;
-                    if (r < vr && c < vc) lmap[(r + 1) * pitch + 1 + c] = (uint8_t)(v[u] >> (8 * j));
-                }
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// per-row terms of one image (rounding term included; staged sampling: ring offset and LDS base folded in) and the
-// off-map flag of each row, for rows t0, t0 + tstep, ...
-template <bool STAGED>
-__device__ __forceinline__ void ego_row_terms(const EgoArgs& a, const EgoImage& I, int x_shift, LdsI32 row_tab, int t0,
-                                              int tstep)
-{
-    const int last_cx = sat_int(I.m0 * (a.dcols - 1) * 1024), last_cy = sat_int(I.m3 * (a.dcols - 1) * 1024);
-    for (int y = t0; y < a.drows; y += tstep) {
-        const int rx = sat_int((I.m1 * y + I.m2) * 1024) + 512, ry = sat_int((I.m4 * y + I.m5) * 1024) + 512;
-        const int xa = rx >> 10, xb = (rx + last_cx) >> 10, ya = ry >> 10, yb = (ry + last_cy) >> 10;
-        const bool off = (xa < 0 && xb < 0) || (xa >= I.vc && xb >= I.vc) || (ya < 0 && yb < 0) || (ya >= I.vr && yb >= I.vr);
-        row_tab[2 * y] = off ? kRowOff : (STAGED ? rx + x_shift * 1024 : rx);
-        row_tab[2 * y + 1] = STAGED ? ry + 1024 : ry;
-    }
-}
-
-// the pixels of rows r0, r0 + rstep, ... for this lane's column groups.  Pixel groups are PX columns wide; the last
-// group of a row is shifted left so that it ends at the last column (it recomputes a few pixels of its neighbour
-// instead of needing a narrower store).
-template <bool STAGED, int PX>
-__device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, int x_shift, int pitch,
-                                           const uint8_t* __restrict__ src, LdsI32 row_tab, uint8_t* __restrict__ image,
-                                           int cg, int r0, int rstep)
-{
-    const uint32_t border = (uint32_t)a.border;
-    const uint64_t border8 = (uint64_t)border * 0x0101010101010101ull;
-    const int x_lo = x_shift - 1, x_hi = x_shift + I.vc, y_lo = 0, y_hi = I.vr + 1;   // ring coordinates (staged sampling)
-    for (int xg = PX * cg; xg < a.dcols; xg += 128) {
-        const int x0 = min(xg, a.dcols - PX);
-        int ccx[PX], ccy[PX];
-#pragma unroll
-        for (int j = 0; j < PX; ++j) {   // cv::hal::warpAffine's adelta / bdelta for this lane's columns
-            ccx[j] = sat_int(I.m0 * (x0 + j) * 1024);
-            ccy[j] = sat_int(I.m3 * (x0 + j) * 1024);
-        }
-        for (int y = r0; y < a.drows; y += rstep) {
-            const int rx = row_tab[2 * y], ry = row_tab[2 * y + 1];
-            uint64_t packed = border8;
-            if (rx != kRowOff) {
-                uint32_t half[2] = {0, 0};
-#pragma unroll
-                for (int j = 0; j < PX; ++j) {
-                    // (saturate_cast<short> never bites: |X|, |Y| < 2^21 and maps are < 2^15)
-                    const int X = (rx + ccx[j]) >> 10, Y = (ry + ccy[j]) >> 10;
-                    uint32_t val;
-                    if (STAGED) {   // clamp onto the border ring of the LDS copy: every address is valid
-                        const int xc = clamp_med3(X, x_lo, x_hi), yc = clamp_med3(Y, y_lo, y_hi);
-                        val = lds_byte_at((uint32_t)(__mul24(yc, pitch) + xc));
-                    } else {        // global gather: only the in-map lanes issue a load
-                        val = border;
-                        if ((unsigned)X < (unsigned)I.vc && (unsigned)Y < (unsigned)I.vr)
-                            val = (uint32_t)src[(uint32_t)__mul24(Y, a.cols) + (uint32_t)X];
-                    }
-                    half[j >> 2] |= val << (8 * (j & 3));
-                }
-                packed = ((uint64_t)half[1] << 32) | half[0];
-            }
-            uint8_t* const p = image + (int64_t)y * a.dcols + x0;
-            if (PX == 8)
-                *reinterpret_cast<u64_unaligned*>(p) = packed;
-            else
-                *reinterpret_cast<u32_unaligned*>(p) = (uint32_t)packed;
-        }
-    }
-}
-
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// One WAVEFRONT per image, persistent workgroups of 4 waves that stage a shared costmap in LDS once and then walk
-// over images.
-//   * transforms: lane l of a wave prepares the (inverted) warp matrix of the wave's l-th image, so the float64
-//     sin / cos / inversion work is done once per image by one lane; the wave then takes the images one by one and
-//     broadcasts that lane's matrix (v_readlane -> scalar registers).
-//   * pixels: lane = (row mod 4, group of 8 consecutive columns).  The column terms of a lane's 8 pixels stay in
-//     registers, the per-row terms come from a small per-wave LDS table, and the 8 pixels leave as one 64-bit store
-//     (image rows are dcols bytes apart, so these stores are generally unaligned).
-//   * rows whose source segment lies entirely off the map are filled with the border value without sampling: the
-//     source coordinates are monotone in x, so it is enough to look at the row's two ends.
-//   * shared map: the LDS copy carries a one-cell ring of the border value and the source coordinates are clamped
-//     onto it (v_med3), so a pixel is add, add, shift, shift, clamp, clamp, multiply-add, LDS byte read, pack --
-//     no bounds compare and no select.  The ring offset and the LDS base address ride in the per-row terms.
-// LDS: [shared map + ring, dword padded] [4 waves x drows x {X0 (kRowOff = row is off the map), Y0}]
-// STAGED = false: maps that do not fit LDS are sampled straight from global memory.
-template <bool STAGED, int PX>
-__global__ void __launch_bounds__(256) ego_costmap_kernel(const EgoArgs a)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pitch = a.cols + 2;
-    const int map_bytes = STAGED ? (((a.rows + 2) * pitch + 3) & ~3) : 0;
-    const LdsU8 lmap = (LdsU8)lds_dyn;
-    const LdsI32 row_tab = (LdsI32)(lmap + map_bytes) + wave * (2 * a.drows);
-    if (STAGED)
-        ego_stage_map(a, a.data, a.valid_rows ? a.valid_rows[0] : a.rows, a.valid_cols ? a.valid_cols[0] : a.cols, lmap,
-                      pitch, map_bytes);
-    // staged sampling: X' = X + x_shift and Y' = Y + 1 index the ringed copy directly (raw LDS byte address)
-    const int x_shift = 1 + (int)(uint32_t)(uintptr_t)lmap;
-    constexpr int kGroups = 128 / PX, kRows = 64 / kGroups;   // lanes of a wave: kRows image rows x kGroups pixel groups
-    const int cg = lane % kGroups, rl = lane / kGroups;
-    const int64_t P = (int64_t)a.drows * a.dcols;
-    const int64_t first = (int64_t)blockIdx.x * 4 + wave, stride = (int64_t)gridDim.x * 4;
-    for (int64_t base = first; base < a.n_images; base += 64 * stride) {
-        EgoXform T;
-        memset(&T, 0, sizeof(T));
-        const int64_t mine = base + lane * stride;   // lane l: transform of the wave's l-th image of this batch
-        if (mine < a.n_images) T = ego_transform(a, mine);
-        const int64_t left = (a.n_images - base + stride - 1) / stride;
-        const int count = (int)(left < 64 ? left : 64);
-        for (int k = 0; k < count; ++k) {            // the wave's images, one at a time
-            const int64_t img = base + k * stride;
-            const EgoImage I = ego_broadcast(T, k);
-            ego_row_terms<STAGED>(a, I, x_shift, row_tab, lane, 64);
-            wave_lds_sync();
-            ego_pixels<STAGED, PX>(a, I, x_shift, pitch, a.data + I.g * a.map_stride, row_tab, a.out + img * P, cg, rl, kRows);
-            wave_lds_sync();   // the table is rewritten for the next image
-        }
-    }
-}
-
-// Private / pooled costmaps that fit LDS: images are first grouped by map entry (ego_bin_* kernels below); every
-// workgroup then takes an equal slice of that grouped list and walks through it run by run (a run = consecutive
-// images of one map entry): stage the entry (with the border ring), produce the run's images four at a time, one per
-// wavefront exactly like the shared-map kernel, and let the 4 waves share each of the up to three left-over images --
-// wave w takes every 4th slice of rows -- so that nobody idles (private maps: every run is a single image).
-// LDS: [map + ring] [4 row tables].
-template <int PX>
-__global__ void __launch_bounds__(256) ego_costmap_binned_kernel(const EgoArgs a, const int32_t* __restrict__ bin_start,
-                                                                 const int32_t* __restrict__ bin_count,
-                                                                 const int32_t* __restrict__ order)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pitch = a.cols + 2;
-    const int map_bytes = ((a.rows + 2) * pitch + 3) & ~3;
-    const LdsU8 lmap = (LdsU8)lds_dyn;
-    const LdsI32 tables = (LdsI32)(lmap + map_bytes);
-    const LdsI32 wave_tab = tables + wave * (2 * a.drows);
-    const int x_shift = 1 + (int)(uint32_t)(uintptr_t)lmap;
-    constexpr int kGroups = 128 / PX, kRows = 64 / kGroups;
-    const int cg = lane % kGroups, rl = lane / kGroups;
-    const int64_t P = (int64_t)a.drows * a.dcols;
-    const int64_t chunk = (a.n_images + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = blockIdx.x * chunk, hi = min(lo + chunk, a.n_images);
-    for (int64_t pos = lo; pos < hi;) {
-        const int64_t me = (int64_t)order[pos] % a.n_envs;
-        const int64_t g = a.geom_of_env ? (int64_t)a.geom_of_env[me] : me;
-        const int64_t run_end = min(hi, (int64_t)bin_start[g] + bin_count[g]);
-        const int run = (int)(run_end - pos);   // (uniform over the workgroup)
-        __syncthreads();                        // everyone is done with the previous map
-        ego_stage_map(a, a.data + g * a.map_stride, a.valid_rows ? a.valid_rows[g] : a.rows,
-                      a.valid_cols ? a.valid_cols[g] : a.cols, lmap, pitch, map_bytes);
-        const int whole = run & ~3;
-        // ---- one image per wavefront: wave w takes the run's images w, w + 4, ...; lane l prepares the l-th of them
-        for (int base = wave; base < whole; base += 256) {
-            EgoXform T;
-            memset(&T, 0, sizeof(T));
-            int my_img = 0;
-            if (base + 4 * lane < whole) {
-                my_img = order[pos + base + 4 * lane];
-                T = ego_transform(a, my_img);
-            }
-            const int batch = min(64, (whole - base + 3) / 4);
-            for (int k = 0; k < batch; ++k) {
-                const int64_t img = (uint32_t)bcast_i(my_img, k);
-                const EgoImage I = ego_broadcast(T, k);
-                ego_row_terms<true>(a, I, x_shift, wave_tab, lane, 64);
-                wave_lds_sync();
-                ego_pixels<true, PX>(a, I, x_shift, pitch, nullptr, wave_tab, a.out + img * P, cg, rl, kRows);
-                wave_lds_sync();
-            }
-        }
-        // ---- the left-over images: the four waves share each of them (one row table, two barriers per image)
-        if (run > whole) {
-            int my_img = 0;
-            EgoXform T;
-            memset(&T, 0, sizeof(T));
-            if (whole + lane < run) {
-                my_img = order[pos + whole + lane];
-                T = ego_transform(a, my_img);
-            }
-            for (int k = 0; k < run - whole; ++k) {
-                const int64_t img = (uint32_t)bcast_i(my_img, k);
-                const EgoImage I = ego_broadcast(T, k);
-                __syncthreads();   // the table is free (earlier images are finished)
-                ego_row_terms<true>(a, I, x_shift, tables, threadIdx.x, 256);
-                __syncthreads();
-                ego_pixels<true, PX>(a, I, x_shift, pitch, nullptr, tables, a.out + img * P, cg, wave * kRows + rl, 4 * kRows);
-            }
-        }
-        pos = run_end;
-    }
-}
-
-// ---- grouping images by map entry: count -> exclusive scan -> scatter ------------------------------------------
-__global__ void ego_bin_count_kernel(const int32_t* __restrict__ geom_of_env, int64_t n_envs, int64_t n_images,
-                                     int32_t* __restrict__ bin_count, int32_t* __restrict__ rank)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_images) return;
-    const int64_t me = i % n_envs;
-    const int64_t g = geom_of_env ? (int64_t)geom_of_env[me] : me;
-    rank[i] = atomicAdd(bin_count + g, 1);
-}
-
-__global__ void __launch_bounds__(1024) ego_bin_scan_kernel(const int32_t* __restrict__ bin_count, int64_t n_bins,
-                                                            int32_t* __restrict__ bin_start)
-{
-    __shared__ int32_t part[1024];
-    __shared__ int32_t carry;
-    const int tid = threadIdx.x;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n_bins; base += 1024) {
-        const int64_t i = base + tid;
-        const int32_t v = i < n_bins ? bin_count[i] : 0;
-        part[tid] = v;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan
-            const int32_t t = tid >= d ? part[tid - d] : 0;
-            __syncthreads();
-            part[tid] += t;
-            __syncthreads();
-        }
-        if (i < n_bins) bin_start[i] = carry + part[tid] - v;
-        __syncthreads();
-        if (tid == 1023) carry += part[1023];
-        __syncthreads();
-    }
-}
-
-__global__ void ego_bin_scatter_kernel(const int32_t* __restrict__ geom_of_env, int64_t n_envs, int64_t n_images,
-                                       const int32_t* __restrict__ bin_start, const int32_t* __restrict__ rank,
-                                       int32_t* __restrict__ order)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_images) return;
-    const int64_t me = i % n_envs;
-    const int64_t g = geom_of_env ? (int64_t)geom_of_env[me] : me;
-    order[bin_start[g] + rank[i]] = (int32_t)i;
 }
 
 // EgocentricCostmap.observation's goal_n_state (envs/egocentric.py:140-160), one thread per env
