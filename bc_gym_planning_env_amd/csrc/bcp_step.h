@@ -78,8 +78,9 @@ struct StepArgs {
     // kernel 2 of step t counts the undecided poses of step t and picks the threshold of step t + 1
     const int32_t* threshold_now;
     int32_t* threshold_next;
-    int32_t* inplace_count;    // undecided poses settled inside kernel 1 this step (the parked ones are in pending_count)
-    int32_t* inplace_next;     // next step's counter; kernel 1 zeroes it
+    int32_t* inplace_count;    // [kShards] undecided poses settled inside kernel 1 this step (the parked ones are in
+                               // pending_count); sharded like the parking counters: no hot atomic
+    int32_t* inplace_next;     // [kShards] next step's counters; kernel 1 zeroes them
     uint64_t seed, step_counter;
     uint32_t flags;
 };
@@ -685,7 +686,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
     double cmd0, cmd1;
     load_env<true>(a, i, active, q, cmd0, cmd1);
     if (gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
-    if (gi == 0 && a.inplace_next) *a.inplace_next = 0;
+    if (gi < kShards && a.inplace_next) a.inplace_next[gi] = 0;
     // (3) LDS writes (the staging loads return first, in issue order)
     if (tid < nq) qv[tid] = my_q;
 #pragma unroll
@@ -731,7 +732,7 @@ __global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
     const int threshold = a.threshold_now ? *a.threshold_now : a.S->dense_threshold;
     if (n_amb > threshold) {
         // many undecided lanes in this wave: settle them in place, one pose at a time by the whole wave
-        if (tid == 0 && a.inplace_count) atomicAdd(a.inplace_count, n_amb);
+        if (tid == 0 && a.inplace_count) atomicAdd(a.inplace_count + (int)(blockIdx.x % kShards), n_amb);
         const bool inner = cls == kAmbiguous && classify_inner_hit(a.S->cull, map_env, px, py, c, s);
         hit = inner;
         uint64_t todo = __ballot(cls == kAmbiguous && !inner);
@@ -785,11 +786,11 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
     if (blockIdx.x == 0 && a.threshold_next && threadIdx.x < kShards) {
         // Undecided poses of this step, parked + settled in place.  Few of them: kernel 2 absorbs them all in one or
         // two rounds, so the next step parks everything (no wave is held up by its own unlucky lanes).  Many (robots
-        // hugging walls everywhere): kernel 2 would need dozens of rounds, the waves settle their own instead.
-        int total = a.pending_count[threadIdx.x];
+        // hugging walls everywhere): kernel 2 would need dozens of rounds, every wave settles its own instead.
+        int total = a.pending_count[threadIdx.x] + a.inplace_count[threadIdx.x];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-        if (threadIdx.x == 0) *a.threshold_next = total + *a.inplace_count <= kParkCapacity ? 64 : a.S->dense_threshold;
+        if (threadIdx.x == 0) *a.threshold_next = total <= kParkCapacity ? 64 : 0;
     }
     for (int idx = blockIdx.x / kShards; idx < a.S->pending_cap; idx += stride) {
         const Pending* e = slots + (int64_t)idx * kShards;   // in bounds whatever `count` says

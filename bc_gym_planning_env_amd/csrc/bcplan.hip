@@ -774,8 +774,10 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
             HIP_TRY(hipMalloc(&h->pending, (size_t)kShards * h->pending_cap * sizeof(Pending)));
             HIP_TRY(hipMalloc((void**)&h->pending_count, 2 * kShards * sizeof(int32_t)));
             HIP_TRY(hipMemsetAsync(h->pending_count, 0, 2 * kShards * sizeof(int32_t), s));
-            HIP_TRY(hipMalloc((void**)&h->adapt, 4 * sizeof(int32_t)));
-            const int32_t init[4] = {h->dense_threshold, h->dense_threshold, 0, 0};
+            // [2] thresholds (alternating by step parity), then [2][kShards] in-place counters
+            HIP_TRY(hipMalloc((void**)&h->adapt, (2 + 2 * kShards) * sizeof(int32_t)));
+            HIP_TRY(hipMemsetAsync(h->adapt, 0, (2 + 2 * kShards) * sizeof(int32_t), s));
+            const int32_t init[2] = {h->dense_threshold, h->dense_threshold};
             HIP_TRY(hipMemcpyAsync(h->adapt, init, sizeof(init), hipMemcpyHostToDevice, s));
             HIP_TRY(hipStreamSynchronize(s));   // (`init` is on the stack)
         }
@@ -957,8 +959,8 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     const bool adapt = h->adaptive && h->adapt && S.pending && S.dense_threshold >= 0;
     a.threshold_now = adapt ? h->adapt + (h->step_counter & 1) : nullptr;
     a.threshold_next = adapt ? h->adapt + ((h->step_counter + 1) & 1) : nullptr;
-    a.inplace_count = adapt ? h->adapt + 2 + (h->step_counter & 1) : nullptr;
-    a.inplace_next = adapt ? h->adapt + 2 + ((h->step_counter + 1) & 1) : nullptr;
+    a.inplace_count = adapt ? h->adapt + 2 + (h->step_counter & 1) * kShards : nullptr;
+    a.inplace_next = adapt ? h->adapt + 2 + ((h->step_counter + 1) & 1) * kShards : nullptr;
     const int blocks = (int)((h->n + kBlock - 1) / kBlock);
     if (S.pending) {
         // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest
