@@ -918,8 +918,7 @@ static int upload_step_static(bcp_handle* h, hipStream_t s)
     S.n = h->n;
     S.env_id_base = h->env_id_base;
     S.exact_mode = h->exact_mode;
-    // fewer waves than SIMDs: nothing to balance, settle every undecided pose inside the step kernel
-    S.dense_threshold = (h->n + kBlock - 1) / kBlock < 1024 && h->exact_mode == 0 ? -1 : h->dense_threshold;
+    S.dense_threshold = h->dense_threshold;   // (a negative value settles every undecided pose inside kernel 1)
     S.wide = h->wide;
     S.pending_cap = h->pending_cap;
     const bool defer = step_uses_deferral(h);
