@@ -203,8 +203,8 @@ struct PathWindow {
     int lo, hi;
 };
 
-__device__ __forceinline__ PathWindow path_window(const DevParams& P, const double* __restrict__ bbox,
-                                                  const int16_t* __restrict__ index, double x, double y)
+template <typename BoxPtr, typename IndexPtr>
+__device__ __forceinline__ PathWindow path_window(const DevParams& P, BoxPtr bbox, IndexPtr index, double x, double y)
 {
     PathWindow w;
     w.lo = 0;
@@ -213,8 +213,8 @@ __device__ __forceinline__ PathWindow path_window(const DevParams& P, const doub
         return w;  // farther than spatial_precision from the bounding box of the whole path
     const int bx = min(max((int)floor((x - bbox[4]) * bbox[5]), 0), kPathBuckets - 1);
     const int by = min(max((int)floor((y - bbox[6]) * bbox[7]), 0), kPathBuckets - 1);
-    const int16_t* ix = index + 2 * bx;
-    const int16_t* iy = index + 2 * (kPathBuckets + by);
+    const IndexPtr ix = index + 2 * bx;
+    const IndexPtr iy = index + 2 * (kPathBuckets + by);
     w.lo = max((int)ix[0], (int)iy[0]);
     w.hi = min((int)ix[1], (int)iy[1]);
     return w;
@@ -324,20 +324,13 @@ __device__ __forceinline__ void fifo_delay(double* __restrict__ q, int delay, in
 
 #ifdef BCP_DIAG
 __device__ unsigned long long g_diag[1024 * 8];
-__device__ unsigned long long g_diag1[1024 * 8];
-#define DIAG1_STAMP(k) do { if (threadIdx.x == 0) g_diag1[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define DIAG_STAMP(k) do { if (threadIdx.x == 0) g_diag[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int bcp_diag_read(unsigned long long* out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(g_diag));
 }
-extern "C" int bcp_diag1_read(unsigned long long* out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag1), sizeof(g_diag1));
-}
 #else
 #define DIAG_STAMP(k) do { } while (0)
-#define DIAG1_STAMP(k) do { } while (0)
 #endif
 
 constexpr int kShards = 64;  // a wave parks into shard (block index % kShards)
@@ -459,9 +452,15 @@ __device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const
 // (:377-396), reward (:352), done (:407-419), outputs, optional reset, state write-back.  Runs on one lane for env i.
 // PLAIN = true (the two-kernel step: no delays, continuous reward provider -- see step_uses_deferral) compiles the
 // delay queues and the pure-pursuit branch out.
+// reward-provider outcome for the pose as it is when nothing collides, computed ahead of the collision verdict
+struct ScoredFree {
+    double rew, min_dist;
+    int target;
+};
+
 template <bool PLAIN>
 __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
-                                             const PathWindow* free_window = nullptr)
+                                             const PathWindow* free_window = nullptr, const ScoredFree* scored = nullptr)
 {
     const DevParams& P = a.S->P;
     const int pose_delay = PLAIN ? 0 : P.pose_delay, state_delay = PLAIN ? 0 : P.state_delay;
@@ -495,7 +494,11 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
         if (!(a.flags & kAblateNoReward)) rew = reward_pure_pursuit(pts, m, seen[0], seen[1], collided, min_dist, target);
         goal = hypot(pts[5 * (m - 1)] - seen[0], pts[5 * (m - 1) + 1] - seen[1]) < 1.0;   // done(), reward.py:141-150
     } else {
-        if (!(a.flags & kAblateNoReward)) {
+        if (scored && !hit && !pose_delay) {   // the scorer wave has already done it (step_fast_pair_kernel)
+            rew = scored->rew;
+            min_dist = scored->min_dist;
+            target = scored->target;
+        } else if (!(a.flags & kAblateNoReward)) {
             // way-point window of the pose: the caller may have looked it up already for the un-rolled-back pose
             const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : g * 8);
             const int16_t* index = a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
@@ -509,7 +512,6 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
         goal = target > m - 1;
     }
     const bool done = goal || (iter >= P.iteration_timeout) || collided;
-    if (free_window) DIAG1_STAMP(5);
 
     a.reward[i] = rew;
     a.done[i] = (uint8_t)done;
@@ -555,8 +557,6 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
         seen_rs[5] = r.steer;
         seen_rs[6] = r.wheel;
     }
-
-    if (free_window) DIAG1_STAMP(6);
     a.S->st.x[i] = r.p.x;
     a.S->st.y[i] = r.p.y;
     a.S->st.angle[i] = r.p.th;
@@ -655,114 +655,174 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
 }
 
 
-// Fast step kernel (kernel 1 of the two-kernel step; needs a distance field).  A pose is cleared in O(1) by the
-// outer test; the few envs it cannot clear are finished optimistically ("free") AND parked in `pending`, and kernel 2
-// redoes those that really collide.  Waves with many undecided lanes (robots hugging walls) settle them in place.
-// Memory operations are grouped so that independent round trips overlap: every wave runs alone on its SIMD, so an
-// exposed L2 / HBM latency is pure stall.
+// Kernel 1 of the two-kernel step (needs a distance field).  A pose is cleared in O(1) by the outer test; the few
+// envs it cannot clear are finished optimistically ("free") AND parked in `pending`, and kernel 2 redoes those that
+// really collide.  Waves with many undecided lanes (robots hugging walls) settle them in place.  Memory operations are
+// grouped so that independent round trips overlap: a wave has at most one partner on its SIMD, so an exposed L2 / HBM
+// latency is nearly pure stall.
+//
+// It runs with TWO wavefronts per 64 envs.  A wave that runs alone on its SIMD is bound by the latency of its
+// own dependent chain, and the two longest stretches after the robot model -- collision classification + parking on
+// one side, the reward scan on the other -- only share the new pose.  So the "mover" wave (loads, robot model,
+// classification, parking / in-place settling, write-back) hands the pose to the "scorer" wave through LDS, the
+// scorer runs the reward provider for the free pose meanwhile, and the mover picks the result up for every env that
+// did not collide in place (those redo the reward themselves for the rolled-back pose).
+// LDS: [qverts][shared path][64 x {x, y, theta}][64 x {reward, min_dist, target}]
 template <bool WIDE>
-__global__ void __launch_bounds__(kBlock) step_fast_kernel(const StepArgs a)
+__global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepArgs a)
 {
     const DevParams& P = a.S->P;
-    const int tid = threadIdx.x;
-    const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool mover = tid < kBlock;
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + lane;
     const bool active = gi < a.S->n;
     const int64_t i = active ? gi : a.S->n - 1;
-    DIAG1_STAMP(0);
 
-    // (1) loads for the LDS staging of the scaled footprint and of the shared path (up to 8 doubles per lane per
-    //     round), issued first ...
+    // (1) staging loads (both waves), then the mover's state / action / noise and the scorer's two reward-state words
     __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
     const int nq = 2 * P.n_verts;
     const double my_q = tid < nq ? P.qverts[tid >> 1][tid & 1] : 0.0;
-    double t[8];
+    double t[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int k = u * kBlock + tid;
+    for (int u = 0; u < 4; ++u) {
+        const int k = u * 2 * kBlock + tid;
         t[u] = k < a.S->lds_path_doubles ? a.S->path.pts[k] : 0.0;
     }
-    // (2) ... then state, action, noise (the first-touch lines of this step): all of it is in flight together
     Pending q;
-    double cmd0, cmd1;
-    load_env<true>(a, i, active, q, cmd0, cmd1);
-    if (gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
-    if (gi < kShards && a.inplace_next) a.inplace_next[gi] = 0;
-    // (3) LDS writes (the staging loads return first, in issue order)
+    double cmd0 = 0.0, cmd1 = 0.0;
+    if (mover) {
+        load_env<true>(a, i, active, q, cmd0, cmd1);
+        if (gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
+        if (gi < kShards && a.inplace_next) a.inplace_next[gi] = 0;
+    } else {
+        q.min_dist = a.S->st.min_dist[i];
+        q.target = a.S->st.target_idx[i];
+        q.geom = a.S->geom_of_env ? a.S->geom_of_env[i] : 0;
+    }
+    // the scorer also brings the bounding box and the bucket index of a shared path into LDS while the mover is busy
+    // with the robot model (its window look-up then needs no global round trip); a private path's box is fetched now
+    // as well -- it does not depend on the pose
+    double box[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t index_words[2] = {0, 0};
+    if (!mover) {
+        if (a.S->path.shared) {
+            if (lane < 8) box[0] = a.S->path.bbox[lane];
+            const uint32_t* iw = reinterpret_cast<const uint32_t*>(a.S->path.index);   // [2][kPathBuckets][2] int16
+            index_words[0] = iw[lane];
+            index_words[1] = iw[kBlock + lane];
+        } else {
+            const int64_t g = slot_of(a.S, i, q);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) box[k] = a.S->path.bbox[g * 8 + k];
+        }
+    }
     if (tid < nq) qv[tid] = my_q;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int k = u * kBlock + tid;
+    for (int u = 0; u < 4; ++u) {
+        const int k = u * 2 * kBlock + tid;
         if (k < a.S->lds_path_doubles) qv[nq + k] = t[u];
     }
-    for (int k = 8 * kBlock + tid; k < a.S->lds_path_doubles; k += kBlock) qv[nq + k] = a.S->path.pts[k];  // long paths
-    __syncthreads();
-    DIAG1_STAMP(1);
+    for (int k = 512 + tid; k < a.S->lds_path_doubles; k += 2 * kBlock) qv[nq + k] = a.S->path.pts[k];  // long paths
     const LdsF64 lds_path = a.S->lds_path_doubles ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
-
-    // ---- _env_step (envs/base/env.py:442-461)
-    Robot& r = q.r;
-    q.old = r.p;
-    q.drawn = 0;
-    q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
-    DIAG1_STAMP(2);
-
-    // (3) everything that depends only on the new pose is looked up together: distance-field samples and the
-    //     way-point window of the reward
-    const int64_t g = slot_of(a.S, i, q);
-    double ox = a.S->map.ox, oy = a.S->map.oy;
-    if (a.S->map.origins) {
-        ox = a.S->map.origins[2 * g + 0];
-        oy = a.S->map.origins[2 * g + 1];
+    __attribute__((address_space(3))) double* hand_pose = qv + nq + a.S->lds_path_doubles;
+    __attribute__((address_space(3))) double* hand_score = hand_pose + 3 * kBlock;
+    __attribute__((address_space(3))) double* lds_box = hand_score + 3 * kBlock;                    // [8]
+    __attribute__((address_space(3))) uint32_t* lds_index = (__attribute__((address_space(3))) uint32_t*)(lds_box + 8);  // [128]
+    if (!mover && a.S->path.shared) {
+        if (lane < 8) lds_box[lane] = box[0];
+        lds_index[lane] = index_words[0];
+        lds_index[kBlock + lane] = index_words[1];
     }
-    const int px = (int)rint((r.p.x - ox) * a.S->map.inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
-    const int py = (int)rint((r.p.y - oy) * a.S->map.inv_res);
-    const double c = cos(r.p.th), s = sin(r.p.th);
-    const int64_t map_env = a.S->map.shared ? 0 : g;
-    OuterLookups look;
-    look.off_map = true;
-    if (!(a.flags & (kAblateNoCollision | kAblateNoClassify))) look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
-    const PathWindow win = path_window(P, a.S->path.bbox + (a.S->path.shared ? 0 : g * 8),
-                                       a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets)), r.p.x, r.p.y);
-    const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
-    DIAG1_STAMP(3);
+
+    // (2) mover: _env_step's robot model (envs/base/env.py:442-461); the new pose goes to the scorer
+    Robot& r = q.r;
+    if (mover) {
+        q.old = r.p;
+        q.drawn = 0;
+        q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
+        hand_pose[lane] = r.p.x;
+        hand_pose[kBlock + lane] = r.p.y;
+        hand_pose[2 * kBlock + lane] = r.p.th;
+    }
+    __syncthreads();
 
     bool hit = false;
-    const uint64_t amb = __ballot(cls == kAmbiguous);
-    const int n_amb = (int)__popcll(amb);
-    const int threshold = a.threshold_now ? *a.threshold_now : a.S->dense_threshold;
-    if (n_amb > threshold) {
-        // many undecided lanes in this wave: settle them in place, one pose at a time by the whole wave
-        if (tid == 0 && a.inplace_count) atomicAdd(a.inplace_count + (int)(blockIdx.x % kShards), n_amb);
-        const bool inner = cls == kAmbiguous && classify_inner_hit(a.S->cull, map_env, px, py, c, s);
-        hit = inner;
-        uint64_t todo = __ballot(cls == kAmbiguous && !inner);
-        const double vqx = tid < P.n_verts ? qv[2 * tid] : 0.0, vqy = tid < P.n_verts ? qv[2 * tid + 1] : 0.0;
-        while (todo) {
-            const int src = __ffsll((unsigned long long)todo) - 1;
-            todo &= todo - 1;
-            const int64_t env_ = ((int64_t)bcast_i((int)(g >> 32), src) << 32) | (uint32_t)bcast_i((int)g, src);
-            const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : env_ * a.S->map.env_stride);
-            const bool h = coop_collides<WIDE>(P, vqx, vqy, bcast_d(c, src), bcast_d(s, src), bcast_i(px, src),
-                                               bcast_i(py, src), words, a.S->map.rows, a.S->map.cols, a.S->map.wpr);
-            if (tid == src) hit = h;
+    if (mover) {
+        // (3a) collision: distance-field classification, then parking or in-place settling
+        const int64_t g = slot_of(a.S, i, q);
+        double ox = a.S->map.ox, oy = a.S->map.oy;
+        if (a.S->map.origins) {
+            ox = a.S->map.origins[2 * g + 0];
+            oy = a.S->map.origins[2 * g + 1];
         }
-    } else if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
-        // a few undecided lanes: park the pre-verdict state for kernel 2 (load-balanced over the whole GPU) and carry
-        // on as if the pose were free, which it is for nearly every parked env
-        const int shard = (int)(blockIdx.x % kShards);
-        const int slot = atomicAdd(a.pending_count + shard, 1);
-        q.c = c;
-        q.s = s;
-        q.px = px;
-        q.py = py;
-        q.env_lo = (int32_t)(uint32_t)i;
-        q.env_hi = (int32_t)(i >> 32);
-        a.S->pending[(int64_t)slot * kShards + shard] = q;  // interleaved: the used slots stay in a few pages
+        const int px = (int)rint((r.p.x - ox) * a.S->map.inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
+        const int py = (int)rint((r.p.y - oy) * a.S->map.inv_res);
+        const double c = cos(r.p.th), s = sin(r.p.th);
+        const int64_t map_env = a.S->map.shared ? 0 : g;
+        OuterLookups look;
+        look.off_map = true;
+        if (!(a.flags & (kAblateNoCollision | kAblateNoClassify)))
+            look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
+        const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
+        const uint64_t amb = __ballot(cls == kAmbiguous);
+        const int n_amb = (int)__popcll(amb);
+        const int threshold = a.threshold_now ? *a.threshold_now : a.S->dense_threshold;
+        if (n_amb > threshold) {
+            if (lane == 0 && a.inplace_count) atomicAdd(a.inplace_count + (int)(blockIdx.x % kShards), n_amb);
+            const bool inner = cls == kAmbiguous && classify_inner_hit(a.S->cull, map_env, px, py, c, s);
+            hit = inner;
+            uint64_t todo = __ballot(cls == kAmbiguous && !inner);
+            const double vqx = lane < P.n_verts ? qv[2 * lane] : 0.0, vqy = lane < P.n_verts ? qv[2 * lane + 1] : 0.0;
+            while (todo) {
+                const int src = __ffsll((unsigned long long)todo) - 1;
+                todo &= todo - 1;
+                const int64_t env_ = ((int64_t)bcast_i((int)(g >> 32), src) << 32) | (uint32_t)bcast_i((int)g, src);
+                const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : env_ * a.S->map.env_stride);
+                const bool h = coop_collides<WIDE>(P, vqx, vqy, bcast_d(c, src), bcast_d(s, src), bcast_i(px, src),
+                                                   bcast_i(py, src), words, a.S->map.rows, a.S->map.cols, a.S->map.wpr);
+                if (lane == src) hit = h;
+            }
+        } else if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
+            const int shard = (int)(blockIdx.x % kShards);
+            const int slot = atomicAdd(a.pending_count + shard, 1);
+            q.c = c;
+            q.s = s;
+            q.px = px;
+            q.py = py;
+            q.env_lo = (int32_t)(uint32_t)i;
+            q.env_hi = (int32_t)(i >> 32);
+            a.S->pending[(int64_t)slot * kShards + shard] = q;  // interleaved: the used slots stay in a few pages
+        }
+    } else if (!(a.flags & kAblateNoReward)) {
+        // (3b) scorer: ContinuousRewardProvider.reward for the pose as it stands if nothing collides
+        const double x = hand_pose[lane], y = hand_pose[kBlock + lane], th = hand_pose[2 * kBlock + lane];
+        const int64_t g = slot_of(a.S, i, q);
+        PathWindow win;
+        if (a.S->path.shared)
+            win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
+        else
+            win = path_window(P, box, a.S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+        const int m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
+        double min_dist = q.min_dist;
+        int target = q.target;
+        double rew;
+        if (lds_path)
+            rew = reward_step(P, lds_path, win, m, x, y, th, min_dist, target);
+        else
+            rew = reward_step(P, a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5), win, m, x, y, th,
+                              min_dist, target);
+        hand_score[lane] = rew;
+        hand_score[kBlock + lane] = min_dist;
+        hand_score[2 * kBlock + lane] = (double)target;
     }
-    DIAG1_STAMP(4);
-    if (!active) return;
-    finalize_env<true>(a, i, q, hit, lds_path, &win);
-    DIAG1_STAMP(7);
+    __syncthreads();
+    if (mover && active) {
+        ScoredFree sc;
+        sc.rew = hand_score[lane];
+        sc.min_dist = hand_score[kBlock + lane];
+        sc.target = (int)hand_score[2 * kBlock + lane];
+        finalize_env<true>(a, i, q, hit, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &sc);
+    }
 }
 
 // Kernel 2 of a step: kPendingWaves wavefronts per parked env: the lanes rasterise

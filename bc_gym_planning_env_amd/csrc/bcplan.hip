@@ -967,11 +967,13 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
         const size_t lds2 = (size_t)2 * 4 * (S.wide ? 8 : 3) * 64 * sizeof(uint32_t);
         const int waves = 2048;  // a multiple of kShards: 32 teams per shard, so that a shard rarely needs a second round
         const bool second = !first_only && S.dense_threshold >= 0;  // (threshold < 0: everything settled in place)
+        // kernel 1 runs with two wavefronts per 64 envs (mover + scorer, step_fast_pair_kernel)
+        const size_t lds1p = lds1 + ((size_t)6 * kBlock + 8) * sizeof(double) + 2 * kBlock * sizeof(uint32_t);
         if (S.wide) {
-            hipLaunchKernelGGL(step_fast_kernel<true>, dim3(blocks), dim3(kBlock), lds1, s, a);
+            hipLaunchKernelGGL(step_fast_pair_kernel<true>, dim3(blocks), dim3(2 * kBlock), lds1p, s, a);
             if (second) hipLaunchKernelGGL(step_pending_kernel<true>, dim3(waves), dim3(kBlock * kPendingWaves), lds2, s, a);
         } else {
-            hipLaunchKernelGGL(step_fast_kernel<false>, dim3(blocks), dim3(kBlock), lds1, s, a);
+            hipLaunchKernelGGL(step_fast_pair_kernel<false>, dim3(blocks), dim3(2 * kBlock), lds1p, s, a);
             if (second) hipLaunchKernelGGL(step_pending_kernel<false>, dim3(waves), dim3(kBlock * kPendingWaves), lds2, s, a);
         }
     } else {

@@ -180,7 +180,7 @@ def main():
         elapsed = float(t.item())
     env.check_errors()
 
-    # One step = two launches on one stream: step_fast_kernel (all envs: robot model, O(1) collision classification,
+    # One step = two launches on one stream: step_fast_pair_kernel (all envs: robot model, O(1) collision classification,
     # reward, done) and step_pending_kernel (the ~1.5 % of envs whose collision needs the exact rasteriser).  Their
     # combined average duration is measured live with HIP events recorded on the launch stream around the timed
     # region (at N=1 the region holds nothing but these launches, back to back); the per-kernel split of the same
@@ -214,7 +214,7 @@ def main():
                                    "8 steps, overlapped with the next steps" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "step_fast_kernel + step_pending_kernel (one step = these two launches)",
+                         "kernel": "step_fast_pair_kernel + step_pending_kernel (one step = these two launches)",
                          "kernel_ms": step_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n,
                          "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",

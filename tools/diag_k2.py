@@ -1,3 +1,6 @@
+"""In-kernel s_memtime stamps of step_pending_kernel (needs a -DBCP_DIAG build of the library at tools/libbcplan_diag.so:
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -DBCP_DIAG -Iinclude
+bc_gym_planning_env_amd/csrc/bcplan.hip -o tools/libbcplan_diag.so)."""
 import sys, os, ctypes as C, numpy as np, torch
 sys.path.insert(0,'.')
 from bc_gym_planning_env_amd import _lib
@@ -24,15 +27,3 @@ for k in range(1,5):
 print('total stamp4-stamp0 median', np.median(d[:,4]-d[:,0]), 'max', (d[:,4]-d[:,0]).max(), ' last end rel t0', (d[:,4]-t0).max())
 idle=a[~work]
 print('idle blocks', len(idle))
-# ---- kernel 1 stamps
-L.bcp_diag1_read.argtypes=[C.c_void_p]
-L.bcp_diag1_read(buf)
-a=np.array(buf[:]).reshape(1024,8).astype(np.int64)
-names=['prologue loads+LDS staging','robot model','lookups (EDT, path window)','ballot/park/in-place','reward','outputs + reset','state stores']
-print('--- step_fast_kernel, 1024 blocks')
-for k in range(1,8):
-    d=a[:,k]-a[:,k-1]
-    print('%-30s median %6d  p90 %6d  max %6d'%(names[k-1], np.median(d), np.percentile(d,90), d.max()))
-tot=a[:,7]-a[:,0]
-print('total median %d p90 %d max %d ; kernel span (last end - first start) %d'%(np.median(tot),np.percentile(tot,90),tot.max(), a[:,7].max()-a[:,0].min()))
-print('start skew: p90 of start-minstart', np.percentile(a[:,0]-a[:,0].min(),90))

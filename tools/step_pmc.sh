@@ -19,7 +19,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for fn in glob.glob("gpurun_out/step_pmc_%s/**/*counter_collection.csv" % c, recursive=True):
         for r in csv.DictReader(open(fn)):
             name = r["Kernel_Name"]
-            for key in ("step_fast_kernel", "step_pending_kernel", "step_kernel", "robot_step_kernel", "copyBuffer"):
+            for key in ("step_fast", "step_pending_kernel", "step_kernel", "robot_step_kernel", "copyBuffer"):
                 if key in name:
                     a = acc[name.split("(")[0].replace("void ", "")]
                     a[0] += 1
