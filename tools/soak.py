@@ -105,3 +105,27 @@ ref = O.OracleBatch(p, n, gd["costmap"], gd["origin"], res, gd["path"])
 ref.reset_from_paths()
 run("diff-drive 64x64", env, ref, scale=(1.0, 1.0))
 print("soak ok")
+
+# 5. egocentric views: thousands of random poses on random-byte costmaps, shared and private, against the oracle
+from bc_gym_planning_env_amd.ops import NativeOps
+rng = np.random.RandomState(seed + 99)
+for trial in range(3):
+    rows, cols = rng.randint(40, 200), rng.randint(40, 200)
+    res = float(rng.choice([0.03, 0.05, 10. / 256]))
+    data = rng.randint(0, 256, (rows, cols)).astype(np.uint8)
+    org = rng.uniform(-3, 0, 2)
+    ops = NativeOps()
+    ops.set_costmap(data, org, res)
+    m = 3000
+    poses = np.stack([rng.uniform(org[0] - 2, org[0] + cols * res + 2, m), rng.uniform(org[1] - 2, org[1] + rows * res + 2, m),
+                      rng.uniform(-10, 10, m)], axis=1)
+    for worg, wsize, border in (((-0.5, -2.0), (3.5, 4.0), 0), ((-1.3, -0.4), (2.21, 1.07), 200), (None, None, 9)):
+        got = ops.extract_egocentric_costmap(poses, worg, wsize, border).cpu().numpy()
+        bad = 0
+        for k in range(m):
+            want = O.extract_egocentric(data, org, res, poses[k], worg, wsize, border)
+            bad += int((want != got[k]).sum())
+        assert bad == 0, (trial, worg, bad)
+    print("egocentric views  map %dx%d @%.4f: %d poses x 3 windows identical to the oracle" % (rows, cols, res, m), flush=True)
+    ops.close()
+print("soak ok (egocentric)")
