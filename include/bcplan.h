@@ -18,8 +18,10 @@
  *   - Unless a parameter says "host", every pointer is a DEVICE pointer on the handle's GPU
  *     (e.g. torch_tensor.data_ptr()); buffers are caller-owned and must outlive their use.
  *   - All launches are asynchronous on the `stream` argument (a hipStream_t, NULL = default stream).
- *     Nothing in bcp_step()/bcp_reset_masked() allocates, synchronises or copies to the host, so the calls
- *     can be captured in a hipGraph.
+ *     bcp_step()/bcp_reset_masked() never synchronise or copy to the host and allocate nothing once the first step
+ *     has run (the first call after a re-bind uploads a 2 KB parameter block; bcp_egocentric_costmaps() allocates its
+ *     scratch on first use).  A step's launches carry the step counter (noise stream key, parity of the alternating
+ *     counter sets) as kernel arguments, so a captured step must not be replayed as a hipGraph node: launch it.
  *   - One handle per GPU / process rank.  A handle is not thread-safe; different handles are independent.
  *   - There is NO CPU fallback in this library: without a GPU bcp_create() fails with BCP_E_NO_DEVICE.
  */
