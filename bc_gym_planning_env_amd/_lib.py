@@ -82,6 +82,7 @@ SYMBOLS = {
     "bcp_egocentric_costmaps": (C.c_int, [_H, C.c_void_p, C.c_int64, _f64p, _f64p, C.c_uint8, C.c_void_p,
                                           C.c_void_p]),
     "bcp_goal_n_state": (C.c_int, [_H, _f64p, C.c_void_p, C.c_void_p]),
+    "bcp_goal_direction_state": (C.c_int, [_H, _f64p, C.c_void_p, C.c_void_p]),
     "bcp_time_step_kernels": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p,
                                         C.POINTER(C.c_float)]),
     "bcp_time_steps": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]),

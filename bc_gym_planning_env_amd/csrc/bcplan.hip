@@ -434,6 +434,29 @@ __global__ void goal_n_state_kernel(const StepStatic* __restrict__ S, double wsx
     if (n_state > 5) o[8] = (float)(ds ? S->st.state_seen[6 * n + i] : S->st.wheel[i]);
 }
 
+// ColoredEgoCostmapRandomAisleTurnEnv's `goal` vector (envs/synth_turn_env.py:412-420), one thread per env: the LAST way
+// point in the robot frame over the window's world size, normalised to unit length, then (v, w, wheel_angle)
+__global__ void goal_direction_state_kernel(const StepStatic* __restrict__ S, double wsx, double wsy, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S->n) return;
+    const int64_t g = S->geom_of_env ? (int64_t)S->geom_of_env[i] : i;
+    const int m = S->path.shared ? S->path.max_len : S->path.lens[g];
+    const double* wp = S->path.pts + ((S->path.shared ? 0 : g * (int64_t)S->path.max_len) + (m - 1)) * 5;
+    const double x = S->st.x[i], y = S->st.y[i], th = S->st.angle[i];   // the robot's own pose (not the delayed one)
+    const double c = cos(th), s = sin(th);
+    const double tx = -x * c - y * s, ty = x * s - y * c, tt = normalize_angle(-th);
+    const double ct = cos(tt), st = sin(tt);
+    const double gx = (ct * wp[0] + (-st) * wp[1] + tx) / wsx, gy = (st * wp[0] + ct * wp[1] + ty) / wsy;
+    const double norm = sqrt(fma(gy, gy, gx * gx));   // np.linalg.norm: fma-contracted 2-term dot
+    double* o = out + 5 * i;
+    o[0] = gx / norm;
+    o[1] = gy / norm;
+    o[2] = S->st.v[i];
+    o[3] = S->st.w[i];
+    o[4] = S->P.model == BCP_MODEL_TRICYCLE ? S->st.wheel[i] : 0.0;
+}
+
 // ------------------------------------------------------------------------------------------------ host API
 // ---- sample points of the distance-field classification (see bcp_coop.h) -----------------------------------
 static double seg_dist(double px, double py, double ax, double ay, double bx, double by)
@@ -1290,6 +1313,23 @@ extern "C" int bcp_goal_n_state(bcp_handle* h, const double* world_size, float* 
     const int n_state = h->params.model == BCP_MODEL_TRICYCLE ? 6 : 5;
     hipLaunchKernelGGL(goal_n_state_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, h->dev_static,
                        world_size[0], world_size[1], n_state, out);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+extern "C" int bcp_goal_direction_state(bcp_handle* h, const double* world_size, double* out, void* stream)
+{
+    if (!h || !world_size || !out) return fail(BCP_E_INVALID, "bcp_goal_direction_state: null argument");
+    if (!h->have_path || !h->have_state)
+        return fail(BCP_E_STATE, "bcp_goal_direction_state: paths and state must be set first");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (h->static_dirty) {
+        const int rc = upload_step_static(h, s);
+        if (rc != BCP_OK) return rc;
+    }
+    hipLaunchKernelGGL(goal_direction_state_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, h->dev_static,
+                       world_size[0], world_size[1], out);
     HIP_TRY(hipGetLastError());
     return BCP_OK;
 }

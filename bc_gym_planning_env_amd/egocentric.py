@@ -56,6 +56,14 @@ class BatchedEgocentricCostmap(object):
                                               self.goal_n_state.data_ptr(), stream))
         return self._obs
 
+    def _refresh_images(self):
+        e = self.env
+        stream = C.c_void_p(torch.cuda.current_stream(e.device).cuda_stream)
+        _lib.check(self._lib.bcp_egocentric_costmaps(
+            e._h, None, e.n_envs, self._origin.ctypes.data_as(_lib._f64p), self._size.ctypes.data_as(_lib._f64p),
+            self._border, self.images.data_ptr(), stream))
+        return stream
+
     def step(self, actions, **kw):
         _o, reward, done, info = self.env.step(actions, **kw)
         return self.observation(), reward, done, info
@@ -78,3 +86,20 @@ class BatchedEgocentricCostmap(object):
 
     def close(self):
         self.env.close()
+
+
+class BatchedColoredEgoCostmap(BatchedEgocentricCostmap):
+    """The observation of ColoredEgoCostmapRandomAisleTurnEnv (envs/synth_turn_env.py:376-451) for a whole batch:
+    OrderedDict(environment=uint8 [N, 133, 133, 1], goal=float64 [N, 5, 1]) -- the egocentric costmap 0.5 m behind to
+    3.5 m ahead of the robot, and (unit direction to the final way point, v, w, wheel_angle)."""
+
+    def __init__(self, env, x_bounds=(-0.5, 3.5), y_bounds=(-2., 2.), border_value=0):
+        super(BatchedColoredEgoCostmap, self).__init__(env, x_bounds, y_bounds, border_value)
+        self.goal = torch.zeros((env.n_envs, 5, 1), dtype=torch.float64, device=env.device)
+        self._obs = OrderedDict((('environment', self.images), ('goal', self.goal)))
+
+    def observation(self, _observation=None):
+        stream = self._refresh_images()
+        _lib.check(self._lib.bcp_goal_direction_state(self.env._h, self._world.ctypes.data_as(_lib._f64p),
+                                                      self.goal.data_ptr(), stream))
+        return self._obs

@@ -237,6 +237,10 @@ int bcp_egocentric_costmaps(bcp_handle *h, const double *poses, int64_t n, const
  * robot_state.to_numpy_array().  out: float32 [N, 3 + 6] (tricycle) / [N, 3 + 5] (diff-drive); zeros for envs whose
  * path is exhausted. */
 int bcp_goal_n_state(bcp_handle *h, const double *world_size /*host*/, float *out, void *stream);
+/* ColoredEgoCostmapRandomAisleTurnEnv's `goal` vector (envs/synth_turn_env.py:412-420) for all envs: the LAST way
+ * point in the robot frame divided by world_size and normalised to unit length, then the robot's egocentric state
+ * (v, w, wheel_angle; 0 for a diff-drive robot).  out: float64 [N, 5]. */
+int bcp_goal_direction_state(bcp_handle *h, const double *world_size /*host*/, double *out, void *stream);
 
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* Runs `steps` bcp_step() launches back to back on `stream` bracketed by HIP events recorded on that stream and

@@ -126,6 +126,7 @@ def lib():
                                              C.c_uint8, _u8p, _i32p, _f64p]
         L.bco_rotate_costmap.argtypes = [_u8p, C.c_int, C.c_int, C.c_double, C.c_uint8, _u8p]
         L.bco_goal_n_state.argtypes = [_f64p, _f64p, C.c_int, _f64p, _f64p, C.c_int, _f32p]
+        L.bco_goal_direction_state.argtypes = [_f64p, _f64p, _f64p, _f64p, _f64p]
         L.bco_reward_pure_pursuit.argtypes = [_f64p, _f64p, C.c_int, C.c_int, _f64p, _i32p]
         L.bco_reward_pure_pursuit.restype = C.c_double
         L.bco_initial_pure_pursuit_state.argtypes = [_f64p, C.c_int, _f64p, _i32p]
@@ -334,6 +335,14 @@ def goal_n_state(pose, remaining_path, world_size, robot_state):
     nxt = _f64(rem[0]) if len(rem) else np.zeros(3)
     lib().bco_goal_n_state(_p(pose, _f64p), _p(nxt, _f64p), len(rem), _p(ws, _f64p), _p(rs, _f64p), len(rs),
                            out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def goal_direction_state(pose, last_waypoint, world_size, ego_state):
+    """ColoredEgoCostmapRandomAisleTurnEnv's goal vector (envs/synth_turn_env.py:412-420) -> float64 [5]"""
+    out = np.zeros(5)
+    lib().bco_goal_direction_state(_p(_f64(pose), _f64p), _p(_f64(last_waypoint), _f64p), _p(_f64(world_size), _f64p),
+                                   _p(_f64(ego_state), _f64p), _p(out, _f64p))
     return out
 
 

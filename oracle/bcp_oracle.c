@@ -590,6 +590,26 @@ void bco_initial_pure_pursuit_state(const double *path, int m, double *min_dist,
     *min_dist = hypot(g[0] - path[0], g[1] - path[1]);
 }
 
+/* envs/synth_turn_env.py:412-420 */
+void bco_goal_direction_state(const double pose[3], const double last_waypoint[3], const double world_size[2],
+                              const double ego_state[3], double out[5])
+{
+    double c = cos(pose[2]), s = sin(pose[2]);
+    double tx = -pose[0] * c - pose[1] * s;
+    double ty = pose[0] * s - pose[1] * c;
+    double tt = bco_normalize_angle(-pose[2]);
+    double ct = cos(tt), st = sin(tt);
+    double ex = ct * last_waypoint[0] + (-st) * last_waypoint[1] + tx;
+    double ey = st * last_waypoint[0] + ct * last_waypoint[1] + ty;
+    double gx = ex / world_size[0], gy = ey / world_size[1];
+    double norm = sqrt(fma(gy, gy, gx * gx)); /* np.linalg.norm: sqrt of a 2-term dot (fma-contracted ddot tail) */
+    out[0] = gx / norm;
+    out[1] = gy / norm;
+    out[2] = ego_state[0];
+    out[3] = ego_state[1];
+    out[4] = ego_state[2];
+}
+
 /* _get_element_from_list_with_delay (env.py:27-49) for the k-th push since reset */
 static void fifo_delay(double *q, int width, int delay, int k, const double *elem, double *out)
 {

@@ -177,6 +177,12 @@ void bco_rotate_costmap(const uint8_t *map, int rows, int cols, double angle, ui
 void bco_goal_n_state(const double pose[3], const double *next_waypoint, int remaining, const double world_size[2],
                       const double *robot_state, int n_state, float *out);
 
+/* ColoredEgoCostmapRandomAisleTurnEnv's `goal` vector (envs/synth_turn_env.py:412-420): the LAST way point in the robot
+ * frame divided by the window's world size, normalised to unit length (np.linalg.norm), then the robot's egocentric
+ * state (v, w, wheel_angle).  float64 [5]. */
+void bco_goal_direction_state(const double pose[3], const double last_waypoint[3], const double world_size[2],
+                              const double ego_state[3], double out[5]);
+
 /* Batched SoA step over n envs with `threads` host threads.
  * state: 7 arrays of n doubles, state[f][i].  maps: shared (map_stride==0) or per-env at i*map_stride bytes.
  * paths: shared (path_stride==0, lens[0]) or per-env at i*path_stride doubles with lens[i].

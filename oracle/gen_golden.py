@@ -559,6 +559,37 @@ def gen_delays_and_pure_pursuit():
             tag, rec["reward"].min(), rec["reward"].max(), rec["collided"].sum(), np.argmax(rec["done"])))
 
 
+def gen_colored_ego():
+    """G12: ColoredEgoCostmapRandomAisleTurnEnv observations (envs/synth_turn_env.py:376-451): 133 x 133 egocentric
+    costmap + the 5-vector (unit goal direction, v, w, wheel angle), along a sampled-action trajectory."""
+    from bc_gym_planning_env.envs.synth_turn_env import ColoredEgoCostmapRandomAisleTurnEnv
+    from bc_gym_planning_env.envs.base import spaces
+    from bc_gym_planning_env.robot_models import differential_drive as dd
+    env = ColoredEgoCostmapRandomAisleTurnEnv()
+    env.seed(3)
+    env.reset()
+    plan_env = env._env
+    spaces.SPACE_LOCAL_RANDOM_STATE.seed(78)
+    st0 = plan_env.get_state()
+    imgs, vecs, states = [], [], []
+    with SlotTap(dd, 6):
+        for t in range(120):
+            a = env.action_space.sample()
+            a = type(a)(command=np.array([a.command[0] * 2.5, a.command[1]]))
+            obs, _r, done, _ = env.step(a)
+            img = obs['environment'][:, :, 0]
+            assert set(np.unique(img)) <= {0, 254}
+            imgs.append(np.packbits(img == 254, axis=1))
+            vecs.append(obs['goal'][:, 0].copy())
+            states.append(tri_state_vec(plan_env._robot.get_state()))
+            if done:
+                break
+    save("g12_colored_ego.npz", costmap=st0.costmap.get_data().copy(), origin=np.array(st0.costmap.get_origin()),
+         resolution=np.float64(st0.costmap.get_resolution()), path=np.array(st0.reward_provider_state.path),
+         images=np.stack(imgs), image_shape=np.array(img.shape), goal=np.stack(vecs), states=np.stack(states),
+         window_origin=np.array([-0.5, -2.0]), window_size=np.array([4.0, 4.0]))
+
+
 def gen_egocentric():
     """G10: EgocentricCostmap(env).step observations (envs/egocentric.py:102-160) along sampled-action trajectories:
     the 133 x 117 egocentric costmap and the goal_n_state vector, with the state they were computed from."""
@@ -608,6 +639,7 @@ def main():
     gen_kat_collision_table()
     gen_mini_geometry()
     gen_egocentric()
+    gen_colored_ego()
     gen_delays_and_pure_pursuit()
     gen_diffdrive_trajectories()
     gen_trajectories()

@@ -155,3 +155,26 @@ def test_wrapper_steps_with_pool_env(torch_cuda, oracle):
             want = oracle.goal_n_state(st[:3, i], env._paths[geom[i]][tidx[i]:], world, rs)
             np.testing.assert_allclose(vec[i], want, rtol=0, atol=1e-6)
     assert len(np.unique(geom)) > 3
+
+
+def test_g12_colored_ego_observation(torch_cuda):
+    """ColoredEgoCostmapRandomAisleTurnEnv's observation from the reference's recorded states: a 350 x 512 costmap (too
+    large for LDS: sampled from global memory), 133 x 133 window, float64 goal vector"""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    from bc_gym_planning_env_amd.egocentric import BatchedColoredEgoCostmap
+    g = np.load(os.path.join(GOLDEN, "g12_colored_ego.npz"))
+    n = len(g["states"])
+    res = float(g["resolution"])
+    env = BatchedPlanEnv(CostMap2D(g["costmap"], res, g["origin"]), g["path"], EnvParams(resolution=res, refine_path=False),
+                         n_envs=n)
+    env.state.robot.copy_(torch.from_numpy(np.ascontiguousarray(g["states"].T)).cuda())
+    wrap = BatchedColoredEgoCostmap(env)
+    assert wrap.image_shape == tuple(int(v) for v in g["image_shape"]) == (133, 133)
+    obs = wrap.observation()
+    want = np.unpackbits(g["images"], axis=2)[:, :, :133].astype(bool)
+    img = obs['environment'].cpu().numpy()
+    assert ((img[..., 0] == 254) == want).all() and set(np.unique(img)) <= {0, 254}
+    vec = obs['goal'].cpu().numpy()
+    assert vec.shape == (n, 5, 1) and vec.dtype == np.float64
+    np.testing.assert_allclose(vec[:, :, 0], g["goal"], rtol=0, atol=1e-9)

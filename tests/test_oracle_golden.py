@@ -210,3 +210,19 @@ def test_g11_delays_and_pure_pursuit(oracle, golden_dir, name):
         assert ref.reward[0] == g["reward"][t], (name, t, ref.reward[0], g["reward"][t])
         assert ref.done[0] == g["done"][t] and ref.collided[0] == g["collided"][t], (name, t)
         assert ref.target_idx[0] == g["target_idx"][t] and ref.min_dist[0] == g["min_dist"][t], (name, t)
+
+
+def test_g12_colored_ego_observation(oracle, golden_dir):
+    """ColoredEgoCostmapRandomAisleTurnEnv (envs/synth_turn_env.py:376-451): 133 x 133 view + unit goal direction"""
+    g = np.load(os.path.join(golden_dir, "g12_colored_ego.npz"))
+    res, org = float(g["resolution"]), g["origin"]
+    wo, ws = g["window_origin"], g["window_size"]
+    rows, cols = [int(v) for v in g["image_shape"]]
+    world = np.array([(wo[0] + res * cols) - wo[0], (wo[1] + res * rows) - wo[1]])
+    for t in range(len(g["states"])):
+        st = g["states"][t]
+        img = oracle.extract_egocentric(g["costmap"], org, res, st[:3], wo, ws)
+        want = np.unpackbits(g["images"][t], axis=1)[:, :cols].astype(bool)
+        assert img.shape == (rows, cols) and ((img == 254) == want).all(), t
+        vec = oracle.goal_direction_state(st[:3], g["path"][-1], world, [st[3], st[4], st[6]])
+        np.testing.assert_allclose(vec, g["goal"][t], rtol=0, atol=1e-12)
