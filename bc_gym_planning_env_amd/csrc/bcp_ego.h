@@ -39,6 +39,7 @@ struct EgoArgs {
     int32_t border;
     int64_t n_envs;              // image i shows the costmap of env i % n_envs
     int64_t n_images;
+    int32_t win_lds_bytes;       // ego_costmap_window_kernel: LDS bytes for the visible part of the map (+ ring)
     uint8_t* out;                // [n][drows][dcols]
 };
 
@@ -201,19 +202,39 @@ __device__ __forceinline__ void ego_stage_map(const EgoArgs& a, const uint8_t* _
     __syncthreads();
 }
 
+// How source coordinates map onto the LDS copy of (a part of) the costmap: the copy holds map columns c0 .. c0 + w - 1
+// and rows r0 .. r0 + h - 1 inside a one-cell ring of the border value, `pitch` = w + 2 bytes per row.
+//   X' = X + x_add, clamped to [x_lo, x_hi]  (x_add = 1 + LDS base address - c0: the sum is a raw LDS byte address)
+//   Y' = Y + y_add, clamped to [0, y_hi]     (y_add = 1 - r0)
+struct EgoStage {
+    int x_add, y_add, x_lo, x_hi, y_hi, pitch;
+};
+
+__device__ __forceinline__ EgoStage ego_stage_of(int lds_base, int c0, int r0, int w, int h)
+{
+    EgoStage G;
+    G.x_add = 1 + lds_base - c0;
+    G.y_add = 1 - r0;
+    G.x_lo = lds_base;
+    G.x_hi = lds_base + w + 1;
+    G.y_hi = h + 1;
+    G.pitch = w + 2;
+    return G;
+}
+
 // per-row terms of one image (rounding term included; staged sampling: ring offset and LDS base folded in) and the
 // off-map flag of each row, for rows t0, t0 + tstep, ...
 template <bool STAGED>
-__device__ __forceinline__ void ego_row_terms(const EgoArgs& a, const EgoImage& I, int x_shift, LdsI32 row_tab, int t0,
-                                              int tstep)
+__device__ __forceinline__ void ego_row_terms(const EgoArgs& a, const EgoImage& I, const EgoStage& G, LdsI32 row_tab,
+                                              int t0, int tstep)
 {
     const int last_cx = sat_int(I.m0 * (a.dcols - 1) * 1024), last_cy = sat_int(I.m3 * (a.dcols - 1) * 1024);
     for (int y = t0; y < a.drows; y += tstep) {
         const int rx = sat_int((I.m1 * y + I.m2) * 1024) + 512, ry = sat_int((I.m4 * y + I.m5) * 1024) + 512;
         const int xa = rx >> 10, xb = (rx + last_cx) >> 10, ya = ry >> 10, yb = (ry + last_cy) >> 10;
         const bool off = (xa < 0 && xb < 0) || (xa >= I.vc && xb >= I.vc) || (ya < 0 && yb < 0) || (ya >= I.vr && yb >= I.vr);
-        row_tab[2 * y] = off ? kRowOff : (STAGED ? rx + x_shift * 1024 : rx);
-        row_tab[2 * y + 1] = STAGED ? ry + 1024 : ry;
+        row_tab[2 * y] = off ? kRowOff : (STAGED ? rx + G.x_add * 1024 : rx);
+        row_tab[2 * y + 1] = STAGED ? ry + G.y_add * 1024 : ry;
     }
 }
 
@@ -221,13 +242,13 @@ __device__ __forceinline__ void ego_row_terms(const EgoArgs& a, const EgoImage& 
 // group of a row is shifted left so that it ends at the last column (it recomputes a few pixels of its neighbour
 // instead of needing a narrower store).
 template <bool STAGED, int PX>
-__device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, int x_shift, int pitch,
+__device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, const EgoStage& G,
                                            const uint8_t* __restrict__ src, LdsI32 row_tab, uint8_t* __restrict__ image,
                                            int cg, int r0, int rstep)
 {
     const uint32_t border = (uint32_t)a.border;
     const uint64_t border8 = (uint64_t)border * 0x0101010101010101ull;
-    const int x_lo = x_shift - 1, x_hi = x_shift + I.vc, y_lo = 0, y_hi = I.vr + 1;   // ring coordinates (staged sampling)
+    const int x_lo = G.x_lo, x_hi = G.x_hi, y_lo = 0, y_hi = G.y_hi, pitch = G.pitch;   // ring coordinates (staged sampling)
     for (int xg = PX * cg; xg < a.dcols; xg += 128) {
         const int x0 = min(xg, a.dcols - PX);
         int ccx[PX], ccy[PX];
@@ -300,8 +321,7 @@ __global__ void __launch_bounds__(256) ego_costmap_kernel(const EgoArgs a)
     if (STAGED)
         ego_stage_map(a, a.data, a.valid_rows ? a.valid_rows[0] : a.rows, a.valid_cols ? a.valid_cols[0] : a.cols, lmap,
                       pitch, map_bytes);
-    // staged sampling: X' = X + x_shift and Y' = Y + 1 index the ringed copy directly (raw LDS byte address)
-    const int x_shift = 1 + (int)(uint32_t)(uintptr_t)lmap;
+    const int lds_base = (int)(uint32_t)(uintptr_t)lmap;   // (source coordinates become raw LDS byte addresses)
     constexpr int kGroups = 128 / PX, kRows = 64 / kGroups;   // lanes of a wave: kRows image rows x kGroups pixel groups
     const int cg = lane % kGroups, rl = lane / kGroups;
     const int64_t P = (int64_t)a.drows * a.dcols;
@@ -316,9 +336,11 @@ __global__ void __launch_bounds__(256) ego_costmap_kernel(const EgoArgs a)
         for (int k = 0; k < count; ++k) {            // the wave's images, one at a time
             const int64_t img = base + k * stride;
             const EgoImage I = ego_broadcast(T, k);
-            ego_row_terms<STAGED>(a, I, x_shift, row_tab, lane, 64);
+            EgoStage G = ego_stage_of(lds_base, 0, 0, I.vc, I.vr);
+            G.pitch = pitch;
+            ego_row_terms<STAGED>(a, I, G, row_tab, lane, 64);
             wave_lds_sync();
-            ego_pixels<STAGED, PX>(a, I, x_shift, pitch, a.data + I.g * a.map_stride, row_tab, a.out + img * P, cg, rl, kRows);
+            ego_pixels<STAGED, PX>(a, I, G, a.data + I.g * a.map_stride, row_tab, a.out + img * P, cg, rl, kRows);
             wave_lds_sync();   // the table is rewritten for the next image
         }
     }
@@ -341,7 +363,7 @@ __global__ void __launch_bounds__(256) ego_costmap_binned_kernel(const EgoArgs a
     const LdsU8 lmap = (LdsU8)ego_lds;
     const LdsI32 tables = (LdsI32)(lmap + map_bytes);
     const LdsI32 wave_tab = tables + wave * (2 * a.drows);
-    const int x_shift = 1 + (int)(uint32_t)(uintptr_t)lmap;
+    const int lds_base = (int)(uint32_t)(uintptr_t)lmap;
     constexpr int kGroups = 128 / PX, kRows = 64 / kGroups;
     const int cg = lane % kGroups, rl = lane / kGroups;
     const int64_t P = (int64_t)a.drows * a.dcols;
@@ -369,9 +391,11 @@ __global__ void __launch_bounds__(256) ego_costmap_binned_kernel(const EgoArgs a
             for (int k = 0; k < batch; ++k) {
                 const int64_t img = (uint32_t)bcast_i(my_img, k);
                 const EgoImage I = ego_broadcast(T, k);
-                ego_row_terms<true>(a, I, x_shift, wave_tab, lane, 64);
+                EgoStage G = ego_stage_of(lds_base, 0, 0, I.vc, I.vr);
+                G.pitch = pitch;
+                ego_row_terms<true>(a, I, G, wave_tab, lane, 64);
                 wave_lds_sync();
-                ego_pixels<true, PX>(a, I, x_shift, pitch, nullptr, wave_tab, a.out + img * P, cg, rl, kRows);
+                ego_pixels<true, PX>(a, I, G, nullptr, wave_tab, a.out + img * P, cg, rl, kRows);
                 wave_lds_sync();
             }
         }
@@ -388,12 +412,108 @@ __global__ void __launch_bounds__(256) ego_costmap_binned_kernel(const EgoArgs a
                 const int64_t img = (uint32_t)bcast_i(my_img, k);
                 const EgoImage I = ego_broadcast(T, k);
                 __syncthreads();   // the table is free (earlier images are finished)
-                ego_row_terms<true>(a, I, x_shift, tables, threadIdx.x, 256);
+                EgoStage G = ego_stage_of(lds_base, 0, 0, I.vc, I.vr);
+                G.pitch = pitch;
+                ego_row_terms<true>(a, I, G, tables, threadIdx.x, 256);
                 __syncthreads();
-                ego_pixels<true, PX>(a, I, x_shift, pitch, nullptr, tables, a.out + img * P, cg, wave * kRows + rl, 4 * kRows);
+                ego_pixels<true, PX>(a, I, G, nullptr, tables, a.out + img * P, cg, wave * kRows + rl, 4 * kRows);
             }
         }
         pos = run_end;
+    }
+}
+
+// Maps too large for LDS (a 333 x 183 AisleTurn costmap with its ring already is): one workgroup per image stages
+// only the part of the map the window can see -- the bounding box of the window's four corners in source coordinates
+// (exact: the source coordinates are monotone along rows and columns), at most about diag(window)^2 bytes -- inside
+// the usual border ring, and the 4 waves then share the image like the left-over path above.
+// LDS: [window part of the map + ring (a.win_lds_bytes)] [one row table]
+template <int PX>
+__global__ void __launch_bounds__(256) ego_costmap_window_kernel(const EgoArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const LdsU8 lmap = (LdsU8)ego_lds;
+    const LdsI32 tables = (LdsI32)(lmap + a.win_lds_bytes);
+    const int lds_base = (int)(uint32_t)(uintptr_t)lmap;
+    constexpr int kGroups = 128 / PX, kRows = 64 / kGroups;
+    const int cg = lane % kGroups, rl = lane / kGroups;
+    const int64_t P = (int64_t)a.drows * a.dcols;
+    const int64_t first = blockIdx.x, stride = gridDim.x;
+    for (int64_t base = first; base < a.n_images; base += 64 * stride) {
+        EgoXform T;
+        memset(&T, 0, sizeof(T));
+        const int64_t mine = base + lane * stride;   // lane l: transform of the workgroup's l-th image of this batch
+        if (mine < a.n_images) T = ego_transform(a, mine);
+        const int64_t left = (a.n_images - base + stride - 1) / stride;
+        const int count = (int)(left < 64 ? left : 64);
+        for (int k = 0; k < count; ++k) {
+            const int64_t img = base + k * stride;
+            const EgoImage I = ego_broadcast(T, k);
+            // source bounding box of the window: its corners (first / last column terms, first / last row terms)
+            const int cx1 = sat_int(I.m0 * (a.dcols - 1) * 1024), cy1 = sat_int(I.m3 * (a.dcols - 1) * 1024);
+            const int rx0 = sat_int(I.m2 * 1024) + 512, ry0 = sat_int(I.m5 * 1024) + 512;
+            const int rx1 = sat_int((I.m1 * (a.drows - 1) + I.m2) * 1024) + 512;
+            const int ry1 = sat_int((I.m4 * (a.drows - 1) + I.m5) * 1024) + 512;
+            const int xs[4] = {rx0 >> 10, (rx0 + cx1) >> 10, rx1 >> 10, (rx1 + cx1) >> 10};
+            const int ys[4] = {ry0 >> 10, (ry0 + cy1) >> 10, ry1 >> 10, (ry1 + cy1) >> 10};
+            int c0 = max(min(min(xs[0], xs[1]), min(xs[2], xs[3])), 0);
+            int c1 = min(max(max(xs[0], xs[1]), max(xs[2], xs[3])), I.vc - 1);
+            int r0 = max(min(min(ys[0], ys[1]), min(ys[2], ys[3])), 0);
+            int r1 = min(max(max(ys[0], ys[1]), max(ys[2], ys[3])), I.vr - 1);
+            int w = c1 - c0 + 1, h = r1 - r0 + 1;
+            if (w <= 0 || h <= 0) w = h = 0;   // the window misses the map: every row is flagged off the map below
+            const int pitch = w + 2;
+            __syncthreads();   // the previous image is finished with the LDS copy and the table
+            if ((h + 2) * pitch <= a.win_lds_bytes) {
+                // ring first (top / bottom rows, left / right columns) ...
+                for (int c = threadIdx.x; c < pitch; c += 256) {
+                    lmap[c] = (uint8_t)a.border;
+                    lmap[(h + 1) * pitch + c] = (uint8_t)a.border;
+                }
+                for (int r = threadIdx.x; r < h; r += 256) {
+                    lmap[(r + 1) * pitch] = (uint8_t)a.border;
+                    lmap[(r + 1) * pitch + w + 1] = (uint8_t)a.border;
+                }
+                // ... then the visible rows: a wave takes rows wave, wave + 4, ...; a row is fetched as aligned dwords
+                // (one per lane: w + 3 <= 256 bytes), eight rows in flight per wave, and scattered byte-wise into LDS
+                const uint8_t* const origin = a.data + I.g * a.map_stride + (int64_t)r0 * a.cols + c0;
+                constexpr int kInFlight = 8;   // rows in flight per wave
+                for (int rb = wave; rb < h; rb += 4 * kInFlight) {
+                    uint32_t word[kInFlight];
+                    int skew[kInFlight];
+#pragma unroll
+                    for (int u = 0; u < kInFlight; ++u) {
+                        const int r = rb + 4 * u;
+                        const uint8_t* row = origin + (int64_t)r * a.cols;
+                        skew[u] = (int)((uintptr_t)row & 3);
+                        const uint32_t* aligned = reinterpret_cast<const uint32_t*>(row - skew[u]);
+                        word[u] = (r < h && 4 * lane < w + skew[u]) ? aligned[lane] : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kInFlight; ++u) {
+                        const int r = rb + 4 * u;
+                        if (r < h) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int c = 4 * lane + j - skew[u];
+                                if ((unsigned)c < (unsigned)w) lmap[(r + 1) * pitch + 1 + c] = (uint8_t)(word[u] >> (8 * j));
+                            }
+                        }
+                    }
+                }
+                const EgoStage G = ego_stage_of(lds_base, c0, r0, w, h);
+                ego_row_terms<true>(a, I, G, tables, threadIdx.x, 256);
+                __syncthreads();
+                ego_pixels<true, PX>(a, I, G, nullptr, tables, a.out + img * P, cg, wave * kRows + rl, 4 * kRows);
+            } else {
+                // (cannot happen for windows the host accepted; kept as a safe fallback: sample from global memory)
+                EgoStage G = ego_stage_of(0, 0, 0, I.vc, I.vr);
+                ego_row_terms<false>(a, I, G, tables, threadIdx.x, 256);
+                __syncthreads();
+                ego_pixels<false, PX>(a, I, G, a.data + I.g * a.map_stride, tables, a.out + img * P, cg, wave * kRows + rl,
+                                      4 * kRows);
+            }
+        }
     }
 }
 

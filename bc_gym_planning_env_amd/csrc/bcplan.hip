@@ -1279,12 +1279,32 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
         if (px8) hipLaunchKernelGGL((ego_costmap_binned_kernel<8>), grid, block, lds, st, a, bin_start, bin_count, order);
         else hipLaunchKernelGGL((ego_costmap_binned_kernel<4>), grid, block, lds, st, a, bin_start, bin_count, order);
     } else {
-        // shared map (staged in LDS when it fits) or maps too large for LDS (sampled from global memory):
-        // persistent workgroups, as many as are resident at once
-        a.stage_map = (a.shared && map_bytes + 4 * row_bytes <= 60 * 1024) ? 1 : 0;
+        // shared map (staged in LDS when it fits) or maps too large for LDS: persistent workgroups, as many as are
+        // resident at once
+        // (gfx950 gives a workgroup up to 160 KB of LDS; a big copy costs occupancy, but LDS sampling still wins)
+        a.stage_map = (a.shared && map_bytes + 4 * row_bytes <= 150 * 1024) ? 1 : 0;
+        // too large: each workgroup stages just the part of the map its window can see -- at most the window's
+        // diagonal (+ 2 px of rounding, + ring) squared
+        const double diag = std::sqrt((double)a.drows * a.drows + (double)a.dcols * a.dcols);
+        const size_t side = (size_t)std::ceil(diag) + 5;
+        const size_t win_bytes = (side * side + 3) & ~(size_t)3;
+        if (!a.stage_map && win_bytes + row_bytes <= 60 * 1024) {
+            a.win_lds_bytes = (int32_t)win_bytes;
+            const size_t lds = win_bytes + row_bytes;
+            const void* fn = px8 ? (const void*)ego_costmap_window_kernel<8> : (const void*)ego_costmap_window_kernel<4>;
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
+            const dim3 grid((unsigned)std::min<int64_t>(n, (int64_t)std::max(per_cu, 1) * cus));
+            if (px8) hipLaunchKernelGGL((ego_costmap_window_kernel<8>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((ego_costmap_window_kernel<4>), grid, block, lds, st, a);
+            HIP_TRY(hipGetLastError());
+            return BCP_OK;
+        }
         const size_t lds = 4 * row_bytes + (a.stage_map ? map_bytes : 0);
         const void* fn = a.stage_map ? (px8 ? (const void*)ego_costmap_kernel<true, 8> : (const void*)ego_costmap_kernel<true, 4>)
                                      : (px8 ? (const void*)ego_costmap_kernel<false, 8> : (const void*)ego_costmap_kernel<false, 4>);
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
         const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)std::max(per_cu, 1) * cus));

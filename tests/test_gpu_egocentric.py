@@ -75,7 +75,8 @@ def test_g10_observation_from_reference_states(torch_cuda, name):
     np.testing.assert_allclose(vec[:, :, 0], g["goal_n_state"], rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("shared", [True, False], ids=["shared-map", "private-maps"])
+@pytest.mark.parametrize("shared", [True, False, "large", "medium"],
+                         ids=["shared-map", "private-maps", "large-shared-map", "medium-shared-map"])
 def test_random_poses_vs_oracle(torch_cuda, oracle, shared):
     """random poses (inside and far outside the map), several windows and border values, a costmap with arbitrary
     byte values; private maps of different shapes go through the global-memory gather"""
@@ -84,7 +85,10 @@ def test_random_poses_vs_oracle(torch_cuda, oracle, shared):
     rng = np.random.RandomState(8)
     n = 96
     res = 0.05
-    shapes = [(90, 70)] if shared else [(90, 70), (64, 101), (33, 47)]
+    large = shared in ("large", "medium")   # 168 KB: too big for LDS, each workgroup stages the part of the map its
+    medium = shared == "medium"             # window sees; 96 KB: staged whole in one big (> 64 KB) LDS allocation
+    shared = bool(shared)
+    shapes = [(330, 290)] if medium else [(420, 400)] if large else ([(90, 70)] if shared else [(90, 70), (64, 101), (33, 47)])
     maps = [rng.randint(0, 256, s).astype(np.uint8) for s in shapes]
     orgs = [rng.uniform(-2, 0, 2) for _ in shapes]
     path = np.array([[0., 0., 0.], [1., 0., 0.], [2., 0., 0.]])
@@ -93,7 +97,8 @@ def test_random_poses_vs_oracle(torch_cuda, oracle, shared):
         env = BatchedPlanEnv(CostMap2D(maps[0], res, orgs[0]), path, params, n_envs=n)
     else:
         env = BatchedPlanEnv([CostMap2D(maps[i % 3], res, orgs[i % 3]) for i in range(n)], [path] * n, params, n_envs=n)
-    poses = np.stack([rng.uniform(-4, 6, n), rng.uniform(-4, 6, n), rng.uniform(-7, 7, n)], axis=1)
+    hi = 23 if large else 6
+    poses = np.stack([rng.uniform(-4, hi, n), rng.uniform(-4, hi, n), rng.uniform(-7, 7, n)], axis=1)
     poses[0] = (0., 0., 0.)
     poses[1] = (1.0, 1.0, np.pi)
     pt = torch.from_numpy(poses).cuda()
