@@ -1244,7 +1244,7 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
     cus = std::max(cus, 1);
     const dim3 block(256);
-    if (!a.shared && map_bytes + 4 * row_bytes <= 60 * 1024 && n < ((int64_t)1 << 31)) {
+    if (!a.shared && map_bytes + 4 * row_bytes <= 150 * 1024 && n < ((int64_t)1 << 31)) {
         // private / pooled maps that fit LDS: group the images by map entry, then one workgroup per entry at a time
         const int64_t n_bins = n_slots(h);
         if (n_bins > h->ego_bins_cap) {
@@ -1272,6 +1272,8 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
         hipLaunchKernelGGL(ego_bin_scatter_kernel, per_image, block, 0, st, a.geom_of_env, a.n_envs, n, bin_start, rank, order);
         const size_t lds = map_bytes + 4 * row_bytes;
         const void* fn = px8 ? (const void*)ego_costmap_binned_kernel<8> : (const void*)ego_costmap_binned_kernel<4>;
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
         const dim3 grid((unsigned)std::min<int64_t>(n, (int64_t)std::max(per_cu, 1) * cus));

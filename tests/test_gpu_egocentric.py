@@ -88,7 +88,8 @@ def test_random_poses_vs_oracle(torch_cuda, oracle, shared):
     large = shared in ("large", "medium")   # 168 KB: too big for LDS, each workgroup stages the part of the map its
     medium = shared == "medium"             # window sees; 96 KB: staged whole in one big (> 64 KB) LDS allocation
     shared = bool(shared)
-    shapes = [(330, 290)] if medium else [(420, 400)] if large else ([(90, 70)] if shared else [(90, 70), (64, 101), (33, 47)])
+    shapes = [(330, 290)] if medium else [(420, 400)] if large else (
+        [(90, 70)] if shared else [(90, 70), (64, 101), (300, 260)])     # (the private 300 x 260 map needs > 64 KB of LDS)
     maps = [rng.randint(0, 256, s).astype(np.uint8) for s in shapes]
     orgs = [rng.uniform(-2, 0, 2) for _ in shapes]
     path = np.array([[0., 0., 0.], [1., 0., 0.], [2., 0., 0.]])
@@ -112,7 +113,7 @@ def test_random_poses_vs_oracle(torch_cuda, oracle, shared):
         shape = (C.c_int32 * 2)()
         _lib.check(env._lib.bcp_egocentric_shape(env._h, s.ctypes.data_as(f64p) if s is not None else None, shape))
         if size is None and not shared:
-            assert tuple(shape) == (90, 101)         # allocation shape of the padded private maps
+            assert tuple(shape) == (300, 260)        # allocation shape of the padded private maps
         out = torch.full((n, shape[0], shape[1]), 99, dtype=torch.uint8, device="cuda")
         guard = torch.full((16,), 123, dtype=torch.uint8, device="cuda")  # (allocated right after `out`, not adjacent)
         _lib.check(env._lib.bcp_egocentric_costmaps(env._h, pt.data_ptr(), n, o.ctypes.data_as(f64p) if o is not None else None,
