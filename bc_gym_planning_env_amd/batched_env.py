@@ -528,7 +528,7 @@ class BatchedPlanEnv(object):
             mask = mask.to(self.device).to(torch.uint8).contiguous()
             ptr = mask.data_ptr()
         _lib.check(self._lib.bcp_broadcast_state(self._h, int(src), ptr, self._stream()))
-        self._last_mask = mask
+        self._last_inputs = (mask,)   # keep the mask alive until the stream has consumed it
 
     def step(self, actions, noise_z=None, noise_z_out=None, done_out=None):
         """One tick for every env.  actions: [N,2] (float32 or float64) tensor / array, or a list of Action.
@@ -578,7 +578,7 @@ class BatchedPlanEnv(object):
         io = _lib.BcpStepIO()
         io.actions = a.data_ptr()
         flags = (_lib.STEP_ACTIONS_F32 if a.dtype == torch.float32 else 0) | (_lib.STEP_AUTO_RESET if self.auto_reset else 0)
-        flags |= getattr(self, "_debug_flags", 0)
+        flags |= getattr(self, "_debug_flags", 0)   # ablation switches of tools/ablate.py (timing experiments only)
         if noise_z is not None:
             io.noise_z = noise_z.data_ptr()
         io.reward, io.done = self.reward.data_ptr(), self.done.data_ptr()

@@ -1079,7 +1079,7 @@ extern "C" int bcp_time_step_kernels(bcp_handle* h, const bcp_step_io* io, uint3
     if (steps <= 0 || !kernel_ms) return fail(BCP_E_INVALID, "bcp_time_step_kernels: bad steps / output");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    // full steps first (the state advances), then the same number of step_kernel-only launches on the reached state:
+    // full steps first (the state advances), then the same number of kernel-1-only launches on the reached state:
     // envs parked by a lone step_kernel are never finished, so every launch of that loop sees the same batch.
     float full = 0, first = 0;
     rc = time_loop(h, io, flags, steps, s, false, &full);

@@ -247,9 +247,11 @@ int bcp_goal_direction_state(bcp_handle *h, const double *world_size /*host*/, d
  * returns the average kernel-launch duration in milliseconds (synchronises).  Used by bench.py for
  * roofline.achieved. */
 int bcp_time_steps(bcp_handle *h, const bcp_step_io *io, uint32_t flags, int32_t steps, void *stream, float *avg_ms);
-/* Per-kernel split of a step: kernel_ms[0] = average duration of step_kernel (a loop of step_kernel-only launches
- * between two events), kernel_ms[1] = average full step minus kernel_ms[0], i.e. step_pending_kernel plus the launch
- * boundary (0 when the step runs as a single kernel).  Advances the envs by `steps` steps. */
+/* Per-kernel split of a step: kernel_ms[0] = average duration of kernel 1 (a loop of launches of kernel 1 alone
+ * between two events), kernel_ms[1] = average full step minus kernel_ms[0], i.e. kernel 2 (step_pending_kernel) plus the
+ * launch boundary (0 when the step runs as a single kernel).  Advances the envs by `steps` steps.  Coarse: the
+ * kernel-1-only loop re-parks the same poses without settling them; profiles/ (rocprofv3 kernel trace) is the
+ * reference for per-kernel durations. */
 int bcp_time_step_kernels(bcp_handle *h, const bcp_step_io *io, uint32_t flags, int32_t steps, void *stream,
                           float *kernel_ms);
 
