@@ -323,8 +323,9 @@ __device__ __forceinline__ void fifo_delay(double* __restrict__ q, int delay, in
 }
 
 #ifdef BCP_DIAG
-__device__ unsigned long long g_diag[1024 * 8];
-#define DIAG_STAMP(k) do { if (threadIdx.x == 0) g_diag[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+constexpr int kDiagBlocks = 4096;   // stamps of the first kDiagBlocks workgroups of step_pending_kernel
+__device__ unsigned long long g_diag[kDiagBlocks * 8];
+#define DIAG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int bcp_diag_read(unsigned long long* out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(g_diag));

@@ -13,10 +13,11 @@ env.state.current_iter.copy_(torch.from_numpy(rng.randint(0,1200,65536).astype(n
 for k in range(1300): env.step(pool[k%16])
 torch.cuda.synchronize()
 L=_lib.load()
-buf=(C.c_ulonglong*(1024*8))()
+buf=(C.c_ulonglong*(4096*8))()
 L.bcp_diag_read.argtypes=[C.c_void_p]
 L.bcp_diag_read(buf)
-a=np.array(buf[:]).reshape(1024,8).astype(np.int64)
+a=np.array(buf[:]).reshape(4096,8).astype(np.int64)
+a=a[a[:,0]>0]   # workgroups that ran
 work=a[:,1]>a[:,0]
 t0=a[:,0].min()
 print('blocks with work', work.sum())
