@@ -100,6 +100,31 @@ def aux_measurements(env, pool, n):
         "roofline": {"bound": "hbm", "achieved": img_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": img_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "step_plus_observation_ms": ms_both, "env_steps_per_s_with_observation": n / (ms_both * 1e-3)}
+    del wrap
+    # a fresh world per episode: RandomMiniEnv.reset() as a device-side walk through a pool of pre-sampled geometries
+    import time as _time
+    from bc_gym_planning_env_amd import mini_env
+    t0 = _time.perf_counter()
+    worlds = mini_env.sample_pool(None, list(range(512)), 4, device=env.device.index or 0)
+    t_pool = _time.perf_counter() - t0
+    penv = mini_env.BatchedRandomMiniEnv(n, pool=worlds, auto_reset=True, seed=3, device=env.device.index or 0)
+    rng = np.random.RandomState(7)
+    penv.state.current_iter.copy_(torch.from_numpy(rng.randint(0, penv.params.iteration_timeout, n).astype(np.int32)).to(env.device))
+    for k in range(penv.params.iteration_timeout):
+        penv.step(pool[k % 16])
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for k in range(100):
+        penv.step(pool[k % 16])
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms_pool = e0.elapsed_time(e1) / 100
+    out["geometry_pool"] = {
+        "what": "RandomMiniEnv with draw_new_turn_on_reset: %d envs over %d pre-sampled worlds (%d chains x %d), every "
+                "reset moves the env to its chain's next world inside the step kernel" % (n, len(worlds), 512, 4),
+        "ms_per_step": ms_pool, "env_steps_per_s": n / (ms_pool * 1e-3),
+        "episodes_ending_per_step": float(penv.done.float().sum()),
+        "host_sampling_worlds_per_s": len(worlds) / t_pool}
     return out
 
 
