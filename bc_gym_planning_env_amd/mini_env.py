@@ -62,8 +62,9 @@ class SpaceSeemsEmptyError(Exception):
 
 
 def _wrap(z):
-    # normalize_angle, utilities/coordinate_transformations.py:28-36
-    return (np.array(z) + np.pi) % _TWO_PI - np.pi
+    # normalize_angle, utilities/coordinate_transformations.py:28-36 (float64 scalars: the same three IEEE operations
+    # as on the reference's 0-d arrays, without building arrays)
+    return (np.float64(z) + np.pi) % _TWO_PI - np.pi
 
 
 def _pose(x, y, theta):
@@ -75,25 +76,26 @@ class _Wedge(object):
     """The angular sector behind the corner obstacle, seen from its apex (not_inside_obstacle, mini_env.py:199-208)."""
 
     def __init__(self, apex, first, width):
-        self.apex, self.first, self.last = apex, first, first + width
+        self.ax, self.ay = np.float64(apex[0]), np.float64(apex[1])
+        self.first, self.last = first, first + width
 
     def clear_of(self, x, y):
-        phi = _wrap(np.arctan2(y - self.apex[1], x - self.apex[0]))  # cart2pol, coordinate_transformations.py:124-135
-        for turn in (0.0, _TWO_PI):
-            if self.first <= phi + turn <= self.last:
-                return False
-        return True
+        phi = _wrap(np.arctan2(y - self.ay, x - self.ax))  # cart2pol, coordinate_transformations.py:124-135
+        if self.first <= phi <= self.last:
+            return False
+        return not (self.first <= phi + _TWO_PI <= self.last)
 
 
 def _ends_on_circle(rng, p, wedge):
     # _sample_pose_circ (mini_env.py:146-180): two antipodal points of a circle, both heading start -> end
+    radius = min((p.inner_w + p.inner_h) / 4. + p.mid_margin, p.lim_euc_dist)
+    uniform, cos, sin = rng.uniform, np.cos, np.sin
     for _ in range(_MAX_TRIES):
-        radius = min((p.inner_w + p.inner_h) / 4. + p.mid_margin, p.lim_euc_dist)
-        phi = rng.uniform(0, _TWO_PI)
-        x, y = radius * np.cos(phi), radius * np.sin(phi)
-        rng.uniform(0, _TWO_PI)  # the reference draws a heading here and then overwrites it
-        heading = np.arctan2(-y - y, -x - x)
+        phi = uniform(0, _TWO_PI)
+        x, y = radius * cos(phi), radius * sin(phi)
+        uniform(0, _TWO_PI)  # the reference draws a heading here and then overwrites it
         if wedge.clear_of(x, y) and wedge.clear_of(-x, -y):
+            heading = np.arctan2(-y - y, -x - x)
             return _pose(x, y, heading), _pose(-x, -y, heading)
     raise SpaceSeemsEmptyError()
 
