@@ -19,6 +19,7 @@ import torch
 
 from . import _lib, robots
 from .api import CostMap2D, EnvParams
+from .batched_env import BatchedPlanEnv
 
 _TWO_PI = 2 * np.pi
 _MAX_TRIES = 1000
@@ -352,27 +353,22 @@ def sample_pool(params=None, seeds=(0,), episodes=1, device=0, collider=None):
     return MiniEnvPool(params, seeds, episodes, [m for c in chains for m in c.accepted])
 
 
-def _batched_plan_env():
-    from .batched_env import BatchedPlanEnv   # (imported late: batched_env does not need this module)
-    return BatchedPlanEnv
-
-
-class BatchedRandomMiniEnv(object):
+class BatchedRandomMiniEnv(BatchedPlanEnv):
     """N RandomMiniEnv instances (envs/mini_env.py:408-494) on one GPU: a BatchedPlanEnv in geometry-pool mode.
 
     Env i follows chain i % n_chains of the pool, starting (i // n_chains) % episodes entries into it, so replicas of a
-    chain are out of phase.  With one chain per env and seeds[i] = s_i, env i sees exactly the worlds
-    `RandomMiniEnv(seed=s_i)` sees for its first `episodes` resets (then the chain wraps around).  As in the
-    reference, construction leaves the env on world 0 of its chain and the first reset() moves it to world 1 --
-    BatchedPlanEnv's constructor already ends with that reset().
+    chain are out of phase (and the undecided poses of a world spread over many wavefronts).  With one chain per env and
+    seeds[i] = s_i, env i sees exactly the worlds `RandomMiniEnv(seed=s_i)` sees for its first `episodes` resets (then
+    the chain wraps around).  As in the reference, construction leaves the env on world 0 of its chain and the first
+    reset() moves it to world 1 -- BatchedPlanEnv's constructor already ends with that reset().
 
     :param pool MiniEnvPool: pre-sampled worlds, or None to sample `n_chains` x `episodes` here
     :param draw_new_turn_on_reset bool: False keeps every env on its first world (RandomMiniEnv's flag of that name)
     Remaining keyword arguments go to BatchedPlanEnv (auto_reset, seed, noise_parameters, env_id_base, ...).
     """
 
-    def __new__(cls, n_envs, params=None, pool=None, seeds=None, n_chains=None, episodes=4, device=0,
-                draw_new_turn_on_reset=True, **kw):
+    def __init__(self, n_envs, params=None, pool=None, seeds=None, n_chains=None, episodes=4, device=0,
+                 draw_new_turn_on_reset=True, **kw):
         params = default_random_mini_env_params() if params is None else params
         if pool is None:
             if seeds is None:
@@ -381,7 +377,7 @@ class BatchedRandomMiniEnv(object):
         chains, per = len(pool.seeds), pool.episodes
         i = np.arange(int(n_envs))
         geom = (i % chains) * per + (i // chains) % per
-        env = _batched_plan_env()(pool.costmaps, pool.paths, params.env_params, n_envs=n_envs, device=device,
-                                  geom_of_env=geom, next_geom=pool.next_geom if draw_new_turn_on_reset else None, **kw)
-        env.pool = pool
-        return env
+        self.pool = pool
+        super(BatchedRandomMiniEnv, self).__init__(
+            pool.costmaps, pool.paths, params.env_params, n_envs=n_envs, device=device, geom_of_env=geom,
+            next_geom=pool.next_geom if draw_new_turn_on_reset else None, **kw)
