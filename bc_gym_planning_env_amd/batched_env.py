@@ -146,15 +146,34 @@ class EnvView(object):
                      robot_state=self._robot_state(seen))
 
     def set_state(self, state):
+        """PlanEnv.set_state (env.py:278-285) for this env: like the reference, the robot takes over
+        `state.robot_state` (with a state delay that is the delayed state -- the reference does the same)."""
         e, i = self._env, self._i
-        rs = state.robot_state
-        col = [rs.x, rs.y, rs.angle, rs.v, rs.w, getattr(rs, "steering_motor_command", 0.0),
-               getattr(rs, "wheel_angle", 0.0)]
-        e.state.robot[:, i] = torch.tensor(col, dtype=torch.float64)
-        e.state.min_spat_dist_so_far[i] = state.reward_provider_state.min_spat_dist_so_far
-        e.state.target_idx[i] = state.reward_provider_state.target_idx
-        e.state.current_iter[i] = state.current_iter
-        e.state.robot_collided[i] = int(state.robot_collided)
+        s = e.state
+
+        def vec(rs):
+            return [rs.x, rs.y, rs.angle, rs.v, rs.w, getattr(rs, "steering_motor_command", 0.0),
+                    getattr(rs, "wheel_angle", 0.0)]
+
+        s.robot[:, i] = torch.tensor(vec(state.robot_state), dtype=torch.float64)
+        s.min_spat_dist_so_far[i] = state.reward_provider_state.min_spat_dist_so_far
+        s.target_idx[i] = state.reward_provider_state.target_idx
+        s.current_iter[i] = state.current_iter
+        s.robot_collided[i] = int(state.robot_collided)
+        if s.pose_seen is not None:
+            s.pose_seen[:, i] = torch.tensor(np.asarray(state.pose, dtype=np.float64))
+        if s.robot_state_seen is not None:
+            s.robot_state_seen[:, i] = torch.tensor(vec(state.robot_state), dtype=torch.float64)
+        it = int(state.current_iter)
+        for q, items in ((s.poses_queue, [np.asarray(p, dtype=np.float64) for p in state.poses_queue]),
+                         (s.robot_state_queue, [np.array(vec(r)) for r in state.robot_state_queue]),
+                         (s.control_queue, [np.asarray(a.command, dtype=np.float64) for a in state.control_queue])):
+            if q is None:
+                continue
+            d = q.shape[0]
+            # the list holds pushes it - len + 1 .. it (oldest first); push k lives in slot (k - 1) % d
+            for k, item in zip(range(it - len(items) + 1, it + 1), items):
+                q[(k - 1) % d, :, i] = torch.tensor(item)
 
     def observation(self):
         s = self.get_state()

@@ -111,3 +111,26 @@ def test_done_out_ring(torch_cuda):
         assert d_b.data_ptr() == ring[t % 4].data_ptr()
         assert (d_a == ring[t % 4]).all()
     assert int(ring[1].sum()) == n      # step 6 (t = 5) timed every env out
+
+
+def test_per_env_state_round_trip_with_delays(torch_cuda):
+    """envs[i].set_state(envs[j].get_state()) transplants one env's full State (queues included): both envs then
+    evolve identically under identical inputs"""
+    torch = torch_cuda
+    n = 8
+    env = _env(torch, n, control_delay=2, pose_delay=3, state_delay=1)
+    rng = np.random.RandomState(4)
+    for t in range(9):
+        env.step(env.action_space.sample_batch(n, rng), noise_z=rng.normal(size=(n, 3)))
+    s5 = env.envs[5].get_state()
+    true5 = env.state.robot[:, 5].clone()
+    env.envs[2].set_state(s5)
+    env.state.robot[:, 2] = true5        # (the robot's undelayed state is not part of State; see EnvView.set_state)
+    assert env.envs[2].get_state() == s5
+    for t in range(12):
+        a = env.action_space.sample_batch(n, rng)
+        z = rng.normal(size=(n, 3))
+        a[2], z[2] = a[5], z[5]
+        obs, rew, done, _ = env.step(a, noise_z=z)
+        assert (env.state.robot[:, 2] == env.state.robot[:, 5]).all()
+        assert (obs.pose[:, 2] == obs.pose[:, 5]).all() and rew[2] == rew[5] and done[2] == done[5]
