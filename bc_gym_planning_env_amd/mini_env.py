@@ -65,7 +65,7 @@ class SpaceSeemsEmptyError(Exception):
 def _wrap(z):
     # normalize_angle, utilities/coordinate_transformations.py:28-36 (float64 scalars: the same three IEEE operations
     # as on the reference's 0-d arrays, without building arrays)
-    return (np.float64(z) + np.pi) % _TWO_PI - np.pi
+    return (np.asarray(z, dtype=np.float64)[()] + np.pi) % _TWO_PI - np.pi
 
 
 def _pose(x, y, theta):
@@ -86,18 +86,33 @@ class _Wedge(object):
             return False
         return not (self.first <= phi + _TWO_PI <= self.last)
 
+    def clear_of_many(self, x, y):
+        phi = _wrap(np.arctan2(y - self.ay, x - self.ax))
+        inside = ((self.first <= phi) & (phi <= self.last)) | ((self.first <= phi + _TWO_PI) & (phi + _TWO_PI <= self.last))
+        return ~inside
+
 
 def _ends_on_circle(rng, p, wedge):
-    # _sample_pose_circ (mini_env.py:146-180): two antipodal points of a circle, both heading start -> end
+    # _sample_pose_circ (mini_env.py:146-180): two antipodal points of a circle, both heading start -> end.
+    # The reference tries up to 1000 (phi, unused heading) pairs one by one; here they are drawn and tested a chunk at a
+    # time -- RandomState.uniform(size=n) yields the same stream as n scalar calls -- and the generator is then wound
+    # back to just after the pair that was accepted, so the stream continues exactly where the reference's would.
     radius = min((p.inner_w + p.inner_h) / 4. + p.mid_margin, p.lim_euc_dist)
-    uniform, cos, sin = rng.uniform, np.cos, np.sin
-    for _ in range(_MAX_TRIES):
-        phi = uniform(0, _TWO_PI)
-        x, y = radius * cos(phi), radius * sin(phi)
-        uniform(0, _TWO_PI)  # the reference draws a heading here and then overwrites it
-        if wedge.clear_of(x, y) and wedge.clear_of(-x, -y):
-            heading = np.arctan2(-y - y, -x - x)
-            return _pose(x, y, heading), _pose(-x, -y, heading)
+    done = 0
+    while done < _MAX_TRIES:
+        chunk = min(8 if done == 0 else 128, _MAX_TRIES - done)
+        before = rng.get_state()
+        phi = rng.uniform(0, _TWO_PI, size=2 * chunk)[0::2]
+        x, y = radius * np.cos(phi), radius * np.sin(phi)
+        ok = wedge.clear_of_many(x, y) & wedge.clear_of_many(-x, -y)
+        if ok.any():
+            k = int(np.argmax(ok))
+            rng.set_state(before)
+            rng.uniform(0, _TWO_PI, size=2 * (k + 1))
+            xk, yk = x[k], y[k]
+            heading = np.arctan2(-yk - yk, -xk - xk)
+            return _pose(xk, yk, heading), _pose(-xk, -yk, heading)
+        done += chunk
     raise SpaceSeemsEmptyError()
 
 
@@ -219,11 +234,18 @@ def add_wall(costmap, p0, p1, width=0.05, cost=CostMap2D.LETHAL_OBSTACLE):
     draw_line(costmap.get_data(), _to_pixel(p0, org, res), _to_pixel(p1, org, res), cost)
 
 
-def prepare_map_and_path(mp):
-    """-> (CostMap2D with the two walls, coarse path [2, 3]) for one sampled world (mini_env.py:362-388)."""
+def map_shape(h, w, resolution):
+    """(rows, cols) of CostMap2D.create_empty(world_size=(h, w), resolution) (utilities/costmap_2d.py:58-69)"""
+    size = _to_pixel(np.array([h, w], dtype=np.float64), np.zeros(2), resolution)
+    return int(size[1]), int(size[0])
+
+
+def prepare_map_and_path(mp, out=None):
+    """-> (CostMap2D with the two walls, coarse path [2, 3]) for one sampled world (mini_env.py:362-388).
+    `out`: optional zeroed uint8 array of the map's shape to draw into (a row of a batch buffer)."""
     res = mp.env_params.resolution
-    size = _to_pixel(np.array([mp.h, mp.w], dtype=np.float64), np.zeros(2), res)      # CostMap2D.create_empty
-    costmap = CostMap2D(np.zeros(tuple(size[::-1]), dtype=np.uint8), res, np.array([-mp.h / 2., -mp.w / 2.]))
+    data = np.zeros(map_shape(mp.h, mp.w, res), dtype=np.uint8) if out is None else out
+    costmap = CostMap2D(data, res, np.array([-mp.h / 2., -mp.w / 2.]))
     add_wall(costmap, mp.obstacle_o, mp.obstacle_a)
     add_wall(costmap, mp.obstacle_o, mp.obstacle_b)
     return costmap, np.array([mp.start_pos, mp.end_pos])
@@ -245,19 +267,24 @@ class PoseCollider(object):
         _lib.check(self._lib.bcp_create(C.byref(self._p), self.capacity, self.device.index or 0, 0, C.byref(self._h)))
         self.resolution = float(env_params.resolution)
 
-    def __call__(self, costmaps, paths):
-        """costmaps: list of K <= capacity CostMap2D of one shape; paths: list of K [2,3] -> bool [K, 2]."""
+    def __call__(self, costmaps, paths, batch=None):
+        """costmaps: list of K <= capacity CostMap2D of one shape; paths: list of K [2,3] -> bool [K, 2].
+        batch: optionally the K maps as one contiguous uint8 [K, rows, cols] array (saves the stacking)."""
         k, cap = len(costmaps), self.capacity
         rows, cols = costmaps[0].get_data().shape
-        data = np.zeros((cap, rows, cols), dtype=np.uint8)
+        if batch is None:
+            batch = np.stack([c.get_data() for c in costmaps])
         origins = np.zeros((cap, 2), dtype=np.float64)
         poses = np.zeros((2, cap, 3), dtype=np.float64)
         for j in range(k):
-            data[j] = costmaps[j].get_data()
             origins[j] = costmaps[j].get_origin()
             poses[:, j] = paths[j]
         dev = self.device
-        d, o, p = torch.from_numpy(data).to(dev), torch.from_numpy(origins).to(dev), torch.from_numpy(poses).to(dev)
+        if getattr(self, "_maps", None) is None or tuple(self._maps.shape[1:]) != (rows, cols):
+            self._maps = torch.zeros((cap, rows, cols), dtype=torch.uint8, device=dev)   # rows >= k keep stale maps:
+        d = self._maps                                                                   # their poses are ignored
+        d[:k].copy_(torch.from_numpy(np.ascontiguousarray(batch)))
+        o, p = torch.from_numpy(origins).to(dev), torch.from_numpy(poses).to(dev)
         out = torch.empty(2 * cap, dtype=torch.uint8, device=dev)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(self._lib.bcp_set_costmaps(self._h, d.data_ptr(), rows, cols, 0, None, None, o.data_ptr(), 1,
@@ -286,7 +313,8 @@ class _Chain(object):
         if seed is not None:
             self.rng.seed(seed)
         self.tries = 0
-        self.accepted = []
+        self.accepted = []   # MiniEnvParams of the accepted worlds ...
+        self.built = []      # ... and their (costmap, coarse path)
 
     def propose(self, params):
         while self.tries < _MAX_TRIES:
@@ -309,10 +337,11 @@ class MiniEnvPool(object):
     """n_chains x episodes pre-sampled worlds.  Entry c * episodes + k is the k-th world of chain c; `next_geom`
     walks a chain and wraps around at its end."""
 
-    def __init__(self, params, seeds, episodes, worlds):
+    def __init__(self, params, seeds, episodes, worlds, built=None):
         self.params, self.seeds, self.episodes = params, list(seeds), int(episodes)
         self.worlds = worlds                                        # list of MiniEnvParams, chain-major
-        built = [prepare_map_and_path(w) for w in worlds]
+        if built is None:
+            built = [prepare_map_and_path(w) for w in worlds]
         self.costmaps = [b[0] for b in built]
         self.paths = [b[1] for b in built]
         g = np.arange(len(worlds), dtype=np.int32)
@@ -340,17 +369,20 @@ def sample_pool(params=None, seeds=(0,), episodes=1, device=0, collider=None):
         while todo:
             batch = todo[:collider.capacity]
             cands = [c.propose(params) for c in batch]
-            built = [prepare_map_and_path(m) for m in cands]
-            hits = collider([b[0] for b in built], [b[1] for b in built])
-            for c, m, (_, path), hit in zip(batch, cands, built, hits):
+            maps = np.zeros((len(cands),) + map_shape(cands[0].h, cands[0].w, params.env_params.resolution), dtype=np.uint8)
+            built = [prepare_map_and_path(m, out=maps[j]) for j, m in enumerate(cands)]
+            hits = collider([b[0] for b in built], [b[1] for b in built], batch=maps)
+            for c, m, (costmap, path), hit in zip(batch, cands, built, hits):
                 if not hit.any() and not _too_close(path, params.env_params):
                     c.accepted.append(m)
+                    c.built.append((costmap.copy(), path))   # (own memory: `maps` is this round's scratch)
                     c.tries = 0
             todo = [c for c in chains if len(c.accepted) < episodes]
     finally:
         if own:
             collider.close()
-    return MiniEnvPool(params, seeds, episodes, [m for c in chains for m in c.accepted])
+    return MiniEnvPool(params, seeds, episodes, [m for c in chains for m in c.accepted],
+                       built=[b for c in chains for b in c.built])
 
 
 class BatchedRandomMiniEnv(BatchedPlanEnv):

@@ -19,7 +19,7 @@ class OracleCollider(object):
     def __init__(self, env_params):
         self.verts = O.TRICYCLE_FOOTPRINT if env_params.robot_name == 'industrial_tricycle_v1' else O.DIFFDRIVE_FOOTPRINT
 
-    def __call__(self, costmaps, paths):
+    def __call__(self, costmaps, paths, batch=None):
         return np.array([[O.pose_collides(p[0], p[1], p[2], self.verts, c.get_data(), c.get_origin(), c.get_resolution())
                           for p in path] for c, path in zip(costmaps, paths)], dtype=bool)
 
