@@ -167,27 +167,36 @@ __device__ __forceinline__ EgoImage ego_broadcast(const EgoXform& T, int k)
 }
 
 // LDS copy of one costmap with a one-cell ring of the border value.  Whole workgroup; ends with a barrier.
-// The map is fetched as aligned dwords, eight independent loads in flight per thread (a cold map costs a few memory
-// round trips instead of one per row), and scattered into the ringed layout byte by byte.
+// The map is fetched as aligned dwords, sixteen independent loads in flight per thread -- a cold map (pool entries come
+// from HBM) then costs two or three memory round trips, the first of them hidden behind the border fill -- and is
+// scattered into the ringed layout byte by byte.
 __device__ __forceinline__ void ego_stage_map(const EgoArgs& a, const uint8_t* __restrict__ src, int vr, int vc, LdsU8 lmap,
                                               int pitch, int map_bytes)
 {
-    __attribute__((address_space(3))) uint32_t* l32 = (__attribute__((address_space(3))) uint32_t*)lmap;
-    for (int k = threadIdx.x; k < map_bytes / 4; k += 256) l32[k] = (uint32_t)a.border * 0x01010101u;
-    __syncthreads();
+    constexpr int kInFlight = 16;
     const int total = a.rows * a.cols;
     const int off = (int)((uintptr_t)src & 3);   // the map entry need not start on a dword boundary
     const uint32_t* __restrict__ w32 = reinterpret_cast<const uint32_t*>(src - off);
     const int n_words = (off + total + 3) >> 2;
-    for (int w0 = threadIdx.x; w0 < n_words; w0 += 8 * 256) {
-        uint32_t v[8];
+    uint32_t v[kInFlight];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int w = w0 + u * 256;
-            v[u] = w < n_words ? w32[w] : 0u;
+    for (int u = 0; u < kInFlight; ++u) {   // first batch: issued before the fill
+        const int w = threadIdx.x + u * 256;
+        v[u] = w < n_words ? w32[w] : 0u;
+    }
+    __attribute__((address_space(3))) uint32_t* l32 = (__attribute__((address_space(3))) uint32_t*)lmap;
+    for (int k = threadIdx.x; k < map_bytes / 4; k += 256) l32[k] = (uint32_t)a.border * 0x01010101u;
+    __syncthreads();
+    for (int w0 = threadIdx.x; w0 < n_words; w0 += kInFlight * 256) {
+        if (w0 != (int)threadIdx.x) {
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) {
+                const int w = w0 + u * 256;
+                v[u] = w < n_words ? w32[w] : 0u;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kInFlight; ++u) {
             const int w = w0 + u * 256;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
