@@ -220,6 +220,22 @@ __device__ __forceinline__ PathWindow path_window(const DevParams& P, BoxPtr bbo
     return w;
 }
 
+// one candidate way point (its five values already in registers) against the three reach conditions of
+// path_tools.py:419-427; they are independent predicates, so the cheap ones go first
+__device__ __forceinline__ bool way_point_reached(const DevParams& P, double sx, double sy, double sth, double sc, double ss,
+                                                  double x, double y, double th)
+{
+    const double dx = sx - x, dy = sy - y;
+    if (fabs(dx) > P.sp_prune || fabs(dy) > P.sp_prune) return false;   // then hypot(dx,dy) >= sp
+    const double par = sc * (x - sx) + ss * (y - sy);                   // path_tools.py:405
+    if (!(par >= P.par_thr)) return false;
+    const double q = dx * dx + dy * dy;
+    bool near = q < P.sp2_lo;
+    if (!near && q <= P.sp2_hi) near = hypot(dx, dy) < P.sp;            // too close to call from q
+    return near && fabs(normalize_angle(th - sth)) < P.ap;
+}
+
+// way points in LDS (shared path): one candidate at a time, first hit from the top wins
 template <typename PathPtr>
 __device__ __forceinline__ int last_reached_from(const DevParams& P, PathPtr path, PathWindow w, int m, int target,
                                                  double x, double y, double th)
@@ -230,22 +246,34 @@ __device__ __forceinline__ int last_reached_from(const DevParams& P, PathPtr pat
     for (int j = hi; j >= lo; --j) {
         const PathPtr s = path + 5 * j;
         // all five values of the way point are fetched up front (one latency instead of three dependent ones)
-        const double sx = s[0], sy = s[1], sth = s[2], sc = s[3], ss = s[4];
-        const double dx = sx - x, dy = sy - y;
-        // the three reach conditions are independent predicates; evaluate the cheap ones first
-        if (fabs(dx) > P.sp_prune || fabs(dy) > P.sp_prune) continue;   // then hypot(dx,dy) >= sp
-        const double par = sc * (x - sx) + ss * (y - sy);               // path_tools.py:405
-        if (!(par >= P.par_thr)) continue;
-        const double q = dx * dx + dy * dy;
-        bool near = q < P.sp2_lo;
-        if (!near && q <= P.sp2_hi) near = hypot(dx, dy) < P.sp;        // too close to call from q
-        if (!near) continue;
-        if (fabs(normalize_angle(th - sth)) < P.ap) return j;
+        if (way_point_reached(P, s[0], s[1], s[2], s[3], s[4], x, y, th)) return j;
     }
     return -1;
 }
 
-// ContinuousRewardProvider.reward (envs/base/reward.py:214-259)
+// way points in global memory (private / pooled paths, cold after the kernel boundary): four candidates are fetched
+// together, so the scan pays one memory round trip per four way points instead of one each
+__device__ __forceinline__ int last_reached_from(const DevParams& P, const double* __restrict__ path, PathWindow w, int m,
+                                                 int target, double x, double y, double th)
+{
+    if (target > m - 1) return -1;
+    const int lo = max(w.lo, target);
+    const int hi = min(w.hi, m - 1);
+    for (int j = hi; j >= lo; j -= 4) {
+        double v[4][5];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double* s = path + 5 * max(j - u, lo);   // (below lo: a harmless repeat of way point lo)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[u][k] = s[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j - u >= lo && way_point_reached(P, v[u][0], v[u][1], v[u][2], v[u][3], v[u][4], x, y, th)) return j - u;
+    }
+    return -1;
+}
+
 template <typename PathPtr>
 __device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path, PathWindow w, int m, double x, double y,
                                               double th, double& min_dist, int& target)
