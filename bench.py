@@ -249,7 +249,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g)
         if world == 1 and not args.no_aux:
-            out["aux"] = aux_measurements(env, pool, n)
+            try:  # informational only: never let it cost the metric line
+                out["aux"] = aux_measurements(env, pool, n)
+            except Exception as exc:  # noqa: BLE001
+                out["aux"] = {"error": repr(exc)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
