@@ -63,9 +63,17 @@ def cpu_baseline(g, envs=16384, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt >= budget_s or steps >= 2000:
             break
+    # the same on ONE core, for a per-core figure (about 3 s)
+    one = 0
+    t1 = time.perf_counter()
+    while time.perf_counter() - t1 < 3.0:
+        ref.step(acts[one % 4], zs[one % 4], auto_reset=True, threads=1)
+        one += 1
+    dt1 = time.perf_counter() - t1
     return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": "%d envs x %d steps of the same workload (C oracle restatement, %d threads, %.1f s)"
-                      % (envs, steps, threads, dt)}
+                      % (envs, steps, threads, dt),
+            "single_core_value": envs * one / dt1}
 
 
 def aux_measurements(env, pool, n):
