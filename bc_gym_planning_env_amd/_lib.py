@@ -47,6 +47,12 @@ class BcpState(C.Structure):
     ]
 
 
+class BcpMiniWorldParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in (
+        "inner_h", "inner_w", "mid_margin", "out_margin", "min_obstacle_angle", "max_obstacle_angle", "lim_euc_dist",
+        "lim_ang_dist", "angular_pose_noise_scale", "resolution", "goal_spat_dist", "goal_ang_dist")]
+
+
 class BcpStepIO(C.Structure):
     _fields_ = [
         ("actions", C.c_void_p), ("noise_z", C.c_void_p), ("noise_z_out", C.c_void_p), ("reward", C.c_void_p),
@@ -83,6 +89,9 @@ SYMBOLS = {
                                           C.c_void_p]),
     "bcp_goal_n_state": (C.c_int, [_H, _f64p, C.c_void_p, C.c_void_p]),
     "bcp_goal_direction_state": (C.c_int, [_H, _f64p, C.c_void_p, C.c_void_p]),
+    "bcp_mini_world_seed": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bcp_sample_mini_worlds": (C.c_int, [_H, C.POINTER(BcpMiniWorldParams), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcp_time_step_kernels": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p,
                                         C.POINTER(C.c_float)]),
     "bcp_time_steps": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]),

@@ -4,7 +4,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bcplan.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("bcp_device.h", "bcp_raster.h", "bcp_coop.h", "bcp_step.h", "bcp_ego.h")] + \
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("bcp_device.h", "bcp_raster.h", "bcp_coop.h", "bcp_step.h", "bcp_ego.h", "bcp_sample.h")] + \
        [os.path.join(os.path.dirname(HERE), "include", "bcplan.h")]
 OUT = os.path.join(HERE, "libbcplan.so")
 

@@ -155,6 +155,14 @@ __device__ __forceinline__ double bcast_d(double v, int src)
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
+// orders the LDS accesses of the lanes of ONE wavefront (a lane reads what another lane of the same wave wrote)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // bits [pos, 32*NW) of an NW-word row mask, word w
 __device__ __forceinline__ uint32_t suffix_word(int pos, int w)
 {

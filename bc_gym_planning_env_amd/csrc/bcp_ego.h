@@ -297,12 +297,6 @@ __device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, 
     }
 }
 
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // One WAVEFRONT per image, persistent workgroups of 4 waves that stage a shared costmap in LDS once and then walk
 // over images.

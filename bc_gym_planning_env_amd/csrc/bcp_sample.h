@@ -1,0 +1,347 @@
+// bcp_sample.h -- RandomMiniEnv worlds sampled on the device ("true on-device sampling"):
+// _sample_mini_env_params (envs/mini_env.py:328-359) -- rejection sampling of an obstacle wedge and a start / end pose
+// (:269-325), the two walls (envs/base/maps.py:28-44 -> cv2.line), and the acceptance test (pose_collides of both path
+// ends, not too close to each other) -- with one WAVEFRONT per independent numpy RandomState stream:
+//   * lane 0 runs the generator (MT19937 exactly as numpy's legacy RandomState: same seeding, same 53-bit doubles, the
+//     same draw order as the reference) and the scalar geometry,
+//   * all 64 lanes clear the candidate's lethal bitmap in LDS, test both path ends against it with the cooperative
+//     rasteriser of the step kernels, and expand an accepted world's bitmap into its uint8 costmap.
+// Included by bcplan.hip (entry points bcp_mini_world_seed, bcp_sample_mini_worlds).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "bcp_device.h"
+#include "bcp_coop.h"
+
+namespace bcp {
+
+constexpr int kMtWords = 624;          // MT19937 state; word kMtWords of a chain's record is the position
+constexpr int kMtRecord = kMtWords + 1;
+
+struct MiniWorldParams {   // RandomMiniEnvParams (envs/mini_env.py:30-47) + the EnvParams fields the sampler reads
+    double inner_h, inner_w, mid_margin, out_margin;
+    double min_obstacle_angle, max_obstacle_angle;
+    double lim_euc_dist, lim_ang_dist, angular_pose_noise_scale;
+    double resolution, goal_spat_dist, goal_ang_dist;
+};
+
+typedef __attribute__((address_space(3))) uint32_t* MtLds;
+
+// ---- numpy.random.RandomState (legacy MT19937) -----------------------------------------------------------------
+// mt19937_seed(state, seed): init_genrand
+__global__ void mt_seed_kernel(const int64_t* __restrict__ seeds, int64_t n_chains, uint32_t* __restrict__ state)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chains) return;
+    uint32_t* key = state + c * kMtRecord;
+    uint32_t seed = (uint32_t)((uint64_t)seeds[c] & 0xffffffffull);
+    for (int pos = 0; pos < kMtWords; ++pos) {
+        key[pos] = seed;
+        seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)pos + 1u;
+    }
+    key[kMtWords] = kMtWords;   // position: the first draw regenerates the block
+}
+
+// rk_random: one tempered 32-bit output (one lane runs this)
+__device__ __forceinline__ uint32_t mt_next(MtLds key)
+{
+    uint32_t pos = key[kMtWords];
+    if (pos >= (uint32_t)kMtWords) {   // genrand block update
+        constexpr uint32_t kUpper = 0x80000000u, kLower = 0x7fffffffu, kMatrix = 0x9908b0dfu;
+        int i = 0;
+        for (; i < kMtWords - 397; ++i) {
+            const uint32_t y = (key[i] & kUpper) | (key[i + 1] & kLower);
+            key[i] = key[i + 397] ^ (y >> 1) ^ ((y & 1u) ? kMatrix : 0u);
+        }
+        for (; i < kMtWords - 1; ++i) {
+            const uint32_t y = (key[i] & kUpper) | (key[i + 1] & kLower);
+            key[i] = key[i + (397 - kMtWords)] ^ (y >> 1) ^ ((y & 1u) ? kMatrix : 0u);
+        }
+        const uint32_t y = (key[kMtWords - 1] & kUpper) | (key[0] & kLower);
+        key[kMtWords - 1] = key[396] ^ (y >> 1) ^ ((y & 1u) ? kMatrix : 0u);
+        pos = 0;
+    }
+    uint32_t y = key[pos];
+    key[kMtWords] = pos + 1;
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// rk_double: 53-bit double in [0, 1) from two outputs; RandomState.random_sample() / .rand()
+__device__ __forceinline__ double mt_double(MtLds key)
+{
+    const uint32_t a = mt_next(key) >> 5, b = mt_next(key) >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+
+// RandomState.uniform(low, high) = low + (high - low) * random_sample()
+__device__ __forceinline__ double mt_uniform(MtLds key, double low, double high) { return low + (high - low) * mt_double(key); }
+
+// ---- geometry (lane 0) --------------------------------------------------------------------------------------------
+struct MiniWorld {   // MiniEnvParams (envs/mini_env.py:79-92)
+    double start[3], end[3], a[2], o[2], b[2], h, w;
+};
+
+struct Wedge {   // not_inside_obstacle (envs/mini_env.py:199-208)
+    double ax, ay, first, last;
+    __device__ __forceinline__ bool clear_of(double x, double y) const
+    {
+        const double phi = normalize_angle(atan2(y - ay, x - ax));   // cart2pol, coordinate_transformations.py:124-135
+        if (first <= phi && phi <= last) return false;
+        return !(first <= phi + kTwoPi && phi + kTwoPi <= last);
+    }
+};
+
+enum { kDrawOk = 0, kDrawEmpty = 1 /* SpaceSeemsEmptyError: redraw the obstacle */, kDrawFail = 2 /* ValueError */ };
+
+// _sample_mini_env_params_no_final_check (envs/mini_env.py:269-325)
+__device__ __forceinline__ int draw_candidate(MtLds mt, const MiniWorldParams& p, MiniWorld& W)
+{
+    W.o[0] = mt_uniform(mt, -p.inner_w / 2, p.inner_w / 2);
+    W.o[1] = mt_uniform(mt, -p.inner_h / 2, p.inner_h / 2);
+    const double first = mt_uniform(mt, 0, kTwoPi);
+    const double width = mt_uniform(mt, p.min_obstacle_angle, p.max_obstacle_angle);
+    const double reach = 3 * (p.inner_h + p.inner_w + p.mid_margin + p.out_margin);
+    W.h = p.inner_h + 2 * p.mid_margin + 2 * p.out_margin;
+    W.w = p.inner_w + 2 * p.mid_margin + 2 * p.out_margin;
+    Wedge wedge{W.o[0], W.o[1], first, first + width};
+    double sx, sy, ex, ey, heading;
+    if (mt_double(mt) < 0.7) {
+        // _sample_pose_circ (:146-180): antipodal points of a circle
+        const double radius = fmin((p.inner_w + p.inner_h) / 4. + p.mid_margin, p.lim_euc_dist);
+        bool found = false;
+        for (int t = 0; t < 1000 && !found; ++t) {
+            const double phi = mt_uniform(mt, 0, kTwoPi);
+            const double x = radius * cos(phi), y = radius * sin(phi);
+            (void)mt_uniform(mt, 0, kTwoPi);   // the reference draws a heading here and overwrites it
+            if (wedge.clear_of(x, y) && wedge.clear_of(-x, -y)) {
+                sx = x;
+                sy = y;
+                ex = -x;
+                ey = -y;
+                heading = atan2(-y - y, -x - x);
+                found = true;
+            }
+        }
+        if (!found) return kDrawEmpty;
+    } else {
+        // _pick_pts_square_method (:183-236)
+        const double half_w = p.inner_w / 2 + p.mid_margin, half_h = p.inner_h / 2 + p.mid_margin;
+        double sth = 0;
+        bool found = false;
+        for (int t = 0; t < 1000 && !found; ++t) {
+            const double x = mt_uniform(mt, -half_w, half_w), y = mt_uniform(mt, -half_h, half_h);
+            const double th = normalize_angle(mt_uniform(mt, 0, kTwoPi));
+            if (wedge.clear_of(x, y)) {
+                sx = x;
+                sy = y;
+                sth = th;
+                found = true;
+            }
+        }
+        if (!found) return kDrawFail;
+        found = false;
+        for (int t = 0; t < 1000 && !found; ++t) {
+            const double x = mt_uniform(mt, -half_w, half_w), y = mt_uniform(mt, -half_h, half_h);
+            const double th = normalize_angle(mt_uniform(mt, 0, kTwoPi));
+            const double dx = sx - x, dy = sy - y;
+            if (wedge.clear_of(x, y) && py_mod(sth - th, kTwoPi) < p.lim_ang_dist &&
+                sqrt(fma(dy, dy, dx * dx)) < p.lim_euc_dist) {
+                ex = x;
+                ey = y;
+                found = true;
+            }
+        }
+        if (!found) return kDrawFail;
+        heading = atan2(ey - sy, ex - sx);
+    }
+    const double half = p.angular_pose_noise_scale / 2.0;
+    const double th0 = normalize_angle(heading);   // OrientedPoint normalises on construction ...
+    W.start[0] = sx;
+    W.start[1] = sy;
+    W.start[2] = normalize_angle(th0 + mt_uniform(mt, -half, half));   // ... and again after the noise
+    W.end[0] = ex;
+    W.end[1] = ey;
+    W.end[2] = normalize_angle(th0 + mt_uniform(mt, -half, half));
+    W.a[0] = reach * cos(first) + W.o[0];
+    W.a[1] = reach * sin(first) + W.o[1];
+    W.b[0] = reach * cos(first + width) + W.o[0];
+    W.b[1] = reach * sin(first + width) + W.o[1];
+    return kDrawOk;
+}
+
+// cv::clipLine on 64-bit points (drawing.cpp), as the oracle's clip_line
+__device__ __forceinline__ bool clip_segment(int64_t cols, int64_t rows, int64_t& x1, int64_t& y1, int64_t& x2, int64_t& y2)
+{
+    const int64_t right = cols - 1, bottom = rows - 1;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        int64_t a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (int64_t)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (int64_t)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (int64_t)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (int64_t)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+// cv2.line(thickness=1) into a 1-bit map in LDS: clip, then the 8-connected left-to-right Bresenham iterator
+__device__ __forceinline__ void draw_wall_bits(MtLds bits, int rows, int cols, int wpr, int64_t x1, int64_t y1, int64_t x2,
+                                               int64_t y2)
+{
+    if ((uint64_t)x1 >= (uint64_t)cols || (uint64_t)x2 >= (uint64_t)cols || (uint64_t)y1 >= (uint64_t)rows ||
+        (uint64_t)y2 >= (uint64_t)rows) {
+        if (!clip_segment(cols, rows, x1, y1, x2, y2)) return;
+    }
+    int64_t dx = x2 - x1, dy = y2 - y1;
+    if (dx < 0) {
+        dx = -dx;
+        dy = -dy;
+        x1 = x2;
+        y1 = y2;
+    }
+    int64_t step_y = 1;
+    if (dy < 0) {
+        dy = -dy;
+        step_y = -1;
+    }
+    const bool vert = dy > dx;
+    const int64_t major = vert ? dy : dx, minor = vert ? dx : dy;
+    int64_t err = major - (minor + minor);
+    int64_t x = x1, y = y1;
+    for (int64_t i = 0; i <= major; ++i) {
+        bits[(int)y * wpr + (int)(x >> 5)] |= 1u << (x & 31);
+        const bool mask = err < 0;
+        err += -(minor + minor) + (mask ? major + major : 0);
+        if (vert) {
+            y += step_y;
+            if (mask) x += 1;
+        } else {
+            x += 1;
+            if (mask) y += step_y;
+        }
+    }
+}
+
+// ---- the sampler: one wavefront per chain -----------------------------------------------------------------------
+// LDS per wave: [MT19937 record: 625 words] [lethal bitmap: rows * wpr words]
+// worlds: [n_chains * episodes][14] = start(3), end(3), obstacle_a(2), obstacle_o(2), obstacle_b(2), h, w
+// status[chain]: 0 ok, 1 = "the sampling space looks empty" (the reference raises ValueError)
+__global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, MiniWorldParams mp, uint32_t* __restrict__ mt_state,
+                                                               int64_t n_chains, int episodes, int rows, int cols, int wide,
+                                                               double* __restrict__ worlds, uint8_t* __restrict__ maps,
+                                                               int32_t* __restrict__ status)
+{
+    extern __shared__ uint32_t sample_lds[];
+    const int lane = threadIdx.x;
+    const int64_t chain = blockIdx.x;
+    if (chain >= n_chains) return;
+    const int wpr = (cols + 31) / 32;
+    const MtLds mt = (MtLds)sample_lds;
+    const MtLds bits = mt + kMtRecord + 1;   // (+1: keeps the bitmap on an even word)
+    for (int k = lane; k < kMtRecord; k += 64) mt[k] = mt_state[chain * kMtRecord + k];
+    wave_lds_sync();
+    const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
+    const double inv_res = 1.0 / mp.resolution;
+    int failed = 0;
+    for (int e = 0; e < episodes && !failed; ++e) {
+        bool accepted = false;
+        MiniWorld W;
+        for (int tries = 0; tries < 1000 && !accepted && !failed; ++tries) {
+            int rc = kDrawOk;
+            if (lane == 0) rc = draw_candidate(mt, mp, W);
+            rc = bcast_i(rc, 0);
+            if (rc == kDrawFail) failed = 1;
+            if (rc != kDrawOk) continue;
+            // prepare_map_and_path (:362-388): empty map with origin (-h/2, -w/2), two walls from the apex
+            const double ox = -bcast_d(W.h, 0) / 2., oy = -bcast_d(W.w, 0) / 2.;
+            for (int k = lane; k < rows * wpr; k += 64) bits[k] = 0u;
+            wave_lds_sync();
+            if (lane == 0) {
+                const int64_t px_o = (int64_t)rint((W.o[0] - ox) * inv_res), py_o = (int64_t)rint((W.o[1] - oy) * inv_res);
+                draw_wall_bits(bits, rows, cols, wpr, px_o, py_o, (int64_t)rint((W.a[0] - ox) * inv_res),
+                               (int64_t)rint((W.a[1] - oy) * inv_res));
+                draw_wall_bits(bits, rows, cols, wpr, px_o, py_o, (int64_t)rint((W.b[0] - ox) * inv_res),
+                               (int64_t)rint((W.b[1] - oy) * inv_res));
+            }
+            wave_lds_sync();
+            // pose_collides of the two ends of the coarse path (:338-343), cooperatively
+            bool collides = false;
+#pragma unroll
+            for (int end = 0; end < 2; ++end) {
+                const double x = bcast_d(end ? W.end[0] : W.start[0], 0), y = bcast_d(end ? W.end[1] : W.start[1], 0);
+                const double th = bcast_d(end ? W.end[2] : W.start[2], 0);
+                const int px = (int)rint((x - ox) * inv_res), py = (int)rint((y - oy) * inv_res);
+                const bool hit = coop_collides(P, vqx, vqy, cos(th), sin(th), px, py, (LdsWords)bits, rows, cols, wpr, wide != 0);
+                collides = collides || hit;
+            }
+            // beginning and goal must not be immediately too close (:345-351)
+            const double dx = bcast_d(W.start[0], 0) - bcast_d(W.end[0], 0), dy = bcast_d(W.start[1], 0) - bcast_d(W.end[1], 0);
+            const double dth = fabs(normalize_angle(bcast_d(W.start[2], 0) - bcast_d(W.end[2], 0)));
+            const bool too_close = hypot(dx, dy) < mp.goal_spat_dist && dth < mp.goal_ang_dist;
+            accepted = !collides && !too_close;
+        }
+        if (!accepted) {
+            failed = 1;
+            break;
+        }
+        const int64_t g = chain * episodes + e;
+        if (lane == 0) {
+            double* o = worlds + g * 14;
+            o[0] = W.start[0];
+            o[1] = W.start[1];
+            o[2] = W.start[2];
+            o[3] = W.end[0];
+            o[4] = W.end[1];
+            o[5] = W.end[2];
+            o[6] = W.a[0];
+            o[7] = W.a[1];
+            o[8] = W.o[0];
+            o[9] = W.o[1];
+            o[10] = W.b[0];
+            o[11] = W.b[1];
+            o[12] = W.h;
+            o[13] = W.w;
+        }
+        // the accepted world's costmap: 254 where the bitmap is set
+        uint8_t* map = maps + g * (int64_t)rows * cols;
+        for (int idx = lane; idx < rows * cols; idx += 64) {
+            const int r = idx / cols, c = idx - r * cols;
+            map[idx] = ((bits[r * wpr + (c >> 5)] >> (c & 31)) & 1u) ? (uint8_t)BCP_LETHAL : (uint8_t)0;
+        }
+    }
+    wave_lds_sync();
+    for (int k = lane; k < kMtRecord; k += 64) mt_state[chain * kMtRecord + k] = mt[k];
+    if (lane == 0) status[chain] = failed;
+}
+
+}  // namespace bcp

@@ -21,6 +21,7 @@
 #include "bcp_coop.h"
 #include "bcp_step.h"
 #include "bcp_ego.h"
+#include "bcp_sample.h"
 
 using namespace bcp;
 
@@ -1352,6 +1353,56 @@ extern "C" int bcp_goal_direction_state(bcp_handle* h, const double* world_size,
     }
     hipLaunchKernelGGL(goal_direction_state_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, h->dev_static,
                        world_size[0], world_size[1], out);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+// ---- RandomMiniEnv worlds sampled on the device ----------------------------------------------------------------
+extern "C" int bcp_mini_world_seed(bcp_handle* h, const int64_t* seeds, int64_t n_chains, uint32_t* mt_state, void* stream)
+{
+    if (!h || !seeds || !mt_state || n_chains <= 0) return fail(BCP_E_INVALID, "bcp_mini_world_seed: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(mt_seed_kernel, dim3((unsigned)((n_chains + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seeds,
+                       n_chains, mt_state);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+extern "C" int bcp_sample_mini_worlds(bcp_handle* h, const bcp_mini_world_params* p, uint32_t* mt_state, int64_t n_chains,
+                                      int32_t episodes, int32_t rows, int32_t cols, double* worlds, uint8_t* maps,
+                                      int32_t* status, void* stream)
+{
+    if (!h || !p || !mt_state || !worlds || !maps || !status || n_chains <= 0 || episodes <= 0)
+        return fail(BCP_E_INVALID, "bcp_sample_mini_worlds: bad argument");
+    if (!(p->resolution > 0) || !check_kernel_size(h->params, p->resolution))
+        return fail(BCP_E_INVALID, "bcp_sample_mini_worlds: bad resolution for this footprint");
+    if ((int)(0.05 / p->resolution) > 1)   // Wall.render: thickness = max(1, int(width / resolution))
+        return fail(BCP_E_INVALID, "bcp_sample_mini_worlds: walls thicker than one pixel are not supported");
+    const int wpr = (cols + 31) / 32;
+    const size_t lds = ((size_t)kMtRecord + 1 + (size_t)rows * wpr) * sizeof(uint32_t);
+    if (rows <= 0 || cols <= 0 || lds > 60 * 1024) return fail(BCP_E_INVALID, "bcp_sample_mini_worlds: unsupported map shape");
+    HIP_TRY(hipSetDevice(h->device));
+    DevParams P = h->dev;
+    for (int k = 0; k < h->params.n_verts; ++k) {   // robot_footprint / map_resolution (path_tools.py:145)
+        P.qverts[k][0] = h->params.verts[k][0] / p->resolution;
+        P.qverts[k][1] = h->params.verts[k][1] / p->resolution;
+    }
+    MiniWorldParams mp;
+    mp.inner_h = p->inner_h;
+    mp.inner_w = p->inner_w;
+    mp.mid_margin = p->mid_margin;
+    mp.out_margin = p->out_margin;
+    mp.min_obstacle_angle = p->min_obstacle_angle;
+    mp.max_obstacle_angle = p->max_obstacle_angle;
+    mp.lim_euc_dist = p->lim_euc_dist;
+    mp.lim_ang_dist = p->lim_ang_dist;
+    mp.angular_pose_noise_scale = p->angular_pose_noise_scale;
+    mp.resolution = p->resolution;
+    mp.goal_spat_dist = p->goal_spat_dist;
+    mp.goal_ang_dist = p->goal_ang_dist;
+    hipLaunchKernelGGL(mini_world_sample_kernel, dim3((unsigned)n_chains), dim3(64), lds, (hipStream_t)stream, P, mp, mt_state,
+                       n_chains, (int)episodes, (int)rows, (int)cols, footprint_is_wide(h->params, p->resolution), worlds, maps,
+                       status);
     HIP_TRY(hipGetLastError());
     return BCP_OK;
 }

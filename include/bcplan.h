@@ -242,6 +242,30 @@ int bcp_goal_n_state(bcp_handle *h, const double *world_size /*host*/, float *ou
  * (v, w, wheel_angle; 0 for a diff-drive robot).  out: float64 [N, 5]. */
 int bcp_goal_direction_state(bcp_handle *h, const double *world_size /*host*/, double *out, void *stream);
 
+/* ---- RandomMiniEnv worlds sampled on the device ------------------------------------------------------------ */
+/* RandomMiniEnvParams (envs/mini_env.py:30-47) + the EnvParams fields the sampler reads.  host struct. */
+typedef struct bcp_mini_world_params {
+    double inner_h, inner_w, mid_margin, out_margin;
+    double min_obstacle_angle, max_obstacle_angle;
+    double lim_euc_dist, lim_ang_dist, angular_pose_noise_scale;
+    double resolution;      /* EnvParams.resolution */
+    double goal_spat_dist;  /* EnvParams.goal_spat_dist / goal_ang_dist: start and goal must not be this close */
+    double goal_ang_dist;
+} bcp_mini_world_params;
+/* numpy.random.RandomState(seed) for n_chains independent streams: mt_state is uint32 [n_chains][625] device memory
+ * (624 MT19937 words + the position), seeds int64 [n_chains] device memory (0 <= seed < 2^32, mt19937_seed). */
+int bcp_mini_world_seed(bcp_handle *h, const int64_t *seeds, int64_t n_chains, uint32_t *mt_state, void *stream);
+/* _sample_mini_env_params (envs/mini_env.py:328-359) `episodes` times in a row for every stream, one wavefront per
+ * stream: same draw order as the reference, two 1-px walls (cv2.line), pose_collides of both path ends with this
+ * handle's footprint, "not too close" test; the streams continue where they stopped.  Outputs (device):
+ *   worlds  double [n_chains * episodes][14] = start(3), end(3), obstacle_a(2), obstacle_o(2), obstacle_b(2), h, w
+ *   maps    uint8  [n_chains * episodes][rows][cols]  (rows, cols as CostMap2D.create_empty gives them for (h, w))
+ *   status  int32  [n_chains]  0, or 1 where the reference would raise "the sampling space looks empty"
+ * Transcendentals are the device's: a world can differ from numpy's in the last bit of a coordinate. */
+int bcp_sample_mini_worlds(bcp_handle *h, const bcp_mini_world_params *p /*host*/, uint32_t *mt_state, int64_t n_chains,
+                           int32_t episodes, int32_t rows, int32_t cols, double *worlds, uint8_t *maps, int32_t *status,
+                           void *stream);
+
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* Runs `steps` bcp_step() launches back to back on `stream` bracketed by HIP events recorded on that stream and
  * returns the average kernel-launch duration in milliseconds (synchronises).  Used by bench.py for

@@ -150,3 +150,38 @@ def test_pool_full_size_two_kernel_path(torch_cuda, oracle):
         _compare(env, ref, t)
         resets += int(ref.done.sum())
     assert resets >= n
+
+
+def test_device_sampler_matches_host_and_reference(torch_cuda):
+    """bcp_sample_mini_worlds (one wavefront per RandomState stream: MT19937, rejection sampler, walls, acceptance test
+    on the device) against the reference's own worlds (g9) and against the host sampler on more streams"""
+    from bc_gym_planning_env_amd import mini_env
+    g = np.load(os.path.join(GOLDEN, "g9_mini_geometry.npz"))
+    seeds, episodes = [int(s) for s in g["seeds"]], g["worlds"].shape[1]
+    pool = mini_env.sample_pool_device(None, seeds, episodes)
+    cols = int(g["map_shape"][1])
+    exact = 0
+    for k, w in enumerate(pool.worlds):
+        ref = g["worlds"][k // episodes, k % episodes]
+        mine = np.concatenate([w.start_pos, w.end_pos, w.obstacle_a, w.obstacle_o, w.obstacle_b, [w.h, w.w]])
+        np.testing.assert_allclose(mine, ref, rtol=0, atol=1e-12, err_msg="world %d" % k)
+        exact += int((mine == ref).all())
+        want = np.unpackbits(g["maps"][k], axis=1)[:, :cols].astype(bool)
+        assert ((pool.costmaps[k].get_data() == 254) == want).all(), k
+        assert set(np.unique(pool.costmaps[k].get_data())) <= {0, 254}
+    assert exact >= len(pool.worlds) // 2       # (device sin / cos / atan2 differ from numpy's in the last bit now and then)
+    # more streams, longer chains: host sampler (bit-exact to the reference) vs device sampler
+    seeds = list(range(500, 564))
+    a = mini_env.sample_pool(None, seeds, 6)
+    b = mini_env.sample_pool_device(None, seeds, 6)
+    same_maps = 0
+    for wa, wb, ca, cb in zip(a.worlds, b.worlds, a.costmaps, b.costmaps):
+        for fa, fb in ((wa.start_pos, wb.start_pos), (wa.end_pos, wb.end_pos), (wa.obstacle_o, wb.obstacle_o),
+                       (wa.obstacle_a, wb.obstacle_a), (wa.obstacle_b, wb.obstacle_b)):
+            np.testing.assert_allclose(fa, fb, rtol=0, atol=1e-12)
+        same_maps += int((ca.get_data() == cb.get_data()).all())
+    assert same_maps >= len(a.worlds) - 1       # a last-bit difference can move a wall end by a pixel, very rarely
+    # and the pool drives an env like any other
+    env = mini_env.BatchedRandomMiniEnv(256, pool=b, auto_reset=True)
+    env.step(env.action_space.sample_batch(256))
+    env.check_errors()

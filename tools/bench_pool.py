@@ -12,6 +12,15 @@ pool = mini_env.sample_pool(None, list(range(chains)), episodes)
 t1 = time.time()
 print("pool: %d worlds sampled in %.1f s (%.1f worlds/s, host numpy + batched GPU acceptance test)" % (
     len(pool), t1 - t0, len(pool) / (t1 - t0)), flush=True)
+for big in (4096, 65536):
+    torch.cuda.synchronize()
+    t2 = time.time()
+    dpool = mini_env.sample_pool_device(None, list(range(big)), episodes)
+    t3 = time.time()
+    print("device sampler: %d worlds in %.2f s (%.0f worlds/s, incl. download and host objects)" % (
+        len(dpool), t3 - t2, len(dpool) / (t3 - t2)), flush=True)
+    del dpool
+t1 = time.time()
 env = mini_env.BatchedRandomMiniEnv(n, pool=pool, auto_reset=True, seed=3)
 torch.cuda.synchronize()
 print("env set-up %.1f s" % (time.time() - t1), flush=True)
