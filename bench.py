@@ -112,8 +112,9 @@ def aux_measurements(env, pool, n):
     # a fresh world per episode: RandomMiniEnv.reset() as a device-side walk through a pool of pre-sampled geometries
     import time as _time
     from bc_gym_planning_env_amd import mini_env
+    torch.cuda.synchronize()
     t0 = _time.perf_counter()
-    worlds = mini_env.sample_pool(None, list(range(512)), 4, device=env.device.index or 0)
+    worlds = mini_env.sample_pool_device(None, list(range(4096)), 4, device=env.device.index or 0)
     t_pool = _time.perf_counter() - t0
     penv = mini_env.BatchedRandomMiniEnv(n, pool=worlds, auto_reset=True, seed=3, device=env.device.index or 0)
     rng = np.random.RandomState(7)
@@ -129,10 +130,12 @@ def aux_measurements(env, pool, n):
     ms_pool = e0.elapsed_time(e1) / 100
     out["geometry_pool"] = {
         "what": "RandomMiniEnv with draw_new_turn_on_reset: %d envs over %d pre-sampled worlds (%d chains x %d), every "
-                "reset moves the env to its chain's next world inside the step kernel" % (n, len(worlds), 512, 4),
+                "reset moves the env to its chain's next world inside the step kernel" % (n, len(worlds), 4096, 4),
         "ms_per_step": ms_pool, "env_steps_per_s": n / (ms_pool * 1e-3),
         "episodes_ending_per_step": float(penv.done.float().sum()),
-        "host_sampling_worlds_per_s": len(worlds) / t_pool}
+        "device_sampling_worlds_per_s": len(worlds) / t_pool,
+        "sampler": "bcp_sample_mini_worlds: numpy's MT19937 stream + rejection sampler + walls + acceptance test, one "
+                   "wavefront per stream (rate includes the download and the host-side pool objects)"}
     return out
 
 
