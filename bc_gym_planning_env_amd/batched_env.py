@@ -36,6 +36,43 @@ def _as_device_actions(actions, n, device):
     return t
 
 
+class DeviceGeometryPool(object):
+    """G geometries that already live on the GPU (e.g. from mini_env.sample_device_pool): what BatchedPlanEnv's
+    geometry-pool mode needs, as device tensors.  `costmaps` / `paths` hand out host copies on demand, for the per-env
+    views (envs[i].get_state())."""
+
+    def __init__(self, maps, origin, resolution, paths, lens, init):
+        self.maps = maps                  # uint8 [G, rows, cols]
+        self.origin = np.asarray(origin, dtype=np.float64)   # one origin for all entries
+        self.resolution = float(resolution)
+        self.path_points = paths          # float64 [G, max_len, 3], already refined
+        self.lens = lens                  # int32 [G]
+        self.init = init                  # float64 [G, 2] = (min_spat_dist_so_far, target_idx)
+
+    def __len__(self):
+        return int(self.maps.shape[0])
+
+    class _Lazy(object):
+        def __init__(self, n, fetch):
+            self._n, self._fetch = n, fetch
+
+        def __len__(self):
+            return self._n
+
+        def __getitem__(self, k):
+            if not -self._n <= k < self._n:
+                raise IndexError(k)
+            return self._fetch(int(k) % self._n)
+
+    @property
+    def costmaps(self):
+        return self._Lazy(len(self), lambda k: CostMap2D(self.maps[k].cpu().numpy(), self.resolution, self.origin))
+
+    @property
+    def paths(self):
+        return self._Lazy(len(self), lambda k: self.path_points[k, :int(self.lens[k])].cpu().numpy())
+
+
 class BatchedState(object):
     """Snapshot of every env's mutable state (what PlanEnv.get_state() deep-copies, env.py:287-291)."""
 
@@ -267,7 +304,11 @@ class BatchedPlanEnv(object):
         self.geom_of_env = None
         if geom_of_env is not None:
             assert template_of_env is None
-            costmap, path = list(costmap), list(path)
+            self._device_pool = costmap if isinstance(costmap, DeviceGeometryPool) else None
+            if self._device_pool is not None:
+                costmap, path = self._device_pool.costmaps, self._device_pool.paths
+            else:
+                costmap, path = list(costmap), list(path)
             g0 = np.asarray(geom_of_env, dtype=np.int32)
             assert g0.shape == (n,) and len(costmap) == len(path) and 0 <= g0.min() and g0.max() < len(costmap)
             self.geom_of_env = torch.from_numpy(g0.copy()).to(dev)
@@ -359,6 +400,16 @@ class BatchedPlanEnv(object):
     def _set_from_templates(self, costmaps, paths):
         """Private per-env costmaps / paths expanded on the device from a few templates."""
         n, dev = self.n_envs, self.device
+        dp = getattr(self, "_device_pool", None)
+        if dp is not None:   # everything is on the device already (refined paths included)
+            g_n = len(dp)
+            self._costmaps, self._paths, self._shared_path = costmaps, paths, False
+            self.set_costmap_tensors(dp.maps, torch.from_numpy(np.tile(dp.origin, (g_n, 1))).to(dev), dp.resolution)
+            self._keep.update(path=dp.path_points, lens=dp.lens)
+            _lib.check(self._lib.bcp_set_paths(self._h, dp.path_points.data_ptr(), dp.lens.data_ptr(),
+                                               int(dp.path_points.shape[1]), 0, self._stream()))
+            torch.cuda.current_stream(dev).synchronize()
+            return
         if self.geom_of_env is not None:   # geometry pool: the library indexes the entries itself
             idx = torch.arange(len(costmaps), device=dev)
         else:
@@ -439,6 +490,13 @@ class BatchedPlanEnv(object):
         reference's TricycleRobotState() default wheel angle is 0.0 and PlanEnv never applies
         params.initial_wheel_angle to it, so neither do we."""
         n = self.n_envs if self.geom_of_env is None else len(self._paths)
+        dp = getattr(self, "_device_pool", None)
+        if dp is not None:   # initial states computed on the device with the paths (bcp_mini_world_paths)
+            dev = self.device
+            robot_t = torch.zeros(7, n, dtype=torch.float64, device=dev)
+            robot_t[0:3] = dp.path_points[:, 0, :].t()
+            return BatchedState(robot_t, dp.init[:, 0].contiguous(), dp.init[:, 1].to(torch.int32).contiguous(),
+                                torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev))
         robot = np.zeros((7, n), dtype=np.float64)
         md = np.zeros(n, dtype=np.float64)
         ti = np.zeros(n, dtype=np.int32)

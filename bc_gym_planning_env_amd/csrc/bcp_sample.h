@@ -344,4 +344,69 @@ __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, Mini
     if (lane == 0) status[chain] = failed;
 }
 
+// ---- from sampled worlds to what a PlanEnv starts with -----------------------------------------------------------
+// make_initial_state (envs/base/env.py:179-214) for every world: refine_path of the coarse (start, end) path
+// (utilities/path_tools.py:178-240: points every path_delta, np.linspace arithmetic, inserted points carry the start
+// heading) and the reward provider's initial state (reward.py:261-288, or :355-371 for pure pursuit).
+// One thread per world.  paths: [G][max_len][3], lens: [G], init: [G][2] = (min_spat_dist_so_far, target_idx).
+// status[g]: 0, 1 = path longer than max_len, 2 = "Goal pose too close to initial pose" (ValueError in the reference).
+__global__ void mini_world_paths_kernel(const double* __restrict__ worlds, int64_t n_worlds, double path_delta, double sp,
+                                        double ap, int pure_pursuit, int max_len, double* __restrict__ paths,
+                                        int32_t* __restrict__ lens, double* __restrict__ init, int32_t* __restrict__ status)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_worlds) return;
+    const double* w = worlds + g * 14;
+    const double x0 = w[0], y0 = w[1], th0 = w[2], x1 = w[3], y1 = w[4], th1 = w[5];
+    double* p = paths + g * (int64_t)max_len * 3;
+    const double dx = x1 - x0, dy = y1 - y0;
+    const double d = sqrt(dx * dx + dy * dy);   // np.linalg.norm(..., axis=1): sqrt(add.reduce(x * x))
+    int m;
+    int rc = 0;
+    if (d > path_delta) {
+        const int npoints = (int)(d / path_delta) + 2;
+        m = npoints;   // npoints - 1 interpolated rows (the last linspace sample is dropped), then the end pose
+        if (m > max_len) {
+            rc = 1;
+            m = max_len;
+        }
+        const double sx = dx / (double)(npoints - 1), sy = dy / (double)(npoints - 1);   // np.linspace: step = delta / div
+        for (int i = 0; i < m - 1; ++i) {
+            p[3 * i + 0] = (double)i * sx + x0;    // arange(num) * step + start
+            p[3 * i + 1] = (double)i * sy + y0;
+            p[3 * i + 2] = th0;
+        }
+    } else {
+        m = 2;
+        p[0] = x0;
+        p[1] = y0;
+        p[2] = th0;
+    }
+    p[3 * (m - 1) + 0] = x1;
+    p[3 * (m - 1) + 1] = y1;
+    p[3 * (m - 1) + 2] = th1;
+    lens[g] = m;
+    double min_dist;
+    int target;
+    if (pure_pursuit) {   // reward.py:355-371
+        target = 1;
+        min_dist = hypot(x1 - x0, y1 - y0);
+    } else {              // find_last_reached(path[0], path) (path_tools.py:408-448), reward.py:261-288
+        int last = -1;
+        for (int j = 0; j < m; ++j) {
+            const double xj = p[3 * j], yj = p[3 * j + 1], tj = p[3 * j + 2];
+            const bool near = hypot(xj - x0, yj - y0) < sp;
+            const bool aligned = fabs(normalize_angle(th0 - tj)) < ap;
+            const bool ahead = cos(tj) * (x0 - xj) + sin(tj) * (y0 - yj) >= -sp / 9;
+            if (near && aligned && ahead) last = j;
+        }
+        if (last == m - 1) rc = 2;
+        target = min(last + 1, m - 1);
+        min_dist = hypot(p[3 * target] - x0, p[3 * target + 1] - y0);
+    }
+    init[2 * g] = min_dist;
+    init[2 * g + 1] = (double)target;
+    status[g] = rc;
+}
+
 }  // namespace bcp

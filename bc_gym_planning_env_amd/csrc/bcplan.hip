@@ -1406,3 +1406,16 @@ extern "C" int bcp_sample_mini_worlds(bcp_handle* h, const bcp_mini_world_params
     HIP_TRY(hipGetLastError());
     return BCP_OK;
 }
+
+extern "C" int bcp_mini_world_paths(bcp_handle* h, const double* worlds, int64_t n_worlds, double path_delta, int32_t max_len,
+                                    double* paths, int32_t* lens, double* init, int32_t* status, void* stream)
+{
+    if (!h || !worlds || !paths || !lens || !init || !status || n_worlds <= 0 || max_len < 2 || !(path_delta > 0))
+        return fail(BCP_E_INVALID, "bcp_mini_world_paths: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(mini_world_paths_kernel, dim3((unsigned)((n_worlds + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
+                       worlds, n_worlds, path_delta, h->params.spatial_precision, h->params.angular_precision,
+                       (int)(h->params.reward_provider == BCP_REWARD_PURE_PURSUIT), (int)max_len, paths, lens, init, status);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}

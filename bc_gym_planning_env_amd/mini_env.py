@@ -19,7 +19,7 @@ import torch
 
 from . import _lib, robots
 from .api import CostMap2D, EnvParams
-from .batched_env import BatchedPlanEnv
+from .batched_env import BatchedPlanEnv, DeviceGeometryPool
 
 _TWO_PI = 2 * np.pi
 _MAX_TRIES = 1000
@@ -385,11 +385,34 @@ def sample_pool(params=None, seeds=(0,), episodes=1, device=0, collider=None):
                        built=[b for c in chains for b in c.built])
 
 
-def sample_pool_device(params=None, seeds=(0,), episodes=1, device=0):
+class DeviceMiniEnvPool(DeviceGeometryPool):
+    """A MiniEnvPool that never leaves the GPU: worlds, costmaps, refined paths and initial reward states as device
+    tensors (sample_pool_device(..., keep_on_device=True)).  `worlds` / `costmaps` / `paths` download on demand."""
+
+    def __init__(self, params, seeds, episodes, worlds, maps, origin, paths, lens, init):
+        super(DeviceMiniEnvPool, self).__init__(maps, origin, params.env_params.resolution, paths, lens, init)
+        self.params, self.seeds, self.episodes = params, list(seeds), int(episodes)
+        self.world_params = worlds        # float64 [G, 14]
+        g = np.arange(len(self), dtype=np.int32)
+        self.next_geom = ((g // self.episodes) * self.episodes + (g % self.episodes + 1) % self.episodes).astype(np.int32)
+
+    @property
+    def worlds(self):
+        ep = self.params.env_params
+
+        def fetch(k):
+            v = self.world_params[k].cpu().numpy()
+            return MiniEnvParams(v[12], v[13], v[0:3], v[3:6], v[6:8], v[8:10], v[10:12], ep)
+        return self._Lazy(len(self), fetch)
+
+
+def sample_pool_device(params=None, seeds=(0,), episodes=1, device=0, keep_on_device=False):
     """The same pool as sample_pool(), sampled entirely on the GPU (bcp_sample_mini_worlds, csrc/bcp_sample.h): one
     wavefront per seed runs numpy's MT19937 stream, the rejection sampler, the wall rasteriser and the acceptance test.
     Orders of magnitude faster than the host sampler; a coordinate can differ from the host's (numpy's) in its last bit
-    because the transcendentals are the device's."""
+    because the transcendentals are the device's.
+    keep_on_device=True returns a DeviceMiniEnvPool: nothing is downloaded, refined paths and initial reward states are
+    computed on the GPU as well (bcp_mini_world_paths) -- the way to build pools of 10^5 .. 10^6 worlds."""
     params = default_random_mini_env_params() if params is None else params
     ep = params.env_params
     lib = _lib.load()
@@ -420,6 +443,24 @@ def sample_pool_device(params=None, seeds=(0,), episodes=1, device=0):
                                               maps.data_ptr(), status.data_ptr(), stream))
         if int(status.sum()):
             raise ValueError("Something went wrong, the sampling space looks empty.")
+        if keep_on_device:
+            if not ep.refine_path:
+                raise NotImplementedError("device pools always carry refined paths")
+            diag = float(np.hypot(2 * (params.inner_w / 2 + params.mid_margin), 2 * (params.inner_h / 2 + params.mid_margin)))
+            max_len = int(diag / ep.path_delta) + 4            # the longest start -> end segment inside the square
+            g_n = n * episodes
+            paths = torch.zeros((g_n, max_len, 3), dtype=torch.float64, device=dev)
+            lens = torch.zeros(g_n, dtype=torch.int32, device=dev)
+            init = torch.zeros((g_n, 2), dtype=torch.float64, device=dev)
+            pstat = torch.zeros(g_n, dtype=torch.int32, device=dev)
+            _lib.check(lib.bcp_mini_world_paths(h, worlds.data_ptr(), g_n, float(ep.path_delta), max_len, paths.data_ptr(),
+                                                lens.data_ptr(), init.data_ptr(), pstat.data_ptr(), stream))
+            worst = int(pstat.max())
+            if worst == 2:
+                raise ValueError("Goal pose too close to initial pose")
+            assert worst == 0, "refined path longer than expected"
+            return DeviceMiniEnvPool(params, seeds, episodes, worlds, maps, np.array([-side_h / 2., -side_w / 2.]), paths,
+                                     lens, init)
         w_host, m_host = worlds.cpu().numpy(), maps.cpu().numpy()
     finally:
         lib.bcp_destroy(h)
@@ -444,7 +485,8 @@ class BatchedRandomMiniEnv(BatchedPlanEnv):
 
     :param pool MiniEnvPool: pre-sampled worlds, or None to sample `n_chains` x `episodes` here
     :param sampler: "device" (sample_pool_device: on the GPU, ~10^5 worlds/s, coordinates within 1e-12 of the
-        reference's) or "host" (sample_pool: numpy, bit-identical to the reference, ~3 x 10^3 worlds/s)
+        reference's), "device_resident" (the same, and the pool never leaves the GPU: for 10^5 .. 10^6 worlds) or
+        "host" (sample_pool: numpy, bit-identical to the reference, ~3 x 10^3 worlds/s)
     :param draw_new_turn_on_reset bool: False keeps every env on its first world (RandomMiniEnv's flag of that name)
     Remaining keyword arguments go to BatchedPlanEnv (auto_reset, seed, noise_parameters, env_id_base, ...).
     """
@@ -455,12 +497,15 @@ class BatchedRandomMiniEnv(BatchedPlanEnv):
         if pool is None:
             if seeds is None:
                 seeds = range(int(n_chains) if n_chains else min(int(n_envs), 1024))
-            sample = {"device": sample_pool_device, "host": sample_pool}[sampler]
-            pool = sample(params, list(seeds), episodes, device)
+            if sampler == "device_resident":
+                pool = sample_pool_device(params, list(seeds), episodes, device, keep_on_device=True)
+            else:
+                pool = {"device": sample_pool_device, "host": sample_pool}[sampler](params, list(seeds), episodes, device)
         chains, per = len(pool.seeds), pool.episodes
         i = np.arange(int(n_envs))
         geom = (i % chains) * per + (i // chains) % per
         self.pool = pool
+        on_device = isinstance(pool, DeviceGeometryPool)
         super(BatchedRandomMiniEnv, self).__init__(
-            pool.costmaps, pool.paths, params.env_params, n_envs=n_envs, device=device, geom_of_env=geom,
-            next_geom=pool.next_geom if draw_new_turn_on_reset else None, **kw)
+            pool if on_device else pool.costmaps, None if on_device else pool.paths, params.env_params, n_envs=n_envs,
+            device=device, geom_of_env=geom, next_geom=pool.next_geom if draw_new_turn_on_reset else None, **kw)

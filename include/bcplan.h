@@ -266,6 +266,14 @@ int bcp_sample_mini_worlds(bcp_handle *h, const bcp_mini_world_params *p /*host*
                            int32_t episodes, int32_t rows, int32_t cols, double *worlds, uint8_t *maps, int32_t *status,
                            void *stream);
 
+/* make_initial_state (envs/base/env.py:179-214) for sampled worlds, on the device: refine_path of each world's coarse
+ * (start, end) path (utilities/path_tools.py:178-240) and the initial state of this handle's reward provider
+ * (reward.py:261-288 / :355-371).  worlds as bcp_sample_mini_worlds writes them; paths: double [n_worlds][max_len][3];
+ * lens: int32 [n_worlds]; init: double [n_worlds][2] = (min_spat_dist_so_far, target_idx); status: int32 [n_worlds],
+ * 0 = ok, 1 = the refined path does not fit max_len, 2 = "Goal pose too close to initial pose". */
+int bcp_mini_world_paths(bcp_handle *h, const double *worlds, int64_t n_worlds, double path_delta, int32_t max_len,
+                         double *paths, int32_t *lens, double *init, int32_t *status, void *stream);
+
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* Runs `steps` bcp_step() launches back to back on `stream` bracketed by HIP events recorded on that stream and
  * returns the average kernel-launch duration in milliseconds (synchronises).  Used by bench.py for
