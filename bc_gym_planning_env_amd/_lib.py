@@ -92,6 +92,10 @@ SYMBOLS = {
     "bcp_mini_world_seed": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "bcp_sample_mini_worlds": (C.c_int, [_H, C.POINTER(BcpMiniWorldParams), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bcp_plan_mini_worlds": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bcp_refresh_mini_worlds": (C.c_int, [_H, C.POINTER(BcpMiniWorldParams)] + [C.c_void_p] * 6 + [C.c_double] +
+                                [C.c_void_p] * 3),
+    "bcp_release_mini_worlds": (C.c_int, [_H, C.c_void_p]),
     "bcp_mini_world_paths": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "bcp_time_step_kernels": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p,

@@ -29,6 +29,7 @@ struct CullDesc {
     int64_t env_stride;   // bytes per env (0: one field shared by all envs)
     int32_t on;           // 0: no distance field -> every in-map pose is AMBIGUOUS
     int32_t pad, width, height;  // padding on each side, padded row width / row count
+    int32_t clamp;        // the field saturates at this distance
     int32_t reach;        // any footprint pixel is within `reach` px of the robot pixel (off-map test)
     int32_t n_out, n_in;
     int32_t t_out;        // free  <=>  edt >= t_out at every outer sample

@@ -256,8 +256,11 @@ __device__ __forceinline__ void draw_wall_bits(MtLds bits, int rows, int cols, i
 // LDS per wave: [MT19937 record: 625 words] [lethal bitmap: rows * wpr words]
 // worlds: [n_chains * episodes][14] = start(3), end(3), obstacle_a(2), obstacle_o(2), obstacle_b(2), h, w
 // status[chain]: 0 ok, 1 = "the sampling space looks empty" (the reference raises ValueError)
+// counts / first_world (optional): see "ring mode" below
 __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, MiniWorldParams mp, uint32_t* __restrict__ mt_state,
                                                                int64_t n_chains, int episodes, int rows, int cols, int wide,
+                                                               const int32_t* __restrict__ counts,
+                                                               const int64_t* __restrict__ first_world,
                                                                double* __restrict__ worlds, uint8_t* __restrict__ maps,
                                                                int32_t* __restrict__ status)
 {
@@ -266,6 +269,7 @@ __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, Mini
     const int64_t chain = blockIdx.x;
     if (chain >= n_chains) return;
     const int wpr = (cols + 31) / 32;
+    if (counts && counts[chain] <= 0) return;   // ring mode: nothing to top up behind this chain's env
     const MtLds mt = (MtLds)sample_lds;
     const MtLds bits = mt + kMtRecord + 1;   // (+1: keeps the bitmap on an even word)
     for (int k = lane; k < kMtRecord; k += 64) mt[k] = mt_state[chain * kMtRecord + k];
@@ -273,7 +277,11 @@ __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, Mini
     const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
     const double inv_res = 1.0 / mp.resolution;
     int failed = 0;
-    for (int e = 0; e < episodes && !failed; ++e) {
+    // ring mode (counts != nullptr): this chain produces its next counts[chain] worlds; world number j of the stream
+    // (first_world[chain], first_world[chain] + 1, ...) goes to slot j % episodes of the chain's `episodes` pool entries
+    const int n_new = counts ? min(counts[chain], episodes) : episodes;
+    const int64_t j0 = counts ? first_world[chain] : 0;
+    for (int e = 0; e < n_new && !failed; ++e) {
         bool accepted = false;
         MiniWorld W;
         for (int tries = 0; tries < 1000 && !accepted && !failed; ++tries) {
@@ -314,7 +322,7 @@ __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, Mini
             failed = 1;
             break;
         }
-        const int64_t g = chain * episodes + e;
+        const int64_t g = chain * episodes + (j0 + e) % episodes;
         if (lane == 0) {
             double* o = worlds + g * 14;
             o[0] = W.start[0];
@@ -350,12 +358,11 @@ __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, Mini
 // heading) and the reward provider's initial state (reward.py:261-288, or :355-371 for pure pursuit).
 // One thread per world.  paths: [G][max_len][3], lens: [G], init: [G][2] = (min_spat_dist_so_far, target_idx).
 // status[g]: 0, 1 = path longer than max_len, 2 = "Goal pose too close to initial pose" (ValueError in the reference).
-__global__ void mini_world_paths_kernel(const double* __restrict__ worlds, int64_t n_worlds, double path_delta, double sp,
-                                        double ap, int pure_pursuit, int max_len, double* __restrict__ paths,
-                                        int32_t* __restrict__ lens, double* __restrict__ init, int32_t* __restrict__ status)
+__device__ __forceinline__ void mini_world_path(const double* __restrict__ worlds, int64_t g, double path_delta, double sp,
+                                                double ap, int pure_pursuit, int max_len, double* __restrict__ paths,
+                                                int32_t* __restrict__ lens, double* __restrict__ init,
+                                                int32_t* __restrict__ status)
 {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_worlds) return;
     const double* w = worlds + g * 14;
     const double x0 = w[0], y0 = w[1], th0 = w[2], x1 = w[3], y1 = w[4], th1 = w[5];
     double* p = paths + g * (int64_t)max_len * 3;
@@ -407,6 +414,101 @@ __global__ void mini_world_paths_kernel(const double* __restrict__ worlds, int64
     init[2 * g] = min_dist;
     init[2 * g + 1] = (double)target;
     status[g] = rc;
+}
+
+__global__ void mini_world_paths_kernel(const double* __restrict__ worlds, EntrySelect sel, double path_delta, double sp,
+                                        double ap, int pure_pursuit, int max_len, double* __restrict__ paths,
+                                        int32_t* __restrict__ lens, double* __restrict__ init, int32_t* __restrict__ status)
+{
+    const int64_t total = sel.size();
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x)
+        mini_world_path(worlds, sel.entry(it), path_delta, sp, ap, pure_pursuit, max_len, paths, lens, init, status);
+}
+
+// ---- pools that never run out: the `episodes` entries of a chain as a ring over its stream of worlds ----------------
+// RandomMiniEnv.reset draws a fresh world every time (envs/mini_env.py:441-459).  With one stream per env (env c on
+// chain c, entries c * E .. c * E + E - 1) the pool holds worlds generated[c] - E .. generated[c] - 1 of the stream,
+// world j in entry c * E + j % E, and next_geom walks them in order except that the newest world's entry points to
+// itself (an env that gets there before the next refresh repeats that world instead of wrapping onto an old one).
+// This kernel looks where env c is, frees the entries behind it -- world numbers first_world[c] .. + counts[c] - 1 are
+// to be sampled into them -- closes the ring behind the last of them (the new guard) and appends the freed entries to
+// `dirty`.  The OLD guard stays shut until mini_world_ring_release_kernel, after everything has been rewritten: steps
+// may run while the new worlds are being made (they neither read nor reach a dirty entry).
+// info[0] = number of dirty entries, info[1] = envs found on the guard entry (they may have repeated a world).
+__global__ void __launch_bounds__(256) mini_world_ring_plan_kernel(int64_t n_chains, int episodes,
+                                                                   const int32_t* __restrict__ geom_of_env,
+                                                                   int32_t* __restrict__ next_geom,
+                                                                   int64_t* __restrict__ generated, int32_t* __restrict__ counts,
+                                                                   int64_t* __restrict__ first_world, int32_t* __restrict__ dirty,
+                                                                   int32_t* __restrict__ info)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int E = episodes;
+    int count = 0;
+    int64_t gen = 0;
+    bool starved = false;
+    if (c < n_chains) {
+        gen = generated[c];
+        const int64_t oldest = gen - E;
+        const int64_t slot = (int64_t)geom_of_env[c] - c * E;
+        const int64_t world = oldest + (((slot - oldest) % E) + E) % E;   // the world number env c is on
+        count = (int)(world - oldest);
+        starved = world == gen - 1;
+        counts[c] = count;
+        first_world[c] = gen;
+        generated[c] = gen + count;
+        if (count > 0) {
+            const int32_t guard = (int32_t)(c * E + (gen + count - 1) % E);
+            next_geom[guard] = guard;
+        }
+    }
+    int incl = count;   // wave-wide inclusive prefix sum: one atomic per wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    const int total = __shfl(incl, 63);
+    int base = 0;
+    if (lane == 63 && total > 0) base = atomicAdd(&info[0], total);
+    base = __shfl(base, 63);
+    const uint64_t starving = __ballot(starved);
+    if (lane == 0 && starving) atomicAdd(&info[1], __popcll(starving));
+    for (int e = 0; e < count; ++e) dirty[base + incl - count + e] = (int32_t)(c * E + (gen + e) % E);
+}
+
+// opens the old guard of every chain that got new worlds: its env may now walk on into them
+__global__ void mini_world_ring_release_kernel(int64_t n_chains, int episodes, const int32_t* __restrict__ counts,
+                                               const int64_t* __restrict__ first_world, int32_t* __restrict__ next_geom)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chains || counts[c] <= 0) return;
+    const int64_t gen = first_world[c];
+    next_geom[c * episodes + (gen - 1) % episodes] = (int32_t)(c * episodes + gen % episodes);
+}
+
+// initial state of the selected pool entries (make_initial_state, envs/base/env.py:179-214): pose = first way point,
+// everything else zero, reward state from `init`
+__global__ void pool_initial_state_kernel(EntrySelect sel, const double* __restrict__ paths, int max_len,
+                                          const double* __restrict__ init, DevState st)
+{
+    const int64_t total = sel.size();
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = sel.entry(it);
+        const double* p = paths + g * (int64_t)max_len * 3;
+        st.x[g] = p[0];
+        st.y[g] = p[1];
+        st.angle[g] = p[2];
+        st.v[g] = 0.0;
+        st.w[g] = 0.0;
+        if (st.steer) st.steer[g] = 0.0;
+        if (st.wheel) st.wheel[g] = 0.0;
+        st.min_dist[g] = init[2 * g];
+        st.target_idx[g] = (int32_t)init[2 * g + 1];
+        st.cur_iter[g] = 0;
+        st.collided[g] = 0;
+    }
 }
 
 }  // namespace bcp

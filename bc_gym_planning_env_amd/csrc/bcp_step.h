@@ -98,18 +98,29 @@ enum : uint32_t {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup
 
+// Which entries of a non-shared array (costmaps, paths, ...) a set-up kernel derives data for: all n of them, or the
+// *count entries listed in `list` (both on the device: a pool that is topped up between steps, bcp_refresh_mini_worlds).
+// The kernels walk `size() * units-per-entry` work items in a grid-stride loop, so their grids never depend on *count.
+struct EntrySelect {
+    const int32_t* list;
+    const int32_t* count;
+    int64_t n;
+    __device__ __forceinline__ int64_t size() const { return list ? (int64_t)*count : n; }
+    __device__ __forceinline__ int64_t entry(int64_t k) const { return list ? (int64_t)list[k] : k; }
+};
+
 // uint8 costmap -> 1-bit lethal mask.  One thread per 32-bit output word.
-__global__ void pack_bitmap_kernel(const uint8_t* __restrict__ data, uint32_t* __restrict__ bits, int64_t n_maps,
+__global__ void pack_bitmap_kernel(const uint8_t* __restrict__ data, uint32_t* __restrict__ bits, EntrySelect sel,
                                    int rows, int cols, int wpr, const int32_t* __restrict__ valid_rows,
                                    const int32_t* __restrict__ valid_cols)
 {
-    const int64_t total = n_maps * rows * wpr;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int w = (int)(idx % wpr);
-        const int64_t t = idx / wpr;
+    const int64_t total = sel.size() * rows * wpr;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(it % wpr);
+        const int64_t t = it / wpr;
         const int r = (int)(t % rows);
-        const int64_t m = t / rows;
+        const int64_t m = sel.entry(t / rows);
+        const int64_t idx = (m * rows + r) * wpr + w;
         const int vr = valid_rows ? valid_rows[m] : rows;
         const int vc = valid_cols ? valid_cols[m] : cols;
         uint32_t word = 0;
@@ -123,9 +134,11 @@ __global__ void pack_bitmap_kernel(const uint8_t* __restrict__ data, uint32_t* _
 }
 
 // path [.,3] -> [.,5] with cos/sin of the heading (utilities/path_tools.py:405)
-__global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restrict__ out, int64_t total)
+__global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restrict__ out, EntrySelect sel, int max_len)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t total = sel.size() * max_len;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = sel.entry(it / max_len) * max_len + it % max_len;
         const double th = xyt[3 * i + 2];
         out[5 * i + 0] = xyt[3 * i + 0];
         out[5 * i + 1] = xyt[3 * i + 1];
@@ -138,11 +151,9 @@ __global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restr
 constexpr int kPathBuckets = 64;
 
 // Per path: bounding box of the way points and a 1-D bucket grid per axis over [min - sp, max + sp].
-__global__ void path_bbox_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
-                                 int64_t n_paths, double sp_prune, double* __restrict__ bbox)
+__device__ __forceinline__ void path_bbox_one(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
+                                              int64_t p, double sp_prune, double* __restrict__ bbox)
 {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_paths) return;
     const int m = lens ? lens[p] : max_len;
     const double* q = xyt + p * (int64_t)max_len * 3;
     double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
@@ -165,15 +176,21 @@ __global__ void path_bbox_kernel(const double* __restrict__ xyt, const int32_t* 
     o[7] = 1.0 / wy;
 }
 
+__global__ void path_bbox_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
+                                 EntrySelect sel, double sp_prune, double* __restrict__ bbox)
+{
+    const int64_t total = sel.size();
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x)
+        path_bbox_one(xyt, lens, max_len, sel.entry(it), sp_prune, bbox);
+}
+
 // index[p][axis][b] = {first, last} way point whose coordinate lies within sp of bucket b (widened by a guard band
 // that swallows the rounding of the bucket computation); {32767, -1} when there is none.  Any way point with
 // |x_j - x| <= sp_prune for a query x that falls into bucket b is inside [first, last].
-__global__ void path_index_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
-                                  int64_t n_paths, double sp_prune, const double* __restrict__ bbox,
-                                  int16_t* __restrict__ index)
+__device__ __forceinline__ void path_index_one(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
+                                               int64_t t, double sp_prune, const double* __restrict__ bbox,
+                                               int16_t* __restrict__ index)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_paths * 2 * kPathBuckets) return;
     const int b = (int)(t % kPathBuckets);
     const int axis = (int)((t / kPathBuckets) % 2);
     const int64_t p = t / (2 * kPathBuckets);
@@ -192,6 +209,16 @@ __global__ void path_index_kernel(const double* __restrict__ xyt, const int32_t*
     }
     index[2 * t] = (int16_t)first;
     index[2 * t + 1] = (int16_t)last;
+}
+
+__global__ void path_index_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
+                                  EntrySelect sel, double sp_prune, const double* __restrict__ bbox,
+                                  int16_t* __restrict__ index)
+{
+    const int64_t total = sel.size() * 2 * kPathBuckets;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x)
+        path_index_one(xyt, lens, max_len, sel.entry(it / (2 * kPathBuckets)) * (2 * kPathBuckets) + it % (2 * kPathBuckets),
+                       sp_prune, bbox, index);
 }
 
 // find_last_reached restricted to j >= target (utilities/path_tools.py:408-448): the reward only asks whether the

@@ -96,10 +96,22 @@ struct bcp_handle {
     int32_t n_geoms;          // > 0: geometry pool of that many entries
     int32_t* geom_of_env;     // caller-owned device int32 [n]
     const int32_t* next_geom; // caller-owned device int32 [n_geoms] or nullptr
+    const double* path_src;   // caller-owned way points [.,max_len,3] as given to bcp_set_paths
+    int32_t* ring;            // owned scratch of bcp_refresh_mini_worlds
+    size_t ring_bytes;
+    int32_t ring_episodes;    // of the last bcp_plan_mini_worlds
+    bool ring_planned, ring_refreshed;   // plan -> refresh -> release, in that order
 };
 
 // number of entries of a non-shared map / path / initial-state array
 static int64_t n_slots(const bcp_handle* h) { return h->n_geoms > 0 ? h->n_geoms : h->n; }
+
+// grid of a grid-stride kernel; a selection's size is only known on the device, so those launches get a chip-filling
+// grid that does not grow with the upper bound
+static unsigned stride_grid(int64_t work_items, int threads, bool selection = false)
+{
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((work_items + threads - 1) / threads, selection ? 4096 : 65536));
+}
 
 static DevState to_dev_state(const bcp_state* s)
 {
@@ -330,14 +342,10 @@ __global__ void __launch_bounds__(kBlock) pixel_footprint_thread_kernel(DevParam
 // ---- Euclidean distance transform of the lethal cells over the padded map(s) (classify(), bcp_coop.h) ----------
 // Distances are only ever compared with thresholds <= `clamp`, so the transform is exact up to `clamp` and
 // saturates there.  pass 1: per padded column, vertical distance to the nearest lethal cell of that column.
-__global__ void edt_columns_kernel(const uint32_t* __restrict__ bits, int64_t n_maps, int rows, int cols, int wpr, int pad,
-                                   int clamp, uint8_t* __restrict__ g)
+__device__ __forceinline__ void edt_column(const uint32_t* __restrict__ bits, int64_t m, int cp, int rows, int cols, int wpr,
+                                           int pad, int clamp, uint8_t* __restrict__ g)
 {
     const int W = cols + 2 * pad, H = rows + 2 * pad;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_maps * W) return;
-    const int cp = (int)(t % W);
-    const int64_t m = t / W;
     const int c = cp - pad;
     const uint32_t* mb = bits + m * (int64_t)rows * wpr;
     uint8_t* mg = g + m * (int64_t)W * H;
@@ -358,12 +366,18 @@ __global__ void edt_columns_kernel(const uint32_t* __restrict__ bits, int64_t n_
     }
 }
 
-// pass 2: d^2(r,c) = min over |c - c'| < clamp of (c - c')^2 + g(r,c')^2, stored as floor(min(clamp, d)).
-__global__ void edt_rows_kernel(const uint8_t* __restrict__ g, int64_t n_maps, int W, int H, int clamp,
-                                uint8_t* __restrict__ out)
+__global__ void edt_columns_kernel(const uint32_t* __restrict__ bits, EntrySelect sel, int rows, int cols, int wpr, int pad,
+                                   int clamp, uint8_t* __restrict__ g)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_maps * (int64_t)W * H) return;
+    const int W = cols + 2 * pad;
+    const int64_t total = sel.size() * W;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+        edt_column(bits, sel.entry(t / W), (int)(t % W), rows, cols, wpr, pad, clamp, g);
+}
+
+// pass 2: d^2(r,c) = min over |c - c'| < clamp of (c - c')^2 + g(r,c')^2, stored as floor(min(clamp, d)).
+__device__ __forceinline__ void edt_cell(const uint8_t* __restrict__ g, int64_t idx, int W, int clamp, uint8_t* __restrict__ out)
+{
     const int cp = (int)(idx % W);
     const uint8_t* row = g + (idx - cp);
     int best = clamp * clamp;
@@ -377,6 +391,14 @@ __global__ void edt_rows_kernel(const uint8_t* __restrict__ g, int64_t n_maps, i
     while (sq * sq > best) --sq;
     while ((sq + 1) * (sq + 1) <= best) ++sq;
     out[idx] = (uint8_t)min(sq, clamp);
+}
+
+__global__ void edt_rows_kernel(const uint8_t* __restrict__ g, EntrySelect sel, int W, int H, int clamp,
+                                uint8_t* __restrict__ out)
+{
+    const int64_t per = (int64_t)W * H, total = sel.size() * per;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x)
+        edt_cell(g, sel.entry(it / per) * per + it % per, W, clamp, out);
 }
 
 __global__ void normalize_angle_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n)
@@ -652,6 +674,7 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->dev_static) (void)hipFree(h->dev_static);
     if (h->ego_bins) (void)hipFree(h->ego_bins);
     if (h->ego_order) (void)hipFree(h->ego_order);
+    if (h->ring) (void)hipFree(h->ring);
     delete h;
     return BCP_OK;
 }
@@ -705,6 +728,36 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
     }
 }
 
+// Derived map data (1-bit lethal mask, distance field) and path data (cos/sin columns, bounding boxes, bucket index)
+// of the selected entries; `max_entries` bounds sel.size() and only sizes the grids.
+static void launch_pack_bitmap(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
+{
+    const MapDesc& m = h->map;
+    hipLaunchKernelGGL(pack_bitmap_kernel, dim3(stride_grid(max_entries * m.rows * m.wpr, 256, sel.list != nullptr)), dim3(256), 0, s, h->map_data,
+                       h->bitmap, sel, m.rows, m.cols, m.wpr, h->map_valid_rows, h->map_valid_cols);
+}
+
+static void launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
+{
+    const MapDesc& m = h->map;
+    const CullDesc& C = h->cull;
+    hipLaunchKernelGGL(edt_columns_kernel, dim3(stride_grid(max_entries * C.width, 64, sel.list != nullptr)), dim3(64), 0, s, h->bitmap, sel, m.rows,
+                       m.cols, m.wpr, C.pad, C.clamp, h->edt_col);
+    hipLaunchKernelGGL(edt_rows_kernel, dim3(stride_grid(max_entries * C.width * C.height, 256, sel.list != nullptr)), dim3(256), 0, s, h->edt_col,
+                       sel, C.width, C.height, C.clamp, h->edt);
+}
+
+static void launch_path_data(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
+{
+    const PathDesc& p = h->path;
+    hipLaunchKernelGGL(path_trig_kernel, dim3(stride_grid(max_entries * p.max_len, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src, h->path5,
+                       sel, p.max_len);
+    hipLaunchKernelGGL(path_bbox_kernel, dim3(stride_grid(max_entries, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src, p.lens, p.max_len,
+                       sel, h->dev.sp_prune, h->path_bbox);
+    hipLaunchKernelGGL(path_index_kernel, dim3(stride_grid(max_entries * 2 * kPathBuckets, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src,
+                       p.lens, p.max_len, sel, h->dev.sp_prune, h->path_bbox, h->path_index);
+}
+
 extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows, int32_t cols, int32_t shared,
                                 const int32_t* valid_rows, const int32_t* valid_cols, const double* origins,
                                 int32_t origins_per_env, double resolution, void* stream)
@@ -725,12 +778,6 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
         HIP_TRY(hipMalloc((void**)&h->bitmap, bytes));
         h->bitmap_bytes = bytes;
     }
-    const int64_t total = n_maps * rows * wpr;
-    const int threads = 256;
-    const int blocks = (int)std::min<int64_t>((total + threads - 1) / threads, 65536);
-    hipLaunchKernelGGL(pack_bitmap_kernel, dim3(blocks), dim3(threads), 0, s, data, h->bitmap, n_maps, rows, cols, wpr,
-                       valid_rows, valid_cols);
-    HIP_TRY(hipGetLastError());
     h->resolution = resolution;
     h->map_data = data;
     h->map_valid_rows = valid_rows;
@@ -755,6 +802,9 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
     // stage the shared bitmap in LDS when the whole collision scratch then stays within 64 KiB per workgroup
     m.in_lds = (shared && collision_lds_bytes(h->params.n_verts, 1, rows, wpr) <= 64 * 1024) ? 1 : 0;
     h->wide = footprint_is_wide(h->params, resolution);
+    const EntrySelect all_maps = {nullptr, nullptr, n_maps};
+    launch_pack_bitmap(h, all_maps, n_maps, s);
+    HIP_TRY(hipGetLastError());
     // distance field for the O(1) pre-classification (shared maps)
     CullDesc& C = h->cull;
     memset(&C, 0, sizeof(C));
@@ -781,17 +831,14 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
             HIP_TRY(hipMalloc((void**)&h->edt_col, cells));
             h->edt_col_bytes = cells;
         }
-        const int64_t n_cols_total = n_maps * W;
-        hipLaunchKernelGGL(edt_columns_kernel, dim3((unsigned)((n_cols_total + 63) / 64)), dim3(64), 0, s, h->bitmap, n_maps,
-                           rows, cols, wpr, C.pad, clamp, h->edt_col);
-        hipLaunchKernelGGL(edt_rows_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, h->edt_col, n_maps, W, H,
-                           clamp, h->edt);
-        HIP_TRY(hipGetLastError());
         C.edt = h->edt;
         C.width = W;
         C.height = H;
+        C.clamp = clamp;
         C.env_stride = shared ? 0 : (int64_t)W * H;
         C.on = C.t_out <= clamp ? 1 : 0;
+        launch_distance_field(h, all_maps, n_maps, s);
+        HIP_TRY(hipGetLastError());
         if (!h->pending) {
             const int64_t blocks = (h->n + kBlock - 1) / kBlock;
             h->pending_cap = (int32_t)(((blocks + kShards - 1) / kShards) * kBlock);  // every env of a shard's blocks
@@ -828,10 +875,6 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
         HIP_TRY(hipMalloc((void**)&h->path5, bytes));
         h->path5_bytes = bytes;
     }
-    const int threads = 256;
-    const int blocks = (int)std::min<int64_t>((total + threads - 1) / threads, 65536);
-    hipLaunchKernelGGL(path_trig_kernel, dim3(blocks), dim3(threads), 0, s, xytheta, h->path5, total);
-    HIP_TRY(hipGetLastError());
     const int64_t n_paths = shared ? 1 : n_slots(h);
     const size_t bb_bytes = (size_t)n_paths * 8 * sizeof(double);
     if (bb_bytes > h->path_bbox_bytes) {
@@ -850,18 +893,16 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
         h->path_index_bytes = ix_bytes;
     }
     if (max_len > 32766) return fail(BCP_E_INVALID, "bcp_set_paths: paths longer than 32766 way points are not supported");
-    hipLaunchKernelGGL(path_bbox_kernel, dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, s, xytheta,
-                       shared ? nullptr : lens, max_len, n_paths, h->dev.sp_prune, h->path_bbox);
-    const int64_t n_idx = n_paths * 2 * kPathBuckets;
-    hipLaunchKernelGGL(path_index_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, s, xytheta,
-                       shared ? nullptr : lens, max_len, n_paths, h->dev.sp_prune, h->path_bbox, h->path_index);
-    HIP_TRY(hipGetLastError());
     h->path.pts = h->path5;
     h->path.bbox = h->path_bbox;
     h->path.index = h->path_index;
     h->path.lens = shared ? nullptr : lens;
     h->path.max_len = max_len;
     h->path.shared = shared ? 1 : 0;
+    h->path_src = xytheta;
+    const EntrySelect all_paths = {nullptr, nullptr, n_paths};
+    launch_path_data(h, all_paths, n_paths, s);
+    HIP_TRY(hipGetLastError());
     h->have_path = true;
     h->static_dirty = true;
     return BCP_OK;
@@ -1368,12 +1409,10 @@ extern "C" int bcp_mini_world_seed(bcp_handle* h, const int64_t* seeds, int64_t 
     return BCP_OK;
 }
 
-extern "C" int bcp_sample_mini_worlds(bcp_handle* h, const bcp_mini_world_params* p, uint32_t* mt_state, int64_t n_chains,
-                                      int32_t episodes, int32_t rows, int32_t cols, double* worlds, uint8_t* maps,
-                                      int32_t* status, void* stream)
+static int sample_mini_worlds(bcp_handle* h, const bcp_mini_world_params* p, uint32_t* mt_state, int64_t n_chains,
+                              int32_t episodes, int32_t rows, int32_t cols, const int32_t* counts, const int64_t* first_world,
+                              double* worlds, uint8_t* maps, int32_t* status, void* stream)
 {
-    if (!h || !p || !mt_state || !worlds || !maps || !status || n_chains <= 0 || episodes <= 0)
-        return fail(BCP_E_INVALID, "bcp_sample_mini_worlds: bad argument");
     if (!(p->resolution > 0) || !check_kernel_size(h->params, p->resolution))
         return fail(BCP_E_INVALID, "bcp_sample_mini_worlds: bad resolution for this footprint");
     if ((int)(0.05 / p->resolution) > 1)   // Wall.render: thickness = max(1, int(width / resolution))
@@ -1401,9 +1440,112 @@ extern "C" int bcp_sample_mini_worlds(bcp_handle* h, const bcp_mini_world_params
     mp.goal_spat_dist = p->goal_spat_dist;
     mp.goal_ang_dist = p->goal_ang_dist;
     hipLaunchKernelGGL(mini_world_sample_kernel, dim3((unsigned)n_chains), dim3(64), lds, (hipStream_t)stream, P, mp, mt_state,
-                       n_chains, (int)episodes, (int)rows, (int)cols, footprint_is_wide(h->params, p->resolution), worlds, maps,
-                       status);
+                       n_chains, (int)episodes, (int)rows, (int)cols, footprint_is_wide(h->params, p->resolution), counts,
+                       first_world, worlds, maps, status);
     HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+extern "C" int bcp_sample_mini_worlds(bcp_handle* h, const bcp_mini_world_params* p, uint32_t* mt_state, int64_t n_chains,
+                                      int32_t episodes, int32_t rows, int32_t cols, double* worlds, uint8_t* maps,
+                                      int32_t* status, void* stream)
+{
+    if (!h || !p || !mt_state || !worlds || !maps || !status || n_chains <= 0 || episodes <= 0)
+        return fail(BCP_E_INVALID, "bcp_sample_mini_worlds: bad argument");
+    return sample_mini_worlds(h, p, mt_state, n_chains, episodes, rows, cols, nullptr, nullptr, worlds, maps, status, stream);
+}
+
+static int check_ring(const bcp_handle* h, int32_t episodes, const char* who)
+{
+    if (episodes < 2 || h->n_geoms <= 0 || (int64_t)h->n_geoms != h->n * episodes || !h->next_geom)
+        return fail(BCP_E_STATE, "%s: needs a geometry pool of n_envs x episodes (>= 2) entries with next_geom", who);
+    if (!h->have_map || !h->have_path || !h->have_init || h->map.shared || h->path.shared || h->map_valid_rows ||
+        h->map_valid_cols)
+        return fail(BCP_E_STATE, "%s: pool costmaps, paths and initial state must be set first", who);
+    return BCP_OK;
+}
+
+extern "C" int bcp_plan_mini_worlds(bcp_handle* h, int32_t episodes, int64_t* generated, int32_t* info, void* stream)
+{
+    if (!h || !generated || !info) return fail(BCP_E_INVALID, "bcp_plan_mini_worlds: null argument");
+    const int rc = check_ring(h, episodes, "bcp_plan_mini_worlds");
+    if (rc != BCP_OK) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = h->n, G = h->n_geoms;
+    const size_t bytes = (size_t)n * sizeof(int64_t) + (size_t)(n + G + 4) * sizeof(int32_t);
+    if (bytes > h->ring_bytes) {
+        if (h->ring) HIP_TRY(hipFree(h->ring));
+        h->ring = nullptr;
+        h->ring_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&h->ring, bytes));
+        h->ring_bytes = bytes;
+    }
+    int64_t* first_world = (int64_t*)h->ring;
+    int32_t* counts = (int32_t*)(first_world + n);
+    int32_t* dirty = counts + n;
+    int32_t* tally = dirty + G;
+    HIP_TRY(hipMemsetAsync(tally, 0, 4 * sizeof(int32_t), s));
+    hipLaunchKernelGGL(mini_world_ring_plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, (int)episodes,
+                       h->geom_of_env, const_cast<int32_t*>(h->next_geom), generated, counts, first_world, dirty, tally);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(info, tally, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    h->ring_episodes = episodes;
+    h->ring_planned = true;
+    return BCP_OK;
+}
+
+extern "C" int bcp_refresh_mini_worlds(bcp_handle* h, const bcp_mini_world_params* p, uint32_t* mt_state, double* worlds,
+                                       uint8_t* maps, double* paths, int32_t* lens, double* init, double path_delta,
+                                       int32_t* status, int32_t* path_status, void* stream)
+{
+    if (!h || !p || !mt_state || !worlds || !maps || !paths || !lens || !init || !status || !path_status || !(path_delta > 0))
+        return fail(BCP_E_INVALID, "bcp_refresh_mini_worlds: bad argument");
+    if (!h->ring_planned) return fail(BCP_E_STATE, "bcp_refresh_mini_worlds: call bcp_plan_mini_worlds first");
+    const int32_t episodes = h->ring_episodes;
+    const int rc0 = check_ring(h, episodes, "bcp_refresh_mini_worlds");
+    if (rc0 != BCP_OK) return rc0;
+    if (maps != h->map_data || paths != h->path_src || lens != h->path.lens)
+        return fail(BCP_E_INVALID, "bcp_refresh_mini_worlds: maps / paths / lens are not the arrays this handle was given");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = h->n, G = h->n_geoms;
+    const int64_t* first_world = (const int64_t*)h->ring;
+    const int32_t* counts = (const int32_t*)(first_world + n);
+    const int32_t* dirty = counts + n;
+    const int32_t* tally = dirty + G;
+    const int rc = sample_mini_worlds(h, p, mt_state, n, episodes, h->map.rows, h->map.cols, counts, first_world, worlds, maps,
+                                      status, stream);
+    if (rc != BCP_OK) return rc;
+    const EntrySelect sel = {dirty, tally, G};
+    hipLaunchKernelGGL(mini_world_paths_kernel, dim3(stride_grid(G, 128, true)), dim3(128), 0, s, worlds, sel, path_delta,
+                       h->params.spatial_precision, h->params.angular_precision,
+                       (int)(h->params.reward_provider == BCP_REWARD_PURE_PURSUIT), (int)h->path.max_len, paths, lens, init,
+                       path_status);
+    launch_pack_bitmap(h, sel, G, s);
+    if (h->cull.edt) launch_distance_field(h, sel, G, s);
+    launch_path_data(h, sel, G, s);
+    hipLaunchKernelGGL(pool_initial_state_kernel, dim3(stride_grid(G, 256, true)), dim3(256), 0, s, sel, paths,
+                       (int)h->path.max_len, init, h->init);
+    HIP_TRY(hipGetLastError());
+    h->ring_planned = false;
+    h->ring_refreshed = true;
+    return BCP_OK;
+}
+
+extern "C" int bcp_release_mini_worlds(bcp_handle* h, void* stream)
+{
+    if (!h) return fail(BCP_E_INVALID, "bcp_release_mini_worlds: null handle");
+    if (!h->ring || !h->ring_refreshed || (int64_t)h->n_geoms != h->n * h->ring_episodes || !h->next_geom)
+        return fail(BCP_E_STATE, "bcp_release_mini_worlds: no bcp_refresh_mini_worlds to complete");
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t n = h->n;
+    const int64_t* first_world = (const int64_t*)h->ring;
+    const int32_t* counts = (const int32_t*)(first_world + n);
+    hipLaunchKernelGGL(mini_world_ring_release_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n,
+                       (int)h->ring_episodes, counts, first_world, const_cast<int32_t*>(h->next_geom));
+    HIP_TRY(hipGetLastError());
+    h->ring_refreshed = false;
     return BCP_OK;
 }
 
@@ -1413,8 +1555,9 @@ extern "C" int bcp_mini_world_paths(bcp_handle* h, const double* worlds, int64_t
     if (!h || !worlds || !paths || !lens || !init || !status || n_worlds <= 0 || max_len < 2 || !(path_delta > 0))
         return fail(BCP_E_INVALID, "bcp_mini_world_paths: bad argument");
     HIP_TRY(hipSetDevice(h->device));
-    hipLaunchKernelGGL(mini_world_paths_kernel, dim3((unsigned)((n_worlds + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
-                       worlds, n_worlds, path_delta, h->params.spatial_precision, h->params.angular_precision,
+    const EntrySelect all = {nullptr, nullptr, n_worlds};
+    hipLaunchKernelGGL(mini_world_paths_kernel, dim3(stride_grid(n_worlds, 128)), dim3(128), 0, (hipStream_t)stream, worlds, all,
+                       path_delta, h->params.spatial_precision, h->params.angular_precision,
                        (int)(h->params.reward_provider == BCP_REWARD_PURE_PURSUIT), (int)max_len, paths, lens, init, status);
     HIP_TRY(hipGetLastError());
     return BCP_OK;

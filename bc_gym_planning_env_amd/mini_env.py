@@ -389,10 +389,12 @@ class DeviceMiniEnvPool(DeviceGeometryPool):
     """A MiniEnvPool that never leaves the GPU: worlds, costmaps, refined paths and initial reward states as device
     tensors (sample_pool_device(..., keep_on_device=True)).  `worlds` / `costmaps` / `paths` download on demand."""
 
-    def __init__(self, params, seeds, episodes, worlds, maps, origin, paths, lens, init):
+    def __init__(self, params, seeds, episodes, worlds, maps, origin, paths, lens, init, mt_state=None, sampler_params=None):
         super(DeviceMiniEnvPool, self).__init__(maps, origin, params.env_params.resolution, paths, lens, init)
         self.params, self.seeds, self.episodes = params, list(seeds), int(episodes)
         self.world_params = worlds        # float64 [G, 14]
+        self.mt_state = mt_state          # int32 [chains, 625]: where every MT19937 stream stands (after `generated` worlds)
+        self.sampler_params = sampler_params   # the BcpMiniWorldParams the worlds were drawn with
         g = np.arange(len(self), dtype=np.int32)
         self.next_geom = ((g // self.episodes) * self.episodes + (g % self.episodes + 1) % self.episodes).astype(np.int32)
 
@@ -460,7 +462,7 @@ def sample_pool_device(params=None, seeds=(0,), episodes=1, device=0, keep_on_de
                 raise ValueError("Goal pose too close to initial pose")
             assert worst == 0, "refined path longer than expected"
             return DeviceMiniEnvPool(params, seeds, episodes, worlds, maps, np.array([-side_h / 2., -side_w / 2.]), paths,
-                                     lens, init)
+                                     lens, init, mt_state=mt, sampler_params=mp)
         w_host, m_host = worlds.cpu().numpy(), maps.cpu().numpy()
     finally:
         lib.bcp_destroy(h)
@@ -488,12 +490,21 @@ class BatchedRandomMiniEnv(BatchedPlanEnv):
         reference's), "device_resident" (the same, and the pool never leaves the GPU: for 10^5 .. 10^6 worlds) or
         "host" (sample_pool: numpy, bit-identical to the reference, ~3 x 10^3 worlds/s)
     :param draw_new_turn_on_reset bool: False keeps every env on its first world (RandomMiniEnv's flag of that name)
+    :param endless bool: one stream per env (seeds[i] or i), pool kept on the GPU, and the `episodes` entries of an env
+        are a ring over its stream that refresh() tops up behind it: env i sees the worlds of RandomMiniEnv(seed=seeds[i])
+        for as long as it runs, never an old one again.  Call refresh() every few steps (see there).
     Remaining keyword arguments go to BatchedPlanEnv (auto_reset, seed, noise_parameters, env_id_base, ...).
     """
 
     def __init__(self, n_envs, params=None, pool=None, seeds=None, n_chains=None, episodes=4, device=0,
-                 draw_new_turn_on_reset=True, sampler="device", **kw):
+                 draw_new_turn_on_reset=True, sampler="device", endless=False, **kw):
         params = default_random_mini_env_params() if params is None else params
+        if endless:
+            if pool is not None or n_chains not in (None, int(n_envs)) or not draw_new_turn_on_reset or episodes < 2:
+                raise ValueError("endless=True samples its own pool: one stream per env, episodes >= 2")
+            sampler, seeds = "device_resident", (range(int(n_envs)) if seeds is None else seeds)
+            if len(list(seeds)) != int(n_envs):
+                raise ValueError("endless=True needs one seed per env")
         if pool is None:
             if seeds is None:
                 seeds = range(int(n_chains) if n_chains else min(int(n_envs), 1024))
@@ -506,6 +517,92 @@ class BatchedRandomMiniEnv(BatchedPlanEnv):
         geom = (i % chains) * per + (i // chains) % per
         self.pool = pool
         on_device = isinstance(pool, DeviceGeometryPool)
+        next_geom = pool.next_geom if draw_new_turn_on_reset else None
+        self.endless = bool(endless)
+        if endless:   # the newest world's entry is the ring's guard (bcp_refresh_mini_worlds)
+            next_geom = next_geom.copy()
+            newest = np.arange(chains) * per + per - 1
+            next_geom[newest] = newest
         super(BatchedRandomMiniEnv, self).__init__(
             pool if on_device else pool.costmaps, None if on_device else pool.paths, params.env_params, n_envs=n_envs,
-            device=device, geom_of_env=geom, next_geom=pool.next_geom if draw_new_turn_on_reset else None, **kw)
+            device=device, geom_of_env=geom, next_geom=next_geom, **kw)
+        if endless:
+            dev = self.device
+            self._generated = torch.full((chains,), per, dtype=torch.int64, device=dev)
+            self._ring_status = torch.zeros(chains, dtype=torch.int32, device=dev)
+            self._ring_path_status = torch.zeros(chains * per, dtype=torch.int32, device=dev)
+            self._ring_info = torch.zeros(4, dtype=torch.int32, device=dev)
+            self._ring_info_done = torch.zeros(4, dtype=torch.int32, device=dev)
+            self._ring_side, self._ring_pending = None, False
+
+    def refresh(self, check=False, overlap=False):
+        """endless=True: re-sample, on the GPU and in stream order, the pool entries of the worlds every env has left
+        (bcp_plan_mini_worlds, bcp_refresh_mini_worlds, bcp_release_mini_worlds) -- RandomMiniEnv.reset's `_sample_mini_env_params`
+        (envs/mini_env.py:441-459), done ahead of time.  Call it between steps.  An env can go through at most
+        `episodes - 1` resets between two refreshes before it has to repeat its newest world; info[1] counts the envs
+        that were found waiting like that.
+
+        overlap=False: everything on the current stream, in order (a refresh takes milliseconds: sampling a world is a
+        serial job for one wavefront, however few worlds there are).
+        overlap=True: the sampling runs on a side stream WHILE the steps go on: this call completes the previous refresh
+        -- its worlds come into reach from the next step on -- and starts the next one.  Nothing blocks on the host; on
+        the GPU the steps wait for a previous refresh that has not finished yet, so call it every few hundred steps
+        (a refresh takes 2 .. 10 ms) and size `episodes` so that no env gets through `episodes - 1` worlds during two
+        such periods.
+
+        :param check bool: wait for the refresh to finish and raise what the reference's sampler would raise
+        :return: device int32 [4] = (entries re-sampled, envs that were waiting on their newest world, 0, 0) of the
+            refresh that was completed by this call; with check=True the first two as python ints"""
+        if not self.endless:
+            raise RuntimeError("refresh() needs BatchedRandomMiniEnv(endless=True)")
+        main = torch.cuda.current_stream(self.device)
+        if overlap:
+            if self._ring_side is None:
+                self._ring_side = torch.cuda.Stream(self.device)
+                self._ring_done, self._ring_go = torch.cuda.Event(), torch.cuda.Event()
+            done = self.finish_refresh(check)
+            self._plan_refresh(main)
+            self._ring_go.record(main)
+            self._ring_side.wait_event(self._ring_go)
+            self._launch_refresh(self._ring_side)
+            self._ring_done.record(self._ring_side)
+            return done
+        self.finish_refresh()
+        self._plan_refresh(main)
+        self._launch_refresh(main)
+        return self.finish_refresh(check)
+
+    def _plan_refresh(self, stream):
+        _lib.check(self._lib.bcp_plan_mini_worlds(self._h, self.pool.episodes, self._generated.data_ptr(),
+                                                  self._ring_info.data_ptr(), C.c_void_p(stream.cuda_stream)))
+        self._ring_pending = True
+
+    def _launch_refresh(self, stream):
+        pool, ep = self.pool, self.params
+        _lib.check(self._lib.bcp_refresh_mini_worlds(
+            self._h, C.byref(pool.sampler_params), pool.mt_state.data_ptr(), pool.world_params.data_ptr(),
+            pool.maps.data_ptr(), pool.path_points.data_ptr(), pool.lens.data_ptr(), pool.init.data_ptr(),
+            float(ep.path_delta), self._ring_status.data_ptr(), self._ring_path_status.data_ptr(),
+            C.c_void_p(stream.cuda_stream)))
+
+    def finish_refresh(self, check=False):
+        """Complete the refresh in flight, if any: wait (on the current stream) for its side stream and open the ring to
+        the new worlds.  refresh() does this itself; call it before reading pool tensors or taking snapshots."""
+        if not self._ring_pending:
+            return None
+        main = torch.cuda.current_stream(self.device)
+        if self._ring_side is not None:
+            main.wait_event(self._ring_done)
+        _lib.check(self._lib.bcp_release_mini_worlds(self._h, C.c_void_p(main.cuda_stream)))
+        self._ring_info_done.copy_(self._ring_info)   # (the plan's tally: the next plan overwrites _ring_info)
+        self._ring_pending = False
+        if not check:
+            return self._ring_info_done
+        if int(self._ring_status.sum()):
+            raise ValueError("Something went wrong, the sampling space looks empty.")
+        worst = int(self._ring_path_status.max())
+        if worst == 2:
+            raise ValueError("Goal pose too close to initial pose")
+        assert worst == 0, "refined path longer than expected"
+        info = self._ring_info_done.cpu().numpy()
+        return int(info[0]), int(info[1])

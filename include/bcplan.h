@@ -166,6 +166,7 @@ int bcp_set_tuning(bcp_handle *h, int32_t key, int32_t value);
  *                permutation), device memory; NULL = stay on the same entry (draw_new_turn_on_reset=False).
  * Call before the arrays are set (changing the entry count invalidates them); n_geoms = 0 turns the pool off. */
 int bcp_set_geometry_pool(bcp_handle *h, int32_t n_geoms, int32_t *geom_of_env, const int32_t *next_geom);
+/* (bcp_plan_mini_worlds / bcp_release_mini_worlds are the only calls that write next_geom) */
 /* (below, N = n_envs, or n_geoms when a geometry pool is in effect)
  * CostMap2D (utilities/costmap_2d.py:13-37).  data: uint8 [rows, cols] when shared, else [N, rows, cols]
  * (row-major, `rows`/`cols` is the padded allocation).  valid_rows/valid_cols (optional, [N] int32) give each
@@ -273,6 +274,34 @@ int bcp_sample_mini_worlds(bcp_handle *h, const bcp_mini_world_params *p /*host*
  * 0 = ok, 1 = the refined path does not fit max_len, 2 = "Goal pose too close to initial pose". */
 int bcp_mini_world_paths(bcp_handle *h, const double *worlds, int64_t n_worlds, double path_delta, int32_t max_len,
                          double *paths, int32_t *lens, double *init, int32_t *status, void *stream);
+
+/* A pool that never runs out: RandomMiniEnv.reset() draws a NEW world every time (envs/mini_env.py:441-459), a pool
+ * of `episodes` entries per stream would wrap around.  For a handle whose geometry pool has n_envs x episodes entries,
+ * env c on the entries c * episodes .. + episodes - 1 of stream c (mt_state [n_envs][625], worlds / maps / paths / lens
+ * / init as produced by bcp_sample_mini_worlds + bcp_mini_world_paths and handed to bcp_set_costmaps / bcp_set_paths /
+ * bcp_bind_initial_state), three calls top the pool up behind the envs without a host round trip.  World number j of
+ * stream c lives in entry c * episodes + j % episodes; next_geom (the array given to bcp_set_geometry_pool, WRITTEN
+ * here) is a ring with one guard: the entry of the newest world points to itself, so an env that gets there before new
+ * worlds are ready repeats that world instead of wrapping onto an old one (set next_geom[c * episodes + episodes - 1]
+ * to itself before the first step).
+ *   1. bcp_plan_mini_worlds     looks where every env is, marks the entries of the worlds it has left as free and
+ *                               closes the ring behind the last of them (the next guard).
+ *        generated  int64 [n_envs] device, in/out: worlds drawn from each stream so far (`episodes` after the first fill)
+ *        info       int32 [4] device, out: {entries freed, envs found waiting on their guard entry, 0, 0}
+ *   2. bcp_refresh_mini_worlds  samples the next worlds of each stream into the free entries: costmap, path, lens, init
+ *                               and initial state are rewritten in place and the handle's derived data (lethal masks,
+ *                               distance fields, path index) is rebuilt for exactly those entries.
+ *        status  int32 [n_envs]: as bcp_sample_mini_worlds;  path_status int32 [n_envs * episodes]: as bcp_mini_world_paths
+ *   3. bcp_release_mini_worlds  opens the previous guard: the envs can walk on into the new worlds.
+ * 1 and 3 belong on the stream of the steps.  Sampling a world is a latency-bound job for one wavefront (~0.3 ms, with
+ * a long tail), so 2 may run on a SIDE stream while steps go on -- they neither read nor reach an entry that is being
+ * rewritten: make the side stream wait for 1 and the stream of the steps wait for 2 before 3 (events).  With one
+ * plan-refresh-release round per `episodes - 1` episodes of the fastest env no world is ever repeated. */
+int bcp_plan_mini_worlds(bcp_handle *h, int32_t episodes, int64_t *generated, int32_t *info, void *stream);
+int bcp_refresh_mini_worlds(bcp_handle *h, const bcp_mini_world_params *p /*host*/, uint32_t *mt_state, double *worlds,
+                            uint8_t *maps, double *paths, int32_t *lens, double *init, double path_delta, int32_t *status,
+                            int32_t *path_status, void *stream);
+int bcp_release_mini_worlds(bcp_handle *h, void *stream);
 
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* Runs `steps` bcp_step() launches back to back on `stream` bracketed by HIP events recorded on that stream and

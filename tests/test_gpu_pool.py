@@ -243,3 +243,108 @@ def test_device_resident_pool(torch_cuda, oracle):
     st = env.envs[5].get_state()      # host views are fetched on demand
     k = int(env.geom_of_env[5])
     assert (st.costmap.get_data() == maps[k]).all() and (st.original_path == pbuf[k, :lens[k]]).all()
+
+
+def _endless_setup(mini_env, n, episodes, long_episodes, timeout):
+    from bc_gym_planning_env_amd import EnvParams
+    params = mini_env.RandomMiniEnvParams(
+        env_params=EnvParams(goal_ang_dist=np.pi / 8., goal_spat_dist=0.2, iteration_timeout=timeout))
+    seeds = list(range(300, 300 + n))
+    env = mini_env.BatchedRandomMiniEnv(n, params, seeds=seeds, episodes=episodes, endless=True, auto_reset=True, seed=9)
+    # the same streams sampled `long_episodes` worlds deep in one go: world j of stream c is entry c * long_episodes + j
+    deep = mini_env.sample_pool_device(params, seeds, long_episodes, keep_on_device=True)
+    return params, env, deep
+
+
+def _check_ring_entries(env, deep, world_of_env, generated):
+    """every ring entry holds the world of its stream that the bookkeeping says, bit for bit, with its path and reward
+    state; the env sits on the entry of its world"""
+    E, K = env.pool.episodes, deep.episodes
+    pw, dw = env.pool.world_params.cpu().numpy(), deep.world_params.cpu().numpy()
+    pm, dm = env.pool.maps.cpu().numpy(), deep.maps.cpu().numpy()
+    pp, dpth = env.pool.path_points.cpu().numpy(), deep.path_points.cpu().numpy()
+    pl, dl = env.pool.lens.cpu().numpy(), deep.lens.cpu().numpy()
+    pi, di = env.pool.init.cpu().numpy(), deep.init.cpu().numpy()
+    init = env._initial_state
+    ix, imd, iti = init.robot[0:3].cpu().numpy(), init.min_spat_dist_so_far.cpu().numpy(), init.target_idx.cpu().numpy()
+    geom = env.geom_of_env.cpu().numpy()
+    nxt = env._keep["next_geom"].cpu().numpy()
+    for c in range(env.n_envs):
+        assert geom[c] == c * E + world_of_env[c] % E, c
+        for j in range(generated[c] - E, generated[c]):
+            g, d = c * E + j % E, c * K + j
+            assert (pw[g] == dw[d]).all() and (pm[g] == dm[d]).all(), (c, j)
+            assert pl[g] == dl[d] and (pp[g, :pl[g]] == dpth[d, :dl[d]]).all() and (pi[g] == di[d]).all(), (c, j)
+            assert (ix[:, g] == dpth[d, 0]).all() and imd[g] == di[d, 0] and iti[g] == int(di[d, 1]), (c, j)
+            assert nxt[g] == (g if j == generated[c] - 1 else c * E + (j + 1) % E), (c, j)
+
+
+@pytest.mark.parametrize("overlap,E", [(False, 3), (True, 5)], ids=["in-order", "side-stream"])
+def test_endless_pool_follows_the_streams(torch_cuda, overlap, E):
+    """BatchedRandomMiniEnv(endless=True) + refresh(): every env walks through the worlds of its own RandomState
+    stream in order, never an old one again; re-sampled entries (costmap, path, initial state, and the handle's
+    distance fields / path index behind them) make the env step exactly like one built on a pool that holds the
+    whole stream up front.  Both with the sampling in stream order and with it on a side stream under the steps."""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import mini_env
+    n, K = 96, 40
+    params, env, deep = _endless_setup(mini_env, n, E, K, timeout=12)
+    ref = mini_env.BatchedRandomMiniEnv(n, params, pool=deep, auto_reset=True, seed=9)
+    world = np.ones(n, dtype=np.int64)          # both constructors end with the reset() that moves on to world 1
+    generated = np.full(n, E, dtype=np.int64)   # worlds planned so far ...
+    reach = generated.copy()                    # ... and released: an env can be on worlds < reach
+    _check_ring_entries(env, deep, world, generated)
+    rng = np.random.RandomState(2)
+    z = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    resampled, planned = 0, None
+    for t in range(150):
+        a = env.action_space.sample_batch(n, rng)
+        a[:, 0] *= 3.0
+        env.step(a, noise_z_out=z)
+        ref.step(a, noise_z=z)
+        for name in ("reward", "done", "collided_now"):
+            assert torch.equal(getattr(env, name), getattr(ref, name)), (name, t)
+        assert torch.equal(env.state.robot, ref.state.robot) and torch.equal(env.state.target_idx, ref.state.target_idx), t
+        assert torch.equal(env.state.min_spat_dist_so_far, ref.state.min_spat_dist_so_far), t
+        world += env.done.cpu().numpy().astype(np.int64)
+        assert (world <= reach - 1).all() and world.max() < K     # nobody had to wait at a guard
+        if t % 2 == 1:
+            got = env.refresh(check=True, overlap=overlap)
+            now = (int((world - (generated - E)).sum()), int((world == generated - 1).sum()))
+            if overlap:           # this call released the previous round and planned the next one
+                assert got == planned
+                reach = generated.copy()
+                generated, planned = world + E, now
+            else:
+                assert got == now
+                generated = world + E
+                reach = generated.copy()
+            resampled += now[0]
+            if t % 20 == 19:
+                env.finish_refresh(check=True)
+                reach, planned = generated.copy(), None
+                _check_ring_entries(env, deep, world, generated)
+    env.finish_refresh(check=True)
+    _check_ring_entries(env, deep, world, generated)
+    assert resampled > 5 * n and world.min() >= 5
+
+
+def test_endless_pool_guard_holds_envs_back(torch_cuda):
+    """without refresh() an env never wraps onto an old world: it repeats its newest one; the next refresh() reports it
+    and the stream goes on"""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import mini_env
+    n, E, K = 8, 2, 6
+    params, env, deep = _endless_setup(mini_env, n, E, K, timeout=3)
+    a = np.zeros((n, 2))
+    for _ in range(10):                         # three timeouts, no refresh: everybody stays on world 1
+        env.step(a)
+    assert (env.geom_of_env.cpu().numpy() == np.arange(n) * E + 1).all()
+    assert env.refresh(check=True) == (n, n)    # world 2 replaces world 0 behind every env
+    world, generated = np.ones(n, dtype=np.int64), np.full(n, E + 1, dtype=np.int64)
+    _check_ring_entries(env, deep, world, generated)
+    for _ in range(3):
+        env.step(a)
+    _check_ring_entries(env, deep, world + 1, generated)
+    with pytest.raises(RuntimeError):
+        mini_env.BatchedRandomMiniEnv(4, params, n_chains=4, episodes=2).refresh()

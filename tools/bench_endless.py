@@ -1,0 +1,70 @@
+"""Endless geometry pool (BatchedRandomMiniEnv(endless=True)): step rate with refresh() every R steps, and what one
+refresh costs.  Usage: python tools/bench_endless.py [n_envs] [episodes] [refresh_every] [steps]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bc_gym_planning_env_amd import mini_env  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+episodes = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+every = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
+
+t0 = time.time()
+env = mini_env.BatchedRandomMiniEnv(n, episodes=episodes, endless=True, auto_reset=True, seed=1)
+torch.cuda.synchronize()
+print("setup: %d envs x %d entries in %.2f s" % (n, episodes, time.time() - t0), flush=True)
+g = torch.Generator(device="cuda").manual_seed(0)
+acts = [torch.rand(n, 2, device="cuda", generator=g, dtype=torch.float64) * torch.tensor([1.0, 1.0], device="cuda",
+        dtype=torch.float64) - torch.tensor([0.0, 0.5], device="cuda", dtype=torch.float64) for _ in range(16)]
+dones = torch.zeros(n, dtype=torch.int64, device="cuda")
+for k in range(64):       # warm-up: spread the envs over their episodes
+    env.step(acts[k % 16])
+    if k % every == every - 1:
+        env.refresh()
+torch.cuda.synchronize()
+for label, do_refresh, overlap in (("step only (envs run into their guards)", False, False),
+                                   ("step + refresh in stream order", True, False),
+                                   ("step + refresh on a side stream", True, True)):
+    new = waiting = 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    infos = []
+    dones.zero_()
+    e0.record()
+    for k in range(steps):
+        env.step(acts[k % 16])
+        dones += env.done
+        if do_refresh and k % every == every - 1:
+            info = env.refresh(overlap=overlap)
+            if info is not None:
+                infos.append(info.clone())
+    env.finish_refresh()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    if infos:
+        inf = torch.stack(infos).cpu().numpy()
+        new, waiting = int(inf[:, 0].sum()), int(inf[:, 1].sum())
+    print("%-42s %.4f ms/step  %.3g env-steps/s  episodes ended %d  refreshes %d  worlds re-sampled %d  "
+          "waiting-at-guard sightings %d" % (label, ms / steps, n * steps / ms * 1e3, int(dones.sum()), len(infos), new,
+                                             waiting), flush=True)
+# one refresh in isolation, after `every` steps
+ts = []
+for rep in range(10):
+    for k in range(every):
+        env.step(acts[k % 16])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    info = env.refresh()
+    e1.record()
+    torch.cuda.synchronize()
+    ts.append((e0.elapsed_time(e1), int(info[0])))
+ms = np.median([t for t, _ in ts])
+cnt = np.median([c for _, c in ts])
+print("one refresh after %d steps: %.3f ms for ~%d worlds (%.3g worlds/s)" % (every, ms, cnt, cnt / ms * 1e3))
+print("status ok:", int(env._ring_status.sum()) == 0, int(env._ring_path_status.max()) == 0)
