@@ -12,7 +12,7 @@ MODEL_TRICYCLE, MODEL_DIFFDRIVE = 0, 1
 REWARD_CONTINUOUS, REWARD_PURE_PURSUIT = 0, 1
 STEP_AUTO_RESET, STEP_ACTIONS_F32 = 1, 2
 ERR_ANGLE_JUMP = 1
-TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL, TUNE_DEFER = 0, 1, 2, 3
+TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL, TUNE_DEFER, TUNE_EDT_LDS = 0, 1, 2, 3, 4
 E_NO_DEVICE = -2
 
 _f64p = C.POINTER(C.c_double)
@@ -92,6 +92,7 @@ SYMBOLS = {
     "bcp_mini_world_seed": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "bcp_sample_mini_worlds": (C.c_int, [_H, C.POINTER(BcpMiniWorldParams), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bcp_get_distance_field": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "bcp_plan_mini_worlds": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcp_refresh_mini_worlds": (C.c_int, [_H, C.POINTER(BcpMiniWorldParams)] + [C.c_void_p] * 6 + [C.c_double] +
                                 [C.c_void_p] * 3),

@@ -529,12 +529,21 @@ class BatchedPlanEnv(object):
             return host_init.initial_pure_pursuit_state(path)
         return host_init.initial_reward_state(path, reward_params)
 
-    def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None, defer=None):
+    def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None, defer=None, edt_lds=None):
         """Execution knobs of libbcplan (bcp_set_tuning); results never depend on them."""
         for key, val in ((_lib.TUNE_EXACT_MODE, exact_mode), (_lib.TUNE_DENSE_THRESHOLD, dense_threshold),
-                         (_lib.TUNE_CULL, cull), (_lib.TUNE_DEFER, defer)):
+                         (_lib.TUNE_CULL, cull), (_lib.TUNE_DEFER, defer), (_lib.TUNE_EDT_LDS, edt_lds)):
             if val is not None:
                 _lib.check(self._lib.bcp_set_tuning(self._h, key, int(val)))
+
+    def distance_field(self, first=0, count=1):
+        """The distance fields libbcplan pre-classifies poses with (bcp_get_distance_field), for `count` map entries
+        from `first`: (uint8 device tensor [count, rows + 2 pad, cols + 2 pad], pad, clamp)."""
+        shape = (C.c_int32 * 4)()
+        _lib.check(self._lib.bcp_get_distance_field(self._h, 0, 0, None, shape, None))
+        out = torch.empty((int(count), shape[0], shape[1]), dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.bcp_get_distance_field(self._h, int(first), int(count), out.data_ptr(), shape, self._stream()))
+        return out, int(shape[2]), int(shape[3])
 
     # ------------------------------------------------------------------ per-env lookups
     def path_of(self, i):

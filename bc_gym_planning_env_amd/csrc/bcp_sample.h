@@ -45,45 +45,83 @@ __global__ void mt_seed_kernel(const int64_t* __restrict__ seeds, int64_t n_chai
     key[kMtWords] = kMtWords;   // position: the first draw regenerates the block
 }
 
-// rk_random: one tempered 32-bit output (one lane runs this)
-__device__ __forceinline__ uint32_t mt_next(MtLds key)
-{
-    uint32_t pos = key[kMtWords];
-    if (pos >= (uint32_t)kMtWords) {   // genrand block update
-        constexpr uint32_t kUpper = 0x80000000u, kLower = 0x7fffffffu, kMatrix = 0x9908b0dfu;
-        int i = 0;
-        for (; i < kMtWords - 397; ++i) {
-            const uint32_t y = (key[i] & kUpper) | (key[i + 1] & kLower);
-            key[i] = key[i + 397] ^ (y >> 1) ^ ((y & 1u) ? kMatrix : 0u);
-        }
-        for (; i < kMtWords - 1; ++i) {
-            const uint32_t y = (key[i] & kUpper) | (key[i + 1] & kLower);
-            key[i] = key[i + (397 - kMtWords)] ^ (y >> 1) ^ ((y & 1u) ? kMatrix : 0u);
-        }
-        const uint32_t y = (key[kMtWords - 1] & kUpper) | (key[0] & kLower);
-        key[kMtWords - 1] = key[396] ^ (y >> 1) ^ ((y & 1u) ? kMatrix : 0u);
-        pos = 0;
+// The stream as the wavefront sees it: a WINDOW of two consecutive 624-word blocks in LDS -- block A, the one numpy's
+// record describes, and block B = its successor (the genrand update of A, done out of place and in parallel) -- and the
+// position `pos` in [0, 1248) of the next unread word.  After mt_reserve() pos < 624, i.e. at least 624 words ahead are
+// addressable at random: lane 0 draws the scalar quantities one after the other, and rejection loops evaluate 64 tries
+// at once, every lane reading the words ITS try would have consumed, before the position is advanced past the first
+// try that succeeded.  Same numbers, same order as RandomState; only the waiting is gone.
+struct MtStream {
+    MtLds buf;   // [2][624] blocks, then the position word
+    int cur;     // which of the two blocks is A (wave-uniform)
+    __device__ __forceinline__ MtLds block_a() const { return buf + cur * kMtWords; }
+    __device__ __forceinline__ MtLds block_b() const { return buf + (cur ^ 1) * kMtWords; }
+    __device__ __forceinline__ uint32_t pos() const { return buf[2 * kMtWords]; }
+    __device__ __forceinline__ void set_pos(uint32_t p) const { buf[2 * kMtWords] = p; }
+    // rk_random's output number `at` of the window (tempered)
+    __device__ __forceinline__ uint32_t word(uint32_t at) const
+    {
+        uint32_t y = at < (uint32_t)kMtWords ? block_a()[at] : block_b()[at - kMtWords];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
     }
-    uint32_t y = key[pos];
-    key[kMtWords] = pos + 1;
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
-}
+    // rk_double: 53-bit double in [0, 1) from the two outputs at `at`; RandomState.random_sample() / .rand()
+    __device__ __forceinline__ double real(uint32_t at) const
+    {
+        const uint32_t a = word(at) >> 5, b = word(at + 1) >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+    // lane 0 only: the next double / RandomState.uniform(low, high) = low + (high - low) * random_sample()
+    __device__ __forceinline__ double next_real() const
+    {
+        const uint32_t at = pos();
+        set_pos(at + 2);
+        return real(at);
+    }
+    __device__ __forceinline__ double next_uniform(double low, double high) const { return low + (high - low) * next_real(); }
+};
 
-// rk_double: 53-bit double in [0, 1) from two outputs; RandomState.random_sample() / .rand()
-__device__ __forceinline__ double mt_double(MtLds key)
+// genrand block update, out of place: dst = successor block of src.  new[i] depends on old[i], old[i + 1] and on
+// old[i + 397] (i < 227) or new[i - 227] (i >= 227), so three sweeps of 227 words are each fully parallel.
+__device__ __forceinline__ void mt_twist(MtLds src, MtLds dst, int lane)
 {
-    const uint32_t a = mt_next(key) >> 5, b = mt_next(key) >> 6;
-    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    constexpr uint32_t kUpper = 0x80000000u, kLower = 0x7fffffffu, kMatrix = 0x9908b0dfu;
+    constexpr int kShift = kMtWords - 397;   // 227
+#pragma unroll 1
+    for (int base = 0; base < kMtWords - 1; base += kShift) {
+        const int end = min(base + kShift, kMtWords - 1);
+        for (int i = base + lane; i < end; i += 64) {
+            const uint32_t y = (src[i] & kUpper) | (src[i + 1] & kLower);
+            const uint32_t far = i < kShift ? src[i + 397] : dst[i - kShift];
+            dst[i] = far ^ (y >> 1) ^ ((y & 1u) ? kMatrix : 0u);
+        }
+        wave_lds_sync();
+    }
+    if (lane == 0) {
+        const uint32_t y = (src[kMtWords - 1] & kUpper) | (dst[0] & kLower);
+        dst[kMtWords - 1] = dst[396] ^ (y >> 1) ^ ((y & 1u) ? kMatrix : 0u);
+    }
+    wave_lds_sync();
 }
 
-// RandomState.uniform(low, high) = low + (high - low) * random_sample()
-__device__ __forceinline__ double mt_uniform(MtLds key, double low, double high) { return low + (high - low) * mt_double(key); }
+// all lanes: slide the window until pos < 624 (numpy regenerates at pos == 624, a fresh seed's state)
+__device__ __forceinline__ void mt_reserve(MtStream& m, int lane)
+{
+    wave_lds_sync();
+    uint32_t at = m.pos();
+    while (at >= (uint32_t)kMtWords) {
+        m.cur ^= 1;                                // B becomes A ...
+        mt_twist(m.block_a(), m.block_b(), lane);  // ... and gets a successor of its own
+        at -= kMtWords;
+    }
+    if (lane == 0) m.set_pos(at);
+    wave_lds_sync();
+}
 
-// ---- geometry (lane 0) --------------------------------------------------------------------------------------------
+// ---- geometry -------------------------------------------------------------------------------------------------------
 struct MiniWorld {   // MiniEnvParams (envs/mini_env.py:79-92)
     double start[3], end[3], a[2], o[2], b[2], h, w;
 };
@@ -100,75 +138,110 @@ struct Wedge {   // not_inside_obstacle (envs/mini_env.py:199-208)
 
 enum { kDrawOk = 0, kDrawEmpty = 1 /* SpaceSeemsEmptyError: redraw the obstacle */, kDrawFail = 2 /* ValueError */ };
 
-// _sample_mini_env_params_no_final_check (envs/mini_env.py:269-325)
-__device__ __forceinline__ int draw_candidate(MtLds mt, const MiniWorldParams& p, MiniWorld& W)
+// One rejection loop of the reference ("for _ in range(1000): draw; if ok: break"), 64 tries at a time: `try_at(at, ...)`
+// evaluates the try whose first random word is window word `at` (every try consumes kWordsPerTry words, accepted or not).
+// Returns the lane that holds the first accepted try (its locals are the result), or -1 after 1000 failures; the
+// stream is left exactly where the sequential loop would have left it.
+template <int kWordsPerTry, typename Try>
+__device__ __forceinline__ int first_accepted(MtStream& m, int lane, Try try_at)
 {
-    W.o[0] = mt_uniform(mt, -p.inner_w / 2, p.inner_w / 2);
-    W.o[1] = mt_uniform(mt, -p.inner_h / 2, p.inner_h / 2);
-    const double first = mt_uniform(mt, 0, kTwoPi);
-    const double width = mt_uniform(mt, p.min_obstacle_angle, p.max_obstacle_angle);
+    static_assert(64 * kWordsPerTry <= kMtWords, "a batch of tries must fit the look-ahead window");
+    for (int t0 = 0; t0 < 1000; t0 += 64) {
+        mt_reserve(m, lane);
+        const uint32_t at = m.pos();
+        const int batch = min(64, 1000 - t0);
+        const bool ok = try_at(at + (uint32_t)(lane * kWordsPerTry)) && lane < batch;
+        const uint64_t hits = __ballot(ok);
+        const int winner = hits ? (int)__builtin_ctzll(hits) : -1;
+        wave_lds_sync();
+        if (lane == 0) m.set_pos(at + (uint32_t)((winner >= 0 ? winner + 1 : batch) * kWordsPerTry));
+        if (winner >= 0) return winner;
+    }
+    return -1;
+}
+
+// _sample_mini_env_params_no_final_check (envs/mini_env.py:269-325); all lanes call it, all lanes get W
+__device__ __forceinline__ int draw_candidate(MtStream& m, const MiniWorldParams& p, MiniWorld& W, int lane)
+{
+    mt_reserve(m, lane);
+    double o0 = 0, o1 = 0, first = 0, width = 0, pick = 0;
+    if (lane == 0) {
+        o0 = m.next_uniform(-p.inner_w / 2, p.inner_w / 2);
+        o1 = m.next_uniform(-p.inner_h / 2, p.inner_h / 2);
+        first = m.next_uniform(0, kTwoPi);
+        width = m.next_uniform(p.min_obstacle_angle, p.max_obstacle_angle);
+        pick = m.next_real();
+    }
+    W.o[0] = bcast_d(o0, 0);
+    W.o[1] = bcast_d(o1, 0);
+    first = bcast_d(first, 0);
+    width = bcast_d(width, 0);
+    pick = bcast_d(pick, 0);
     const double reach = 3 * (p.inner_h + p.inner_w + p.mid_margin + p.out_margin);
     W.h = p.inner_h + 2 * p.mid_margin + 2 * p.out_margin;
     W.w = p.inner_w + 2 * p.mid_margin + 2 * p.out_margin;
-    Wedge wedge{W.o[0], W.o[1], first, first + width};
+    const Wedge wedge{W.o[0], W.o[1], first, first + width};
     double sx, sy, ex, ey, heading;
-    if (mt_double(mt) < 0.7) {
-        // _sample_pose_circ (:146-180): antipodal points of a circle
+    if (pick < 0.7) {
+        // _sample_pose_circ (:146-180): antipodal points of a circle; a try = the angle and a heading the reference
+        // draws and then overwrites
         const double radius = fmin((p.inner_w + p.inner_h) / 4. + p.mid_margin, p.lim_euc_dist);
-        bool found = false;
-        for (int t = 0; t < 1000 && !found; ++t) {
-            const double phi = mt_uniform(mt, 0, kTwoPi);
-            const double x = radius * cos(phi), y = radius * sin(phi);
-            (void)mt_uniform(mt, 0, kTwoPi);   // the reference draws a heading here and overwrites it
-            if (wedge.clear_of(x, y) && wedge.clear_of(-x, -y)) {
-                sx = x;
-                sy = y;
-                ex = -x;
-                ey = -y;
-                heading = atan2(-y - y, -x - x);
-                found = true;
-            }
-        }
-        if (!found) return kDrawEmpty;
+        double x = 0, y = 0;
+        const int winner = first_accepted<4>(m, lane, [&](uint32_t at) {
+            const double phi = 0 + (kTwoPi - 0) * m.real(at);
+            x = radius * cos(phi);
+            y = radius * sin(phi);
+            return wedge.clear_of(x, y) && wedge.clear_of(-x, -y);
+        });
+        if (winner < 0) return kDrawEmpty;
+        sx = bcast_d(x, winner);
+        sy = bcast_d(y, winner);
+        ex = -sx;
+        ey = -sy;
+        heading = atan2(-sy - sy, -sx - sx);
     } else {
-        // _pick_pts_square_method (:183-236)
+        // _pick_pts_square_method (:183-236); a try = x, y, heading
         const double half_w = p.inner_w / 2 + p.mid_margin, half_h = p.inner_h / 2 + p.mid_margin;
-        double sth = 0;
-        bool found = false;
-        for (int t = 0; t < 1000 && !found; ++t) {
-            const double x = mt_uniform(mt, -half_w, half_w), y = mt_uniform(mt, -half_h, half_h);
-            const double th = normalize_angle(mt_uniform(mt, 0, kTwoPi));
-            if (wedge.clear_of(x, y)) {
-                sx = x;
-                sy = y;
-                sth = th;
-                found = true;
-            }
-        }
-        if (!found) return kDrawFail;
-        found = false;
-        for (int t = 0; t < 1000 && !found; ++t) {
-            const double x = mt_uniform(mt, -half_w, half_w), y = mt_uniform(mt, -half_h, half_h);
-            const double th = normalize_angle(mt_uniform(mt, 0, kTwoPi));
+        double x = 0, y = 0, th = 0;
+        int winner = first_accepted<6>(m, lane, [&](uint32_t at) {
+            x = -half_w + (half_w - -half_w) * m.real(at);
+            y = -half_h + (half_h - -half_h) * m.real(at + 2);
+            th = normalize_angle(0 + (kTwoPi - 0) * m.real(at + 4));
+            return wedge.clear_of(x, y);
+        });
+        if (winner < 0) return kDrawFail;
+        sx = bcast_d(x, winner);
+        sy = bcast_d(y, winner);
+        const double sth = bcast_d(th, winner);
+        winner = first_accepted<6>(m, lane, [&](uint32_t at) {
+            x = -half_w + (half_w - -half_w) * m.real(at);
+            y = -half_h + (half_h - -half_h) * m.real(at + 2);
+            th = normalize_angle(0 + (kTwoPi - 0) * m.real(at + 4));
             const double dx = sx - x, dy = sy - y;
-            if (wedge.clear_of(x, y) && py_mod(sth - th, kTwoPi) < p.lim_ang_dist &&
-                sqrt(fma(dy, dy, dx * dx)) < p.lim_euc_dist) {
-                ex = x;
-                ey = y;
-                found = true;
-            }
-        }
-        if (!found) return kDrawFail;
+            return wedge.clear_of(x, y) && py_mod(sth - th, kTwoPi) < p.lim_ang_dist &&
+                   sqrt(fma(dy, dy, dx * dx)) < p.lim_euc_dist;
+        });
+        if (winner < 0) return kDrawFail;
+        ex = bcast_d(x, winner);
+        ey = bcast_d(y, winner);
         heading = atan2(ey - sy, ex - sx);
     }
+    mt_reserve(m, lane);
     const double half = p.angular_pose_noise_scale / 2.0;
+    double n0 = 0, n1 = 0;
+    if (lane == 0) {
+        n0 = m.next_uniform(-half, half);
+        n1 = m.next_uniform(-half, half);
+    }
+    n0 = bcast_d(n0, 0);
+    n1 = bcast_d(n1, 0);
     const double th0 = normalize_angle(heading);   // OrientedPoint normalises on construction ...
     W.start[0] = sx;
     W.start[1] = sy;
-    W.start[2] = normalize_angle(th0 + mt_uniform(mt, -half, half));   // ... and again after the noise
+    W.start[2] = normalize_angle(th0 + n0);          // ... and again after the noise
     W.end[0] = ex;
     W.end[1] = ey;
-    W.end[2] = normalize_angle(th0 + mt_uniform(mt, -half, half));
+    W.end[2] = normalize_angle(th0 + n1);
     W.a[0] = reach * cos(first) + W.o[0];
     W.a[1] = reach * sin(first) + W.o[1];
     W.b[0] = reach * cos(first + width) + W.o[0];
@@ -214,51 +287,53 @@ __device__ __forceinline__ bool clip_segment(int64_t cols, int64_t rows, int64_t
     return (c1 | c2) == 0;
 }
 
-// cv2.line(thickness=1) into a 1-bit map in LDS: clip, then the 8-connected left-to-right Bresenham iterator
+// cv2.line(thickness=1) into a 1-bit map in LDS: clip, then the 8-connected left-to-right Bresenham iterator.  All
+// lanes call it with the same end points; pixel i of the line is at minor offset floor((2 * minor * i + major - 1) /
+// (2 * major)) (the closed form of the iterator's error accumulation, as in coop_raster's outline runs), so the lanes
+// set the pixels 64 at a time.
 __device__ __forceinline__ void draw_wall_bits(MtLds bits, int rows, int cols, int wpr, int64_t x1, int64_t y1, int64_t x2,
-                                               int64_t y2)
+                                               int64_t y2, int lane)
 {
     if ((uint64_t)x1 >= (uint64_t)cols || (uint64_t)x2 >= (uint64_t)cols || (uint64_t)y1 >= (uint64_t)rows ||
         (uint64_t)y2 >= (uint64_t)rows) {
         if (!clip_segment(cols, rows, x1, y1, x2, y2)) return;
     }
-    int64_t dx = x2 - x1, dy = y2 - y1;
+    int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
+    int x0 = (int)x1, y0 = (int)y1;
     if (dx < 0) {
         dx = -dx;
         dy = -dy;
-        x1 = x2;
-        y1 = y2;
+        x0 = (int)x2;
+        y0 = (int)y2;
     }
-    int64_t step_y = 1;
+    int step_y = 1;
     if (dy < 0) {
         dy = -dy;
         step_y = -1;
     }
     const bool vert = dy > dx;
-    const int64_t major = vert ? dy : dx, minor = vert ? dx : dy;
-    int64_t err = major - (minor + minor);
-    int64_t x = x1, y = y1;
-    for (int64_t i = 0; i <= major; ++i) {
-        bits[(int)y * wpr + (int)(x >> 5)] |= 1u << (x & 31);
-        const bool mask = err < 0;
-        err += -(minor + minor) + (mask ? major + major : 0);
-        if (vert) {
-            y += step_y;
-            if (mask) x += 1;
-        } else {
-            x += 1;
-            if (mask) y += step_y;
-        }
+    const int major = vert ? dy : dx, minor = vert ? dx : dy;
+    for (int i = lane; i <= major; i += 64) {
+        const int across = major > 0 ? (2 * minor * i + major - 1) / (2 * major) : 0;
+        const int x = vert ? x0 + across : x0 + i;
+        const int y = vert ? y0 + step_y * i : y0 + step_y * across;
+        __hip_atomic_fetch_or(bits + (y * wpr + (x >> 5)), 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
 }
 
+typedef uint64_t __attribute__((aligned(1))) SampleU64Unaligned;
+
 // ---- the sampler: one wavefront per chain -----------------------------------------------------------------------
-// LDS per wave: [MT19937 record: 625 words] [lethal bitmap: rows * wpr words]
+// LDS per wave: [MT19937 window: 2 x 624 words + position] [lethal bitmap: rows * wpr words]
 // worlds: [n_chains * episodes][14] = start(3), end(3), obstacle_a(2), obstacle_o(2), obstacle_b(2), h, w
 // status[chain]: 0 ok, 1 = "the sampling space looks empty" (the reference raises ValueError)
 // counts / first_world (optional): see "ring mode" below
+// WIDE as in coop_collides: one copy of the rasteriser per kernel
+constexpr int kSampleLdsWords = 2 * kMtWords + 2;   // the bitmap follows the window (on an even word)
+
+template <bool WIDE>
 __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, MiniWorldParams mp, uint32_t* __restrict__ mt_state,
-                                                               int64_t n_chains, int episodes, int rows, int cols, int wide,
+                                                               int64_t n_chains, int episodes, int rows, int cols,
                                                                const int32_t* __restrict__ counts,
                                                                const int64_t* __restrict__ first_world,
                                                                double* __restrict__ worlds, uint8_t* __restrict__ maps,
@@ -270,10 +345,13 @@ __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, Mini
     if (chain >= n_chains) return;
     const int wpr = (cols + 31) / 32;
     if (counts && counts[chain] <= 0) return;   // ring mode: nothing to top up behind this chain's env
-    const MtLds mt = (MtLds)sample_lds;
-    const MtLds bits = mt + kMtRecord + 1;   // (+1: keeps the bitmap on an even word)
-    for (int k = lane; k < kMtRecord; k += 64) mt[k] = mt_state[chain * kMtRecord + k];
+    MtStream mt{(MtLds)sample_lds, 0};
+    const MtLds bits = mt.buf + kSampleLdsWords;
+    uint32_t* record = mt_state + chain * kMtRecord;   // numpy's: 624 key words + position (624 = "regenerate first")
+    for (int k = lane; k < kMtWords; k += 64) mt.buf[k] = record[k];
+    if (lane == 0) mt.set_pos(min(record[kMtWords], (uint32_t)kMtWords));
     wave_lds_sync();
+    mt_twist(mt.block_a(), mt.block_b(), lane);
     const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
     const double inv_res = 1.0 / mp.resolution;
     int failed = 0;
@@ -285,36 +363,32 @@ __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, Mini
         bool accepted = false;
         MiniWorld W;
         for (int tries = 0; tries < 1000 && !accepted && !failed; ++tries) {
-            int rc = kDrawOk;
-            if (lane == 0) rc = draw_candidate(mt, mp, W);
-            rc = bcast_i(rc, 0);
+            const int rc = draw_candidate(mt, mp, W, lane);
             if (rc == kDrawFail) failed = 1;
             if (rc != kDrawOk) continue;
             // prepare_map_and_path (:362-388): empty map with origin (-h/2, -w/2), two walls from the apex
-            const double ox = -bcast_d(W.h, 0) / 2., oy = -bcast_d(W.w, 0) / 2.;
+            const double ox = -W.h / 2., oy = -W.w / 2.;
             for (int k = lane; k < rows * wpr; k += 64) bits[k] = 0u;
             wave_lds_sync();
-            if (lane == 0) {
-                const int64_t px_o = (int64_t)rint((W.o[0] - ox) * inv_res), py_o = (int64_t)rint((W.o[1] - oy) * inv_res);
-                draw_wall_bits(bits, rows, cols, wpr, px_o, py_o, (int64_t)rint((W.a[0] - ox) * inv_res),
-                               (int64_t)rint((W.a[1] - oy) * inv_res));
-                draw_wall_bits(bits, rows, cols, wpr, px_o, py_o, (int64_t)rint((W.b[0] - ox) * inv_res),
-                               (int64_t)rint((W.b[1] - oy) * inv_res));
-            }
+            const int64_t px_o = (int64_t)rint((W.o[0] - ox) * inv_res), py_o = (int64_t)rint((W.o[1] - oy) * inv_res);
+            draw_wall_bits(bits, rows, cols, wpr, px_o, py_o, (int64_t)rint((W.a[0] - ox) * inv_res),
+                           (int64_t)rint((W.a[1] - oy) * inv_res), lane);
+            draw_wall_bits(bits, rows, cols, wpr, px_o, py_o, (int64_t)rint((W.b[0] - ox) * inv_res),
+                           (int64_t)rint((W.b[1] - oy) * inv_res), lane);
             wave_lds_sync();
             // pose_collides of the two ends of the coarse path (:338-343), cooperatively
             bool collides = false;
-#pragma unroll
+#pragma unroll 1
             for (int end = 0; end < 2; ++end) {
-                const double x = bcast_d(end ? W.end[0] : W.start[0], 0), y = bcast_d(end ? W.end[1] : W.start[1], 0);
-                const double th = bcast_d(end ? W.end[2] : W.start[2], 0);
+                const double x = end ? W.end[0] : W.start[0], y = end ? W.end[1] : W.start[1];
+                const double th = end ? W.end[2] : W.start[2];
                 const int px = (int)rint((x - ox) * inv_res), py = (int)rint((y - oy) * inv_res);
-                const bool hit = coop_collides(P, vqx, vqy, cos(th), sin(th), px, py, (LdsWords)bits, rows, cols, wpr, wide != 0);
+                const bool hit = coop_collides<WIDE>(P, vqx, vqy, cos(th), sin(th), px, py, (LdsWords)bits, rows, cols, wpr);
                 collides = collides || hit;
             }
             // beginning and goal must not be immediately too close (:345-351)
-            const double dx = bcast_d(W.start[0], 0) - bcast_d(W.end[0], 0), dy = bcast_d(W.start[1], 0) - bcast_d(W.end[1], 0);
-            const double dth = fabs(normalize_angle(bcast_d(W.start[2], 0) - bcast_d(W.end[2], 0)));
+            const double dx = W.start[0] - W.end[0], dy = W.start[1] - W.end[1];
+            const double dth = fabs(normalize_angle(W.start[2] - W.end[2]));
             const bool too_close = hypot(dx, dy) < mp.goal_spat_dist && dth < mp.goal_ang_dist;
             accepted = !collides && !too_close;
         }
@@ -340,16 +414,34 @@ __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, Mini
             o[12] = W.h;
             o[13] = W.w;
         }
-        // the accepted world's costmap: 254 where the bitmap is set
+        // the accepted world's costmap: 254 where the bitmap is set, eight cells per lane and store (the last group of a
+        // row is shifted left to end at the row's end)
         uint8_t* map = maps + g * (int64_t)rows * cols;
-        for (int idx = lane; idx < rows * cols; idx += 64) {
-            const int r = idx / cols, c = idx - r * cols;
-            map[idx] = ((bits[r * wpr + (c >> 5)] >> (c & 31)) & 1u) ? (uint8_t)BCP_LETHAL : (uint8_t)0;
+        if (cols >= 8) {
+            const int groups = (cols + 7) / 8;
+            for (int it = lane; it < rows * groups; it += 64) {
+                const int r = it / groups, c0 = min((it - r * groups) * 8, cols - 8);
+                const int w = c0 >> 5;
+                const uint64_t two = ((uint64_t)(w + 1 < wpr ? bits[r * wpr + w + 1] : 0u) << 32) | bits[r * wpr + w];
+                const uint64_t eight = (two >> (c0 & 31)) & 0xffull;
+                // bit b -> byte b: one bit per byte, then "byte != 0" as 0 / 1, then x 254
+                const uint64_t spread = (eight * 0x0101010101010101ull) & 0x8040201008040201ull;
+                const uint64_t ones = ((spread + 0x7f7f7f7f7f7f7f7full) >> 7) & 0x0101010101010101ull;
+                *reinterpret_cast<SampleU64Unaligned*>(map + r * (int64_t)cols + c0) = ones * (uint64_t)BCP_LETHAL;
+            }
+        } else {
+            for (int idx = lane; idx < rows * cols; idx += 64) {
+                const int r = idx / cols, c = idx - r * cols;
+                map[idx] = ((bits[r * wpr + (c >> 5)] >> (c & 31)) & 1u) ? (uint8_t)BCP_LETHAL : (uint8_t)0;
+            }
         }
     }
-    wave_lds_sync();
-    for (int k = lane; k < kMtRecord; k += 64) mt_state[chain * kMtRecord + k] = mt[k];
-    if (lane == 0) status[chain] = failed;
+    mt_reserve(mt, lane);
+    for (int k = lane; k < kMtWords; k += 64) record[k] = mt.block_a()[k];
+    if (lane == 0) {
+        record[kMtWords] = mt.pos();
+        status[chain] = failed;
+    }
 }
 
 // ---- from sampled worlds to what a PlanEnv starts with -----------------------------------------------------------

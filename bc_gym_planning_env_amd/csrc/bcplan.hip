@@ -101,6 +101,7 @@ struct bcp_handle {
     size_t ring_bytes;
     int32_t ring_episodes;    // of the last bcp_plan_mini_worlds
     bool ring_planned, ring_refreshed;   // plan -> refresh -> release, in that order
+    int32_t edt_in_lds;       // distance transform of maps that fit: the LDS-resident kernel (BCP_TUNE_EDT_LDS)
 };
 
 // number of entries of a non-shared map / path / initial-state array
@@ -108,6 +109,8 @@ static int64_t n_slots(const bcp_handle* h) { return h->n_geoms > 0 ? h->n_geoms
 
 // grid of a grid-stride kernel; a selection's size is only known on the device, so those launches get a chip-filling
 // grid that does not grow with the upper bound
+constexpr size_t kMaxDynamicLds = 150 * 1024;   // of the 160 KB a gfx950 workgroup can have
+
 static unsigned stride_grid(int64_t work_items, int threads, bool selection = false)
 {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>((work_items + threads - 1) / threads, selection ? 4096 : 65536));
@@ -401,6 +404,89 @@ __global__ void edt_rows_kernel(const uint8_t* __restrict__ g, EntrySelect sel, 
         edt_cell(g, sel.entry(it / per) * per + it % per, W, clamp, out);
 }
 
+// The same transform for maps that fit into LDS (every private / pool map), one workgroup per map, `clamp` <= 60:
+//   pass 1: h(r, c) = distance to the nearest lethal cell of ROW r, from the row's bit mask with clz / ctz on the 64 bits
+//           either side of c -- no sweep, every cell on its own; four cells per thread, packed into an LDS dword;
+//   pass 2: d^2(r, c) = min over |r - r'| < clamp of (r - r')^2 + h(r', c)^2, rows taken from the centre outwards and
+//           abandoned once (r - r')^2 alone reaches the best value so far.
+// It computes the very min the two kernels above compute (the order of the two 1-D passes does not matter), from LDS
+// instead of through the caches: ~20 x faster, which is what lets a pool be topped up between steps.
+__device__ __forceinline__ uint32_t edt_row_word(LdsWords row, int wpr, int w) { return (w >= 0 && w < wpr) ? row[w] : 0u; }
+
+// bit i = column start + i of the row (zero outside the map), i = 0 .. 63
+__device__ __forceinline__ uint64_t edt_row_window(LdsWords row, int wpr, int start)
+{
+    const int w0 = start >> 5, sh = start & 31;   // (arithmetic shift: floor for negative starts)
+    const uint64_t lo = ((uint64_t)edt_row_word(row, wpr, w0 + 1) << 32) | edt_row_word(row, wpr, w0);
+    const uint64_t hi = edt_row_word(row, wpr, w0 + 2);
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+
+__global__ void __launch_bounds__(256) edt_lds_kernel(const uint32_t* __restrict__ bits, EntrySelect sel, int rows, int cols,
+                                                      int wpr, int pad, int clamp, uint8_t* __restrict__ out)
+{
+    const int W = cols + 2 * pad, H = rows + 2 * pad, Wq = (W + 3) / 4;
+    const LdsU32 bm = (LdsU32)lds_dyn;   // [rows][wpr] lethal mask
+    const LdsU32 hq = bm + rows * wpr;   // [H][Wq] h, four cells per dword
+    const int tid = threadIdx.x;
+    const uint32_t far4 = (uint32_t)clamp * 0x01010101u;
+    const int64_t n_sel = sel.size();
+    for (int64_t k = blockIdx.x; k < n_sel; k += gridDim.x) {
+        const int64_t m = sel.entry(k);
+        __syncthreads();   // the previous map's pass 2 is done with the LDS
+        for (int i = tid; i < rows * wpr; i += 256) bm[i] = bits[m * (int64_t)rows * wpr + i];
+        __syncthreads();
+        // (a wave per row, a lane per group of four cells: no divisions, and the four cells share their two windows)
+        for (int rp = tid >> 6; rp < H; rp += 4) {
+            const int r = rp - pad;
+            for (int q = tid & 63; q < Wq; q += 64) {
+                uint32_t packed = far4;
+                if (r >= 0 && r < rows) {
+                    const LdsWords row = (LdsWords)(bm + r * wpr);
+                    const int c0 = q * 4 - pad;
+                    // left: bit 63 = column c0, bit 63 - j = column c0 - j;  right: bit j = column c0 + j
+                    const uint64_t left = edt_row_window(row, wpr, c0 - 63), right = edt_row_window(row, wpr, c0);
+                    packed = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {   // the same two windows seen from column c0 + b (clamp <= 60)
+                        const uint64_t lb = (left >> b) | (right << (63 - b)), rb = right >> b;
+                        const int dr = rb ? (int)__builtin_ctzll(rb) : 64, dl = lb ? (int)__builtin_clzll(lb) : 64;
+                        packed |= (uint32_t)min(min(dr, dl), clamp) << (8 * b);
+                    }
+                }
+                hq[rp * Wq + q] = packed;
+            }
+        }
+        __syncthreads();
+        uint8_t* field = out + m * (int64_t)W * H;
+        for (int rp = tid >> 6; rp < H; rp += 4) {
+            for (int q = tid & 63; q < Wq; q += 64) {
+                int best[4] = {clamp * clamp, clamp * clamp, clamp * clamp, clamp * clamp};
+                for (int d = 0; d < clamp; ++d) {
+                    const int dd = d * d;
+                    if (dd >= max(max(best[0], best[1]), max(best[2], best[3]))) break;
+                    const uint32_t up = rp - d >= 0 ? hq[(rp - d) * Wq + q] : far4;
+                    const uint32_t dn = rp + d < H ? hq[(rp + d) * Wq + q] : far4;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int hv = (int)min((up >> (8 * b)) & 0xffu, (dn >> (8 * b)) & 0xffu);
+                        best[b] = min(best[b], dd + hv * hv);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int cp = q * 4 + b;
+                    if (cp >= W) break;
+                    int sq = (int)__builtin_amdgcn_sqrtf((float)best[b]);   // best <= 3600: the fix-ups make it exact
+                    while (sq * sq > best[b]) --sq;
+                    while ((sq + 1) * (sq + 1) <= best[b]) ++sq;
+                    field[rp * W + cp] = (uint8_t)min(sq, clamp);
+                }
+            }
+        }
+    }
+}
+
 __global__ void normalize_angle_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -644,6 +730,7 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     memset(h, 0, sizeof(*h));
     h->params = *params;
     h->n = n_envs;
+    h->edt_in_lds = 1;
     h->device = device;
     h->env_id_base = env_id_base;
     h->seed = 0;
@@ -719,6 +806,9 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
         case BCP_TUNE_DEFER:
             h->defer = value ? 1 : 0;
             return BCP_OK;
+        case BCP_TUNE_EDT_LDS:
+            h->edt_in_lds = value ? 1 : 0;
+            return BCP_OK;
         case BCP_TUNE_CULL:
             h->cull_enabled = value ? 1 : 0;
             h->cull.on = (value && h->cull.edt) ? 1 : 0;
@@ -741,6 +831,15 @@ static void launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_en
 {
     const MapDesc& m = h->map;
     const CullDesc& C = h->cull;
+    const size_t lds = ((size_t)m.rows * m.wpr + (size_t)C.height * ((C.width + 3) / 4)) * sizeof(uint32_t);
+    if (C.clamp <= 60 && lds <= kMaxDynamicLds && h->edt_in_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edt_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        const int64_t blocks = std::min<int64_t>(max_entries, sel.list ? 2048 : 16384);
+        hipLaunchKernelGGL(edt_lds_kernel, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), lds, s, h->bitmap, sel,
+                           m.rows, m.cols, m.wpr, C.pad, C.clamp, h->edt);
+        return;
+    }
     hipLaunchKernelGGL(edt_columns_kernel, dim3(stride_grid(max_entries * C.width, 64, sel.list != nullptr)), dim3(64), 0, s, h->bitmap, sel, m.rows,
                        m.cols, m.wpr, C.pad, C.clamp, h->edt_col);
     hipLaunchKernelGGL(edt_rows_kernel, dim3(stride_grid(max_entries * C.width * C.height, 256, sel.list != nullptr)), dim3(256), 0, s, h->edt_col,
@@ -855,6 +954,26 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
     }
     h->have_map = true;
     h->static_dirty = true;
+    return BCP_OK;
+}
+
+extern "C" int bcp_get_distance_field(bcp_handle* h, int64_t first_entry, int64_t n_entries, uint8_t* out, int32_t* shape,
+                                      void* stream)
+{
+    if (!h || !shape) return fail(BCP_E_INVALID, "bcp_get_distance_field: null argument");
+    if (!h->have_map || !h->cull.edt) return fail(BCP_E_STATE, "bcp_get_distance_field: no distance field (no costmap, or culling off)");
+    const CullDesc& C = h->cull;
+    shape[0] = C.height;
+    shape[1] = C.width;
+    shape[2] = C.pad;
+    shape[3] = C.clamp;
+    if (!out) return BCP_OK;
+    const int64_t n_maps = h->map.shared ? 1 : n_slots(h);
+    if (first_entry < 0 || n_entries <= 0 || first_entry + n_entries > n_maps)
+        return fail(BCP_E_INVALID, "bcp_get_distance_field: entries out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t per = (size_t)C.width * C.height;
+    HIP_TRY(hipMemcpyAsync(out, h->edt + first_entry * per, n_entries * per, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return BCP_OK;
 }
 
@@ -1418,7 +1537,7 @@ static int sample_mini_worlds(bcp_handle* h, const bcp_mini_world_params* p, uin
     if ((int)(0.05 / p->resolution) > 1)   // Wall.render: thickness = max(1, int(width / resolution))
         return fail(BCP_E_INVALID, "bcp_sample_mini_worlds: walls thicker than one pixel are not supported");
     const int wpr = (cols + 31) / 32;
-    const size_t lds = ((size_t)kMtRecord + 1 + (size_t)rows * wpr) * sizeof(uint32_t);
+    const size_t lds = ((size_t)kSampleLdsWords + (size_t)rows * wpr) * sizeof(uint32_t);
     if (rows <= 0 || cols <= 0 || lds > 60 * 1024) return fail(BCP_E_INVALID, "bcp_sample_mini_worlds: unsupported map shape");
     HIP_TRY(hipSetDevice(h->device));
     DevParams P = h->dev;
@@ -1439,9 +1558,12 @@ static int sample_mini_worlds(bcp_handle* h, const bcp_mini_world_params* p, uin
     mp.resolution = p->resolution;
     mp.goal_spat_dist = p->goal_spat_dist;
     mp.goal_ang_dist = p->goal_ang_dist;
-    hipLaunchKernelGGL(mini_world_sample_kernel, dim3((unsigned)n_chains), dim3(64), lds, (hipStream_t)stream, P, mp, mt_state,
-                       n_chains, (int)episodes, (int)rows, (int)cols, footprint_is_wide(h->params, p->resolution), counts,
-                       first_world, worlds, maps, status);
+    if (footprint_is_wide(h->params, p->resolution))
+        hipLaunchKernelGGL(mini_world_sample_kernel<true>, dim3((unsigned)n_chains), dim3(64), lds, (hipStream_t)stream, P, mp,
+                           mt_state, n_chains, (int)episodes, (int)rows, (int)cols, counts, first_world, worlds, maps, status);
+    else
+        hipLaunchKernelGGL(mini_world_sample_kernel<false>, dim3((unsigned)n_chains), dim3(64), lds, (hipStream_t)stream, P, mp,
+                           mt_state, n_chains, (int)episodes, (int)rows, (int)cols, counts, first_world, worlds, maps, status);
     HIP_TRY(hipGetLastError());
     return BCP_OK;
 }

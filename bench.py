@@ -136,6 +136,34 @@ def aux_measurements(env, pool, n):
         "device_sampling_worlds_per_s": len(worlds) / t_pool,
         "sampler": "bcp_sample_mini_worlds: numpy's MT19937 stream + rejection sampler + walls + acceptance test, one "
                    "wavefront per stream (rate includes the download and the host-side pool objects)"}
+    del penv, worlds
+    # ... and worlds that never repeat: one RandomState stream per env, the pool entries of a stream are a ring that is
+    # re-sampled behind the env on a side stream while the steps go on (plan / refresh / release)
+    eenv = mini_env.BatchedRandomMiniEnv(n, episodes=4, endless=True, auto_reset=True, seed=3, device=env.device.index or 0)
+    eenv.state.current_iter.copy_(torch.from_numpy(rng.randint(0, eenv.params.iteration_timeout, n).astype(np.int32)).to(env.device))
+    infos = []
+    for k in range(256):
+        eenv.step(pool[k % 16])
+        if k % 128 == 127:
+            eenv.refresh(overlap=True)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for k in range(512):
+        eenv.step(pool[k % 16])
+        if k % 128 == 127:
+            info = eenv.refresh(overlap=True)
+            if info is not None:
+                infos.append(info.clone())
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms_endless = e0.elapsed_time(e1) / 512
+    tally = torch.stack(infos).sum(0).cpu().numpy() if infos else np.zeros(4)
+    out["endless_geometry_pool"] = {
+        "what": "RandomMiniEnv(seed=i) for every env i, for ever: %d streams x 4 ring entries, refresh(overlap=True) every "
+                "128 steps re-samples the worlds the envs have left (MT19937 stream order) on a side stream" % n,
+        "ms_per_step": ms_endless, "env_steps_per_s": n / (ms_endless * 1e-3),
+        "worlds_resampled_per_refresh": float(tally[0]) / max(len(infos), 1),
+        "envs_seen_waiting_for_worlds": int(tally[1])}
     return out
 
 

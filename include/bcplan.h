@@ -149,8 +149,10 @@ int bcp_seed(bcp_handle *h, uint64_t seed);
  *                             step kernel (cooperatively with a distance field, per thread without one)
  *   BCP_TUNE_CULL             0 = skip the distance-field pre-classification (every in-map pose is rasterised)
  *   BCP_TUNE_DEFER            0 = settle undecided poses inside the step kernel instead of the second, load-balanced
- *                             kernel (only relevant with a distance field and exact mode auto) */
-enum { BCP_TUNE_EXACT_MODE = 0, BCP_TUNE_DENSE_THRESHOLD = 1, BCP_TUNE_CULL = 2, BCP_TUNE_DEFER = 3 };
+ *                             kernel (only relevant with a distance field and exact mode auto)
+ *   BCP_TUNE_EDT_LDS          0 = build distance fields with the two-pass global-memory kernels even where a map fits
+ *                             into LDS (takes effect at the next bcp_set_costmaps) */
+enum { BCP_TUNE_EXACT_MODE = 0, BCP_TUNE_DENSE_THRESHOLD = 1, BCP_TUNE_CULL = 2, BCP_TUNE_DEFER = 3, BCP_TUNE_EDT_LDS = 4 };
 int bcp_set_tuning(bcp_handle *h, int32_t key, int32_t value);
 
 /* ---- static per-episode inputs ------------------------------------------------------------------------ */
@@ -177,6 +179,14 @@ int bcp_set_geometry_pool(bcp_handle *h, int32_t n_geoms, int32_t *geom_of_env, 
 int bcp_set_costmaps(bcp_handle *h, const uint8_t *data, int32_t rows, int32_t cols, int32_t shared,
                      const int32_t *valid_rows, const int32_t *valid_cols, const double *origins,
                      int32_t origins_per_env, double resolution, void *stream);
+
+/* Introspection (tests, debugging): the distance field bcp_set_costmaps derived for the pre-classification of poses --
+ * floor(min(clamp, Euclidean distance in cells to the nearest lethal cell)) over the map padded by `pad` cells.
+ * shape (host int32 [4]) receives {rows + 2 pad, cols + 2 pad, pad, clamp}; out (device uint8 [n_entries][shape0][shape1],
+ * or NULL to ask for the shape only) the fields of entries first_entry .. first_entry + n_entries - 1 (entry 0 of a
+ * shared map). */
+int bcp_get_distance_field(bcp_handle *h, int64_t first_entry, int64_t n_entries, uint8_t *out, int32_t *shape /*host*/,
+                           void *stream);
 /* Static path of the reward provider (ContinuousRewardProviderState.path, reward.py:17-18), already refined.
  * xytheta: double [max_len,3] when shared, else [N,max_len,3]; lens: NULL when shared (then len = max_len) else
  * int32 [N].  Precomputes cos/sin of the waypoint headings (path_tools.py:405) on the device. */

@@ -348,3 +348,39 @@ def test_endless_pool_guard_holds_envs_back(torch_cuda):
     _check_ring_entries(env, deep, world + 1, generated)
     with pytest.raises(RuntimeError):
         mini_env.BatchedRandomMiniEnv(4, params, n_chains=4, episodes=2).refresh()
+
+
+def test_distance_fields_lds_kernel_vs_two_pass_vs_scipy(torch_cuda):
+    """the distance fields behind the pose pre-classification: the LDS-resident transform (pool / private maps), the
+    two-pass global-memory kernels and scipy's exact EDT agree cell for cell"""
+    torch = torch_cuda
+    from scipy import ndimage
+    from bc_gym_planning_env_amd import mini_env
+    pool = mini_env.sample_pool_device(None, list(range(7, 19)), 2, keep_on_device=True)
+    env = mini_env.BatchedRandomMiniEnv(24, pool=pool)
+    g_n = len(pool)
+    fast, pad, clamp = env.distance_field(0, g_n)
+    env.set_tuning(edt_lds=0)
+    env.set_costmap_tensors(env._keep["map"], env._keep["origins"], env.resolution)
+    slow, pad2, clamp2 = env.distance_field(0, g_n)
+    assert (pad, clamp) == (pad2, clamp2) and torch.equal(fast, slow)
+    maps = pool.maps.cpu().numpy()
+    for k in (0, 5, g_n - 1):
+        free = np.pad(maps[k] != 254, pad, constant_values=True)
+        want = np.minimum(np.floor(ndimage.distance_transform_edt(free) + 1e-9), clamp).astype(np.uint8)
+        assert (fast[k].cpu().numpy() == want).all(), k
+    # and a map with lethal cells right at its border and in every row (all window edge cases of the bit scans)
+    rng = np.random.RandomState(0)
+    dense = np.where(rng.rand(g_n, *maps.shape[1:]) < 0.02, 254, 0).astype(np.uint8)
+    dense[:, 0, 0] = dense[:, -1, -1] = dense[:, 0, -1] = 254
+    env.set_tuning(edt_lds=1)
+    dmap = torch.from_numpy(dense).cuda()
+    env.set_costmap_tensors(dmap, env._keep["origins"], env.resolution)
+    fast = env.distance_field(0, g_n)[0].cpu().numpy()
+    env.set_tuning(edt_lds=0)
+    env.set_costmap_tensors(dmap, env._keep["origins"], env.resolution)
+    assert (env.distance_field(0, g_n)[0].cpu().numpy() == fast).all()
+    for k in (1, g_n - 2):
+        free = np.pad(dense[k] != 254, pad, constant_values=True)
+        want = np.minimum(np.floor(ndimage.distance_transform_edt(free) + 1e-9), clamp).astype(np.uint8)
+        assert (fast[k] == want).all(), k
