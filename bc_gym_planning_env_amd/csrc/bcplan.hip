@@ -832,7 +832,8 @@ static void launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_en
     const MapDesc& m = h->map;
     const CullDesc& C = h->cull;
     const size_t lds = ((size_t)m.rows * m.wpr + (size_t)C.height * ((C.width + 3) / 4)) * sizeof(uint32_t);
-    if (C.clamp <= 60 && lds <= kMaxDynamicLds && h->edt_in_lds) {
+    // (one workgroup per map: worth it from a few dozen maps on; a lone shared map keeps the two wide kernels)
+    if (C.clamp <= 60 && lds <= kMaxDynamicLds && h->edt_in_lds && max_entries >= 32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edt_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         const int64_t blocks = std::min<int64_t>(max_entries, sel.list ? 2048 : 16384);

@@ -1,13 +1,16 @@
 #!/bin/bash
 # rocprofv3 over the metric workload: (1) kernel trace + stats of `python3 bench.py`, (2) FETCH_SIZE and WRITE_SIZE
-# passes (one run each) over tools/pmc_run.py.  Writes gpurun_out/step_kernel_stats.csv and gpurun_out/step_pmc.json;
+# passes (one run each) over tools/pmc_run.py.  Writes gpurun_out/step_kernel_stats.csv, gpurun_out/aux_kernel_stats.csv and gpurun_out/step_pmc.json;
 # copy them to profiles/ (r<round>_bench_kernel_stats.csv, r<round>_pmc_summary.json).
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/step_trace -o p -- python3 bench.py --no-cpu-baseline > gpurun_out/step_trace.log 2>&1
-grep -E "^\"Name\"|step_|ego_|goal_n" gpurun_out/step_trace/p_kernel_stats.csv > gpurun_out/step_kernel_stats.csv
+# metric workload alone (the averages of the step kernels are the metric's), then the whole default run with its aux legs
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/step_trace -o p -- python3 bench.py --no-cpu-baseline --no-aux > gpurun_out/step_trace.log 2>&1
+grep -E "^\"Name\"|step_|ego_|goal_n|mini_world|edt_|pack_bitmap|path_" gpurun_out/step_trace/p_kernel_stats.csv > gpurun_out/step_kernel_stats.csv
 tail -1 gpurun_out/step_trace.log > gpurun_out/step_trace_bench_line.json || true
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/aux_trace -o p -- python3 bench.py --no-cpu-baseline > gpurun_out/aux_trace.log 2>&1
+grep -E "^\"Name\"|step_|ego_|goal_n|mini_world|edt_|pack_bitmap|path_" gpurun_out/aux_trace/p_kernel_stats.csv > gpurun_out/aux_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --output-format csv --pmc $c -d gpurun_out/step_pmc_$c -o p -- python3 tools/pmc_run.py > gpurun_out/step_pmc_$c.log 2>&1
 done
