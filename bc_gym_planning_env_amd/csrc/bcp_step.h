@@ -377,6 +377,7 @@ __device__ __forceinline__ void fifo_delay(double* __restrict__ q, int delay, in
     }
 }
 
+constexpr int kWavePerPoseFrom = 1;   // step_pending_kernel: more than this many rounds of parked poses per team -> a pose per wave
 #ifdef BCP_DIAG
 constexpr int kDiagBlocks = 4096;   // stamps of the first kDiagBlocks workgroups of step_pending_kernel
 __device__ unsigned long long g_diag[kDiagBlocks * 8];
@@ -886,7 +887,11 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
 // the env's finalisation from the parked state.  The first entry is fetched speculatively, together with the
 // counter that says whether it exists, so the two round trips overlap.
 constexpr int kPendingWaves = 4;  // wave = 2 * (row-chunk slot) + (edge slot)
-constexpr int kParkCapacity = 8192;  // undecided poses per step that kernel 2 takes without the waves' help
+// Undecided poses per step up to which kernel 1 parks them all.  With a pose per wave (below) kernel 2 takes 8192 poses
+// per round and spreads them evenly, which beat settling them inside kernel 1's waves in every workload measured (the
+// aisle config, tens of thousands of undecided poses per step: 0.076 ms parked, 0.086 ms in place, 0.102 ms with the
+// former limit of 8192); the in-place path remains for far denser cases and as BCP_TUNE_DENSE_THRESHOLD.
+constexpr int kParkCapacity = 1 << 20;
 
 template <bool WIDE>
 __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(const StepArgs a)
@@ -900,13 +905,32 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
     const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
     const int count = a.pending_count[shard];
     if (blockIdx.x == 0 && a.threshold_next && threadIdx.x < kShards) {
-        // Undecided poses of this step, parked + settled in place.  Few of them: kernel 2 absorbs them all in one or
-        // two rounds, so the next step parks everything (no wave is held up by its own unlucky lanes).  Many (robots
-        // hugging walls everywhere): kernel 2 would need dozens of rounds, every wave settles its own instead.
+        // Undecided poses of this step, parked + settled in place.  Up to kParkCapacity the next step parks everything
+        // (no wave is held up by its own unlucky lanes); beyond that every wave settles its own.
         int total = a.pending_count[threadIdx.x] + a.inplace_count[threadIdx.x];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
         if (threadIdx.x == 0) *a.threshold_next = total <= kParkCapacity ? 64 : 0;
+    }
+    if (count > kWavePerPoseFrom * stride) {
+        // Many parked poses in this shard (private worlds with the robots near their walls: several rounds for every
+        // team): throughput matters more than the latency of one pose, so every WAVE takes poses of its own -- four
+        // times as many in flight, each about twice as long in the single-wave rasteriser.
+        for (int idx = (blockIdx.x / kShards) * kPendingWaves + wave; idx < count; idx += stride * kPendingWaves) {
+            const Pending* e = slots + (int64_t)idx * kShards;
+            const int64_t i = ((int64_t)e->env_hi << 32) | (uint32_t)e->env_lo;
+            const int64_t g = a.S->geom_of_env ? (int64_t)e->geom : i;
+            const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : g * a.S->map.env_stride);
+            bool hit = false;
+            if (!(a.flags & kAblateNoCoop))
+                hit = coop_collides<WIDE>(P, vqx, vqy, e->c, e->s, e->px, e->py, words, a.S->map.rows, a.S->map.cols,
+                                          a.S->map.wpr);
+            if (hit && lane == 0) {
+                Pending q = *e;
+                finalize_env<true>(a, i, q, true);
+            }
+        }
+        return;
     }
     for (int idx = blockIdx.x / kShards; idx < a.S->pending_cap; idx += stride) {
         const Pending* e = slots + (int64_t)idx * kShards;   // in bounds whatever `count` says

@@ -40,7 +40,8 @@ t0 = time.time()
 env = BatchedPlanEnv(cms, [x['path'] for x in gs], params, n_envs=n, auto_reset=True, template_of_env=idx)
 torch.cuda.synchronize()
 print('C4 set-up %.1f s, map storage %s' % (time.time() - t0, tuple(env._keep['map'].shape)), flush=True)
-for mode in (dict(exact_mode=0), dict(exact_mode=2), dict(exact_mode=1)):
+for mode in (dict(exact_mode=0), dict(exact_mode=2), dict(exact_mode=1), dict(exact_mode=0, dense_threshold=64),
+             dict(exact_mode=0, dense_threshold=16)):
     env.set_tuning(**mode)
     env.reset()
     run(env, n, 50, [np.pi / 30, -np.pi / 2], [np.pi / 6, np.pi / 2], 'C4 aisle private maps %s' % mode, 163 + 900 + 3120)
