@@ -59,14 +59,16 @@ class Action(object):
 
 
 @attr.s
-class RewardParams(object):
+class RewardParams(Serializable):
+    """envs/base/reward.py:39-53"""
     spatial_precision = attr.ib(type=float)
     angular_precision = attr.ib(type=float)
     spatial_progress_multiplier = attr.ib(type=float, default=0.0)
 
 
 @attr.s(frozen=True)
-class EnvParams(object):
+class EnvParams(Serializable):
+    """envs/base/params.py:14-59 (serialize / deserialize nest the reward provider's parameters)"""
     dt = attr.ib(type=float, default=0.05)
     goal_ang_dist = attr.ib(type=float, default=np.pi / 2)
     goal_spat_dist = attr.ib(type=float, default=1.0)
@@ -84,6 +86,20 @@ class EnvParams(object):
     reward_provider_params = attr.ib(
         default=attr.Factory(lambda self: RewardParams(spatial_precision=self.goal_spat_dist,
                                                        angular_precision=self.goal_ang_dist), takes_self=True))
+
+    def serialize(self):
+        out = attr.asdict(self)
+        out['version'] = self.VERSION
+        out['reward_provider_params'] = self.reward_provider_params.serialize()
+        return out
+
+    @classmethod
+    def deserialize(cls, state):
+        state = dict(state)
+        ver = state.pop('version')
+        assert ver == cls.VERSION
+        state['reward_provider_params'] = RewardParams.deserialize(state['reward_provider_params'])
+        return cls(**state)
 
 
 class CostMap2D(object):
@@ -312,7 +328,7 @@ class State(Serializable):
     def __eq__(self, other):
         if not isinstance(other, State):
             return False
-        same_arrays = all((np.asarray(a) == np.asarray(b)).all() and np.shape(a) == np.shape(b) for a, b in (
+        same_arrays = all(np.shape(a) == np.shape(b) and (np.asarray(a) == np.asarray(b)).all() for a, b in (
             (self.path, other.path), (self.original_path, other.original_path), (self.pose, other.pose)))
         queues = (len(self.poses_queue) == len(other.poses_queue)
                   and all((np.asarray(a) == np.asarray(b)).all() for a, b in zip(self.poses_queue, other.poses_queue))

@@ -7,6 +7,8 @@ raw pointers (tensor.data_ptr()); all arithmetic happens in libbcplan.so.
 """
 import ctypes as C
 
+import attr
+
 import numpy as np
 import torch
 
@@ -181,6 +183,15 @@ class EnvView(object):
                      robot_state_queue=[self._robot_state(v) for v in fifo(s.robot_state_queue)],
                      control_queue=[Action(command=v) for v in fifo(s.control_queue)], pose=pose,
                      robot_state=self._robot_state(seen))
+
+    VERSION = 1
+
+    def serialize(self):
+        """PlanEnv.serialize (env.py:251-261): this env, its parametrisation included, as basic python types;
+        BatchedPlanEnv.deserialize builds a batch from such records."""
+        st = self.get_state()
+        return {'version': self.VERSION, 'state': st.serialize(), 'params': self._env.params.serialize(),
+                'path': st.original_path, 'costmap': st.costmap.get_state()}
 
     def set_state(self, state):
         """PlanEnv.set_state (env.py:278-285) for this env: like the reference, the robot takes over
@@ -528,6 +539,28 @@ class BatchedPlanEnv(object):
         if self._pure_pursuit:
             return host_init.initial_pure_pursuit_state(path)
         return host_init.initial_reward_state(path, reward_params)
+
+    @classmethod
+    def deserialize(cls, records, **kw):
+        """PlanEnv.deserialize (env.py:263-276), batched: one env per record of `EnvView.serialize()` (or of the
+        reference's `PlanEnv.serialize()`), each with its own costmap and path; the parametrisation is the first
+        record's (they must agree).  Extra keyword arguments go to the constructor (device, seed, auto_reset, ...)."""
+        records = [dict(r) for r in records]
+        for r in records:
+            assert r.pop('version') == EnvView.VERSION
+        params = EnvParams.deserialize(records[0]['params'])
+        if any(EnvParams.deserialize(r['params']) != params for r in records[1:]):
+            raise ValueError("all envs of a batch share one EnvParams")
+        costmaps = [CostMap2D.from_state(r['costmap']) for r in records]
+        paths = [np.asarray(r['path'], dtype=np.float64) for r in records]
+        # `path` is State.original_path, i.e. already refined: it is taken as it is.  (The reference's deserialize goes
+        # through the constructor's refine_path once more -- a no-op except for segments within rounding of path_delta --
+        # but then set_state puts the recorded path back anyway.)
+        env = cls(costmaps, paths, attr.evolve(params, refine_path=False), n_envs=len(records), **kw)
+        env.params = params
+        for i, r in enumerate(records):
+            env.envs[i].set_state(State.deserialize(r['state']))
+        return env
 
     def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None, defer=None, edt_lds=None):
         """Execution knobs of libbcplan (bcp_set_tuning); results never depend on them."""

@@ -134,3 +134,33 @@ def test_per_env_state_round_trip_with_delays(torch_cuda):
         obs, rew, done, _ = env.step(a, noise_z=z)
         assert (env.state.robot[:, 2] == env.state.robot[:, 5]).all()
         assert (obs.pose[:, 2] == obs.pose[:, 5]).all() and rew[2] == rew[5] and done[2] == done[5]
+
+
+def test_whole_env_serialize_roundtrip(torch_cuda):
+    """PlanEnv.serialize / deserialize (env.py:251-276) per env of a batch: records of basic types (picklable) rebuild a
+    batch -- private costmaps and paths, parametrisation and mid-episode state included -- that steps identically"""
+    import pickle
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import BatchedPlanEnv, EnvParams, mini_env
+    params = mini_env.RandomMiniEnvParams(env_params=EnvParams(goal_ang_dist=np.pi / 8., goal_spat_dist=0.2,
+                                                               iteration_timeout=40, pose_delay=1, control_delay=1))
+    pool = mini_env.sample_pool(params, [3, 4, 5], 2)
+    n = 6
+    env = BatchedPlanEnv(pool.costmaps, pool.paths, params.env_params, n_envs=n, seed=5, auto_reset=True)
+    rng = np.random.RandomState(1)
+    for _ in range(7):
+        env.step(env.action_space.sample_batch(n, rng))
+    records = pickle.loads(pickle.dumps([env.envs[i].serialize() for i in range(n)]))
+    assert set(records[0]) == {'version', 'state', 'params', 'path', 'costmap'}
+    assert EnvParams.deserialize(records[0]['params']) == params.env_params
+    twin = BatchedPlanEnv.deserialize(records, seed=5, auto_reset=True)
+    for i in range(n):
+        assert twin.envs[i].get_state() == env.envs[i].get_state()
+    z = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    for _ in range(60):
+        a = env.action_space.sample_batch(n, rng)
+        env.step(a, noise_z_out=z)
+        twin.step(a, noise_z=z)
+        assert torch.equal(env.reward, twin.reward) and torch.equal(env.done, twin.done)
+        assert torch.equal(env.state.robot, twin.state.robot)
+    assert twin.envs[2].get_state() == env.envs[2].get_state()

@@ -146,3 +146,17 @@ def test_state_serialization_round_trip():
         assert cp == st and cp.poses_queue[0] is not st.poses_queue[0]
         cp.poses_queue[0][0] = 99.0
         assert cp != st
+
+
+def test_env_params_serialize_roundtrip():
+    """EnvParams / RewardParams as the reference's Serializable (envs/base/params.py:46-59): nested dict of basic types"""
+    import pickle
+    from bc_gym_planning_env_amd import EnvParams
+    from bc_gym_planning_env_amd.api import RewardParams
+    p = EnvParams(goal_spat_dist=0.3, pose_delay=2, reward_provider_name='continuous_reward_pure_pursuit',
+                  reward_provider_params=RewardParams(spatial_precision=0.3, angular_precision=0.5,
+                                                      spatial_progress_multiplier=2.0))
+    rec = pickle.loads(pickle.dumps(p.serialize()))
+    assert rec['version'] == 1 and rec['reward_provider_params'] == dict(
+        spatial_precision=0.3, angular_precision=0.5, spatial_progress_multiplier=2.0, version=1)
+    assert EnvParams.deserialize(rec) == p and EnvParams.deserialize(EnvParams().serialize()) == EnvParams()
