@@ -62,9 +62,27 @@ struct StepStatic {
     const int32_t* next_geom;
 };
 
+// What a wave needs before anything else -- where its state, its path and (kernel 2) its parked poses are -- travels
+// with the kernel arguments: the first vector loads then depend on the argument fetch alone and overlap the (cold, the
+// kernel boundary emptied the L2) scalar fetch of *S instead of queueing behind it.  A copy of the corresponding *S fields.
+struct StepHot {
+    DevState st;
+    int64_t n;
+    int32_t* geom_of_env;
+    const double* path_pts;
+    const double* path_bbox;
+    const int16_t* path_index;
+    struct Pending* pending;
+    const uint32_t* map_bits;
+    int64_t map_env_stride;
+    int32_t model, lds_path_doubles, path_shared, pending_cap;
+    int32_t map_rows, map_cols, map_wpr, map_shared;
+};
+
 // Per-launch kernel arguments (small).
 struct StepArgs {
     const StepStatic* S;
+    StepHot hot;
     const void* actions;
     const double* noise_z;
     double* noise_z_out;
@@ -643,19 +661,19 @@ __device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, bool acti
 {
     const DevParams& P = a.S->P;
     Robot& r = q.r;
-    r.p.x = a.S->st.x[i];
-    r.p.y = a.S->st.y[i];
-    r.p.th = a.S->st.angle[i];
-    r.v = a.S->st.v[i];
-    r.w = a.S->st.w[i];
-    const bool tri = P.model == BCP_MODEL_TRICYCLE;
-    r.steer = tri ? a.S->st.steer[i] : 0.0;
-    r.wheel = tri ? a.S->st.wheel[i] : 0.0;
-    q.min_dist = a.S->st.min_dist[i];
-    q.target = a.S->st.target_idx[i];
-    q.iter = a.S->st.cur_iter[i];
-    q.collided = a.S->st.collided[i] != 0;
-    q.geom = a.S->geom_of_env ? a.S->geom_of_env[i] : 0;
+    r.p.x = a.hot.st.x[i];
+    r.p.y = a.hot.st.y[i];
+    r.p.th = a.hot.st.angle[i];
+    r.v = a.hot.st.v[i];
+    r.w = a.hot.st.w[i];
+    const bool tri = a.hot.model == BCP_MODEL_TRICYCLE;
+    r.steer = tri ? a.hot.st.steer[i] : 0.0;
+    r.wheel = tri ? a.hot.st.wheel[i] : 0.0;
+    q.min_dist = a.hot.st.min_dist[i];
+    q.target = a.hot.st.target_idx[i];
+    q.iter = a.hot.st.cur_iter[i];
+    q.collided = a.hot.st.collided[i] != 0;
+    q.geom = a.hot.geom_of_env ? a.hot.geom_of_env[i] : 0;
     if (a.flags & BCP_STEP_ACTIONS_F32) {
         const float2 c = reinterpret_cast<const float2*>(a.actions)[i];
         cmd0 = (double)c.x;
@@ -667,7 +685,7 @@ __device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, bool acti
     }
     if (!PLAIN && P.control_delay && active) {   // the robot executes the command given control_delay steps ago (env.py:371-373)
         double cmd[2] = {cmd0, cmd1};
-        fifo_delay<2>(a.S->st.control_q, P.control_delay, a.S->n, i, q.iter + 1, cmd);
+        fifo_delay<2>(a.hot.st.control_q, P.control_delay, a.hot.n, i, q.iter + 1, cmd);
         cmd0 = cmd[0];
         cmd1 = cmd[1];
     }
@@ -691,8 +709,8 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     const DevParams& P = a.S->P;
     const int tid = threadIdx.x;
     const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
-    const bool active = gi < a.S->n;
-    const int64_t i = active ? gi : a.S->n - 1;  // inactive lanes of the last wave shadow env n-1 and never store
+    const bool active = gi < a.hot.n;
+    const int64_t i = active ? gi : a.hot.n - 1;  // inactive lanes of the last wave shadow env n-1 and never store
 
     const CollisionLds L = collision_lds_setup(P, a.S->map, tid);
     Pending q;
@@ -732,8 +750,8 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
     const int tid = threadIdx.x, lane = tid & 63;
     const bool mover = tid < kBlock;
     const int64_t gi = (int64_t)blockIdx.x * kBlock + lane;
-    const bool active = gi < a.S->n;
-    const int64_t i = active ? gi : a.S->n - 1;
+    const bool active = gi < a.hot.n;
+    const int64_t i = active ? gi : a.hot.n - 1;
 
     // (1) staging loads (both waves), then the mover's state / action / noise and the scorer's two reward-state words
     __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
@@ -743,7 +761,7 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int k = u * 2 * kBlock + tid;
-        t[u] = k < a.S->lds_path_doubles ? a.S->path.pts[k] : 0.0;
+        t[u] = k < a.hot.lds_path_doubles ? a.hot.path_pts[k] : 0.0;
     }
     Pending q;
     double cmd0 = 0.0, cmd1 = 0.0;
@@ -752,9 +770,9 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
         if (gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
         if (gi < kShards && a.inplace_next) a.inplace_next[gi] = 0;
     } else {
-        q.min_dist = a.S->st.min_dist[i];
-        q.target = a.S->st.target_idx[i];
-        q.geom = a.S->geom_of_env ? a.S->geom_of_env[i] : 0;
+        q.min_dist = a.hot.st.min_dist[i];
+        q.target = a.hot.st.target_idx[i];
+        q.geom = a.hot.geom_of_env ? a.hot.geom_of_env[i] : 0;
     }
     // the scorer also brings the bounding box and the bucket index of a shared path into LDS while the mover is busy
     // with the robot model (its window look-up then needs no global round trip); a private path's box is fetched now
@@ -762,30 +780,30 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
     double box[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t index_words[2] = {0, 0};
     if (!mover) {
-        if (a.S->path.shared) {
-            if (lane < 8) box[0] = a.S->path.bbox[lane];
-            const uint32_t* iw = reinterpret_cast<const uint32_t*>(a.S->path.index);   // [2][kPathBuckets][2] int16
+        if (a.hot.path_shared) {
+            if (lane < 8) box[0] = a.hot.path_bbox[lane];
+            const uint32_t* iw = reinterpret_cast<const uint32_t*>(a.hot.path_index);   // [2][kPathBuckets][2] int16
             index_words[0] = iw[lane];
             index_words[1] = iw[kBlock + lane];
         } else {
-            const int64_t g = slot_of(a.S, i, q);
+            const int64_t g = a.hot.geom_of_env ? (int64_t)q.geom : i;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) box[k] = a.S->path.bbox[g * 8 + k];
+            for (int k = 0; k < 8; ++k) box[k] = a.hot.path_bbox[g * 8 + k];
         }
     }
     if (tid < nq) qv[tid] = my_q;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int k = u * 2 * kBlock + tid;
-        if (k < a.S->lds_path_doubles) qv[nq + k] = t[u];
+        if (k < a.hot.lds_path_doubles) qv[nq + k] = t[u];
     }
-    for (int k = 512 + tid; k < a.S->lds_path_doubles; k += 2 * kBlock) qv[nq + k] = a.S->path.pts[k];  // long paths
-    const LdsF64 lds_path = a.S->lds_path_doubles ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
-    __attribute__((address_space(3))) double* hand_pose = qv + nq + a.S->lds_path_doubles;
+    for (int k = 512 + tid; k < a.hot.lds_path_doubles; k += 2 * kBlock) qv[nq + k] = a.hot.path_pts[k];  // long paths
+    const LdsF64 lds_path = a.hot.lds_path_doubles ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
+    __attribute__((address_space(3))) double* hand_pose = qv + nq + a.hot.lds_path_doubles;
     __attribute__((address_space(3))) double* hand_score = hand_pose + 3 * kBlock;
     __attribute__((address_space(3))) double* lds_box = hand_score + 3 * kBlock;                    // [8]
     __attribute__((address_space(3))) uint32_t* lds_index = (__attribute__((address_space(3))) uint32_t*)(lds_box + 8);  // [128]
-    if (!mover && a.S->path.shared) {
+    if (!mover && a.hot.path_shared) {
         if (lane < 8) lds_box[lane] = box[0];
         lds_index[lane] = index_words[0];
         lds_index[kBlock + lane] = index_words[1];
@@ -901,7 +919,7 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
     const int lane = threadIdx.x % kBlock, wave = threadIdx.x / kBlock;
     const int shard = (int)(blockIdx.x % kShards);
     const int stride = gridDim.x / kShards;
-    const Pending* slots = a.S->pending + shard;
+    const Pending* slots = a.hot.pending + shard;
     const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
     const int count = a.pending_count[shard];
     if (blockIdx.x == 0 && a.threshold_next && threadIdx.x < kShards) {
@@ -919,12 +937,12 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
         for (int idx = (blockIdx.x / kShards) * kPendingWaves + wave; idx < count; idx += stride * kPendingWaves) {
             const Pending* e = slots + (int64_t)idx * kShards;
             const int64_t i = ((int64_t)e->env_hi << 32) | (uint32_t)e->env_lo;
-            const int64_t g = a.S->geom_of_env ? (int64_t)e->geom : i;
-            const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : g * a.S->map.env_stride);
+            const int64_t g = a.hot.geom_of_env ? (int64_t)e->geom : i;
+            const uint32_t* words = a.hot.map_bits + (a.hot.map_shared ? 0 : g * a.hot.map_env_stride);
             bool hit = false;
             if (!(a.flags & kAblateNoCoop))
-                hit = coop_collides<WIDE>(P, vqx, vqy, e->c, e->s, e->px, e->py, words, a.S->map.rows, a.S->map.cols,
-                                          a.S->map.wpr);
+                hit = coop_collides<WIDE>(P, vqx, vqy, e->c, e->s, e->px, e->py, words, a.hot.map_rows, a.hot.map_cols,
+                                          a.hot.map_wpr);
             if (hit && lane == 0) {
                 Pending q = *e;
                 finalize_env<true>(a, i, q, true);
@@ -932,21 +950,21 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
         }
         return;
     }
-    for (int idx = blockIdx.x / kShards; idx < a.S->pending_cap; idx += stride) {
+    for (int idx = blockIdx.x / kShards; idx < a.hot.pending_cap; idx += stride) {
         const Pending* e = slots + (int64_t)idx * kShards;   // in bounds whatever `count` says
         const double c = e->c, s = e->s;
         const int px = e->px, py = e->py;
         const int64_t i = ((int64_t)e->env_hi << 32) | (uint32_t)e->env_lo;
-        const int64_t g = a.S->geom_of_env ? (int64_t)e->geom : i;
+        const int64_t g = a.hot.geom_of_env ? (int64_t)e->geom : i;
         if (idx >= count) break;
         DIAG_STAMP(1);
-        const uint32_t* words = a.S->map.bits + (a.S->map.shared ? 0 : g * a.S->map.env_stride);
+        const uint32_t* words = a.hot.map_bits + (a.hot.map_shared ? 0 : g * a.hot.map_env_stride);
         // (no inner distance-field test here: nearly every parked pose is free, so the test would cost a dependent
         //  round trip per pose and almost never spare the rasteriser)
         bool hit = false;
         DIAG_STAMP(2);
         if (!(a.flags & kAblateNoCoop))
-            hit = coop_collides_quad<WIDE>(P, vqx, vqy, c, s, px, py, words, a.S->map.rows, a.S->map.cols, a.S->map.wpr, wave,
+            hit = coop_collides_quad<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr, wave,
                                            (LdsU32)lds_dyn);
         DIAG_STAMP(3);
         hit = __syncthreads_or(hit);  // wave-uniform verdicts of the block's waves

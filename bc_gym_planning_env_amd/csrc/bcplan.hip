@@ -1128,6 +1128,24 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     const StepStatic& S = h->host_static;
     StepArgs a;
     a.S = h->dev_static;
+    StepHot& hot = a.hot;
+    hot.st = S.st;
+    hot.n = S.n;
+    hot.geom_of_env = S.geom_of_env;
+    hot.path_pts = S.path.pts;
+    hot.path_bbox = S.path.bbox;
+    hot.path_index = S.path.index;
+    hot.pending = S.pending;
+    hot.map_bits = S.map.bits;
+    hot.map_env_stride = S.map.env_stride;
+    hot.model = S.P.model;
+    hot.lds_path_doubles = S.lds_path_doubles;
+    hot.path_shared = S.path.shared;
+    hot.pending_cap = S.pending_cap;
+    hot.map_rows = S.map.rows;
+    hot.map_cols = S.map.cols;
+    hot.map_wpr = S.map.wpr;
+    hot.map_shared = S.map.shared;
     a.actions = io->actions;
     a.noise_z = io->noise_z;
     a.noise_z_out = io->noise_z_out;
