@@ -533,3 +533,60 @@ def test_action_list_api(torch_cuda):
     o = obs[0]
     assert o.pose.shape == (3,) and o.robot_state.wheel_angle != 0.0
     assert np.array_equal(obs[1].pose, o.pose)
+
+
+@pytest.mark.parametrize("mode", [dict(), dict(defer=0)], ids=["two-kernel", "one-kernel"])
+def test_long_shared_path_vs_oracle(torch_cuda, oracle, mode):
+    """A shared path of 4000 way points that crosses itself many times (a Lissajous curve over the map): too long for the
+    LDS staging of the fast kernel (the scorer wave then scans it in global memory), bucket windows that hold way points
+    of several passes, int16 window bounds far from zero -- against the oracle, with resets."""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    g = load("g8_traj_mini_00.npz")
+    res = float(g["resolution"])
+    m = 4000
+    s = np.linspace(0.0, 0.93, m)     # (not closed: the goal must not sit on the start)
+    x, y = 2.2 * np.sin(2 * np.pi * 3 * s), 2.2 * np.sin(2 * np.pi * 4 * s + 0.4)
+    th = np.arctan2(np.gradient(y), np.gradient(x))
+    path = np.stack([x, y, th], axis=1)
+    n, steps = 2048, 30
+    params = EnvParams(goal_spat_dist=0.2, goal_ang_dist=np.pi / 8, resolution=res, refine_path=False,
+                       iteration_timeout=60)
+    env = BatchedPlanEnv(CostMap2D(g["costmap"], res, g["origin"]), path, params, n_envs=n, auto_reset=True, seed=9)
+    env.set_tuning(**mode)
+    p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE, spatial_precision=0.2, angular_precision=np.pi / 8,
+                           iteration_timeout=60)
+    ref = oracle.OracleBatch(p, n, g["costmap"], g["origin"], res, path)
+    ref.reset_from_paths()
+    rng = np.random.RandomState(3)
+    idx = rng.randint(0, m - 2, n)
+    st = np.zeros((7, n))
+    st[0] = path[idx, 0] + rng.normal(0, 0.1, n)
+    st[1] = path[idx, 1] + rng.normal(0, 0.1, n)
+    st[2] = path[idx, 2] + rng.normal(0, 0.2, n)
+    st[3] = rng.uniform(0, 0.5, n)
+    tgt = np.clip(idx + rng.randint(-3, 4, n), 1, m - 1).astype(np.int32)
+    md = np.hypot(path[tgt, 0] - st[0], path[tgt, 1] - st[1]) + rng.uniform(-0.01, 0.05, n)
+    it = rng.randint(0, 60, n).astype(np.int32)
+    for f in range(7):
+        ref.st[f][:] = st[f]
+    ref.min_dist[:], ref.target_idx[:], ref.cur_iter[:] = md, tgt, it
+    env.state.robot.copy_(torch.from_numpy(st))
+    env.state.min_spat_dist_so_far.copy_(torch.from_numpy(md))
+    env.state.target_idx.copy_(torch.from_numpy(tgt))
+    env.state.current_iter.copy_(torch.from_numpy(it))
+    zout = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    n_rew = n_done = 0
+    for t in range(steps):
+        a = env.action_space.sample_batch(n, rng)
+        a[:, 0] *= 2.0
+        env.step(a, noise_z_out=zout)
+        ref.step(a.astype(np.float64), z_in(zout.cpu().numpy()), auto_reset=True, threads=8)
+        np.testing.assert_array_equal(env.done.cpu().numpy(), ref.done, err_msg="step %d" % t)
+        np.testing.assert_array_equal(env.state.target_idx.cpu().numpy(), ref.target_idx, err_msg="step %d" % t)
+        np.testing.assert_allclose(env.reward.cpu().numpy(), ref.reward, rtol=0, atol=ATOL)
+        np.testing.assert_allclose(env.state.robot.cpu().numpy(), np.stack(ref.st), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(env.state.min_spat_dist_so_far.cpu().numpy(), ref.min_dist, rtol=0, atol=ATOL)
+        n_rew += int((ref.reward == 1.0).sum())
+        n_done += int(ref.done.sum())
+    assert n_rew > 500 and n_done > 200, (n_rew, n_done)
