@@ -31,10 +31,12 @@ def test_gpu_sampler_reproduces_reference_worlds(torch_cuda):
         assert ((pool.costmaps[k].get_data() == 254) == want).all()
 
 
-def _pool_and_oracle(oracle, mini_env, n, n_chains, episodes, timeout, next_geom=True):
+def _pool_and_oracle(oracle, mini_env, n, n_chains, episodes, timeout, next_geom=True, pure_pursuit=0, **delays):
     from bc_gym_planning_env_amd import EnvParams
     params = mini_env.RandomMiniEnvParams(
-        env_params=EnvParams(goal_ang_dist=np.pi / 8., goal_spat_dist=0.2, iteration_timeout=timeout))
+        env_params=EnvParams(goal_ang_dist=np.pi / 8., goal_spat_dist=0.2, iteration_timeout=timeout,
+                             reward_provider_name='continuous_reward_pure_pursuit' if pure_pursuit else 'continuous_reward',
+                             **delays))
     pool = mini_env.sample_pool(params, list(range(100, 100 + n_chains)), episodes)
     env = mini_env.BatchedRandomMiniEnv(n, params, pool=pool, auto_reset=True, seed=11,
                                         draw_new_turn_on_reset=next_geom)
@@ -48,7 +50,7 @@ def _pool_and_oracle(oracle, mini_env, n, n_chains, episodes, timeout, next_geom
     i = np.arange(n)
     geom0 = (i % n_chains) * episodes + (i // n_chains) % episodes
     p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE, spatial_precision=0.2, angular_precision=np.pi / 8,
-                           iteration_timeout=timeout)
+                           iteration_timeout=timeout, reward_provider=pure_pursuit, **delays)
     ref = oracle.OracleBatch(p, n, maps, origins, params.env_params.resolution, pbuf, lens=[len(q) for q in paths],
                              geom=geom0, next_geom=pool.next_geom if next_geom else None)
     ref.reset_from_paths()
@@ -90,6 +92,32 @@ def test_pool_steps_and_resets_vs_oracle(torch_cuda, oracle, mode):
         hits += int(ref.collided_now.sum())
     assert resets > 2 * n and hits > 20
     assert len(np.unique(ref.geom)) == len(pool)        # every world of the pool was in use at the end
+
+
+@pytest.mark.parametrize("cfg", [dict(pose_delay=1, state_delay=1, control_delay=2), dict(pure_pursuit=1, pose_delay=1)],
+                         ids=["delays", "pure-pursuit"])
+def test_pool_with_delays_and_pure_pursuit_vs_oracle(torch_cuda, oracle, cfg):
+    """the geometry pool together with the delay queues / the second reward provider (general step kernel): resets move
+    an env to its next world AND restart its FIFOs"""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import mini_env
+    n, steps = 512, 70
+    env, ref, pool = _pool_and_oracle(oracle, mini_env, n, n_chains=5, episodes=3, timeout=20, **cfg)
+    _compare(env, ref, "init")
+    rng = np.random.RandomState(8)
+    zout = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    resets = 0
+    for t in range(steps):
+        a = env.action_space.sample_batch(n, rng)
+        a[:, 0] *= 3.0
+        obs, rew, done, _ = env.step(a, noise_z_out=zout)
+        ref.step(a.astype(np.float64), z_in(zout.cpu().numpy()), auto_reset=True, threads=8)
+        np.testing.assert_array_equal(done.cpu().numpy(), ref.done, err_msg="done step %d" % t)
+        np.testing.assert_allclose(rew.cpu().numpy(), ref.reward, rtol=0, atol=ATOL)
+        np.testing.assert_allclose(obs.pose.cpu().numpy(), ref.obs_pose.T, rtol=0, atol=ATOL)
+        _compare(env, ref, t)
+        resets += int(ref.done.sum())
+    assert resets > 2 * n
 
 
 def test_pool_without_successor_table_keeps_worlds(torch_cuda, oracle):
