@@ -79,6 +79,8 @@ struct StepHot {
     int32_t map_rows, map_cols, map_wpr, map_shared;
 };
 
+constexpr int kShards = 64;  // a wave parks into shard (block index % kShards)
+
 // Per-launch kernel arguments (small).
 struct StepArgs {
     const StepStatic* S;
@@ -101,7 +103,49 @@ struct StepArgs {
     int32_t* inplace_next;     // [kShards] next step's counters; kernel 1 zeroes them
     uint64_t seed, step_counter;
     uint32_t flags;
+    // The step counter (parity of the alternating counter sets above, counter of the noise stream) and the noise seed
+    // live on the DEVICE, so that the launch arguments of a step never change and a captured hipGraph of steps can be
+    // replayed: the kernels fill in the eight fields above themselves (resolve_step).  tick[0] = counter as kernel 1 (or
+    // the single-kernel step) reads it, tick[1] = as kernel 2 reads it, tick[2] = seed, tick[3] = ticket of the
+    // single-kernel step.  Two-kernel step: kernel 1 copies tick[0] to tick[1], kernel 2 stores tick[1] + 1 to tick[0]
+    // -- each word is only written while no kernel that reads it is running.  Single-kernel step: the last workgroup
+    // to finish (ticket) advances tick[0].
+    uint64_t* tick;
+    int32_t* pending_base;     // [2][kShards] or nullptr
+    int32_t* adapt_base;       // [2] thresholds + [2][kShards] in-place counters, or nullptr (no adaptation)
 };
+
+constexpr uint32_t kStepAdvances = 1u << 24;   // internal flag: this launch is the last kernel of its step
+
+// which: 0 = kernel 1 / single-kernel step, 1 = kernel 2
+__device__ __forceinline__ StepArgs resolve_step(const StepArgs& in, int which)
+{
+    StepArgs a = in;
+    const uint64_t step = in.tick[which];
+    a.step_counter = step;
+    a.seed = in.tick[2];
+    const int p = (int)(step & 1u);
+    a.pending_count = in.pending_base ? in.pending_base + p * kShards : nullptr;
+    a.pending_next = in.pending_base ? in.pending_base + (p ^ 1) * kShards : nullptr;
+    a.threshold_now = in.adapt_base ? in.adapt_base + p : nullptr;
+    a.threshold_next = in.adapt_base ? in.adapt_base + (p ^ 1) : nullptr;
+    a.inplace_count = in.adapt_base ? in.adapt_base + 2 + p * kShards : nullptr;
+    a.inplace_next = in.adapt_base ? in.adapt_base + 2 + (p ^ 1) * kShards : nullptr;
+    return a;
+}
+
+// end of a kernel that is the last one of its step (flag kStepAdvances): the last workgroup to get here moves the
+// counter on.  Every workgroup has read tick[0] long before it takes its ticket.
+__device__ __forceinline__ void advance_step_by_ticket(const StepArgs& a)
+{
+    if (!(a.flags & kStepAdvances) || threadIdx.x != 0) return;
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(a.tick + 3);
+    __threadfence();
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+        *ticket = 0u;
+        a.tick[0] = a.step_counter + 1;
+    }
+}
 
 // Ablation switches in the upper half of the step flags (tools/ablate*.py time the step with stages removed; results
 // are then WRONG by construction).  Not part of the ABI: bcplan.h only defines bits 0-1.
@@ -408,7 +452,6 @@ extern "C" int bcp_diag_read(unsigned long long* out)
 #define DIAG_STAMP(k) do { } while (0)
 #endif
 
-constexpr int kShards = 64;  // a wave parks into shard (block index % kShards)
 
 // dynamic LDS of the collision kernels:
 //   [lethal bitmap words (when the shared map is staged)] [qverts: n_verts * 2 doubles] [vertex scratch of the
@@ -704,8 +747,9 @@ __device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, bool acti
 // General step kernel: robot model, collision settled in place by collides_wave (distance-field classification when
 // there is one, then the cooperative / per-thread exact rasterisers), reward, done, write-back.  Used when there
 // is no distance field, when the batch is too small to need load balancing, or when a mode is forced.
-__global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
+__global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs launch_args)
 {
+    const StepArgs a = resolve_step(launch_args, 0);
     const DevParams& P = a.S->P;
     const int tid = threadIdx.x;
     const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
@@ -725,8 +769,8 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
     if (!(a.flags & kAblateNoCollision))
         hit = collides_wave(P, a.S->map, a.S->cull, L, a.S->exact_mode, a.S->dense_threshold, a.S->wide != 0, active,
                             slot_of(a.S, i, q), q.r.p.x, q.r.p.y, q.r.p.th);
-    if (!active) return;
-    finalize_env<false>(a, i, q, hit);
+    if (active) finalize_env<false>(a, i, q, hit);
+    advance_step_by_ticket(a);
 }
 
 
@@ -744,8 +788,9 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs a)
 // did not collide in place (those redo the reward themselves for the rolled-back pose).
 // LDS: [qverts][shared path][64 x {x, y, theta}][64 x {reward, min_dist, target}]
 template <bool WIDE>
-__global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepArgs a)
+__global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepArgs launch_args)
 {
+    const StepArgs a = resolve_step(launch_args, 0);
     const DevParams& P = a.S->P;
     const int tid = threadIdx.x, lane = tid & 63;
     const bool mover = tid < kBlock;
@@ -898,6 +943,8 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
         sc.target = (int)hand_score[2 * kBlock + lane];
         finalize_env<true>(a, i, q, hit, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &sc);
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick[1] = a.step_counter;   // for kernel 2 (see StepArgs::tick)
+    advance_step_by_ticket(a);   // (only when no kernel 2 follows)
 }
 
 // Kernel 2 of a step: kPendingWaves wavefronts per parked env: the lanes rasterise
@@ -912,8 +959,9 @@ constexpr int kPendingWaves = 4;  // wave = 2 * (row-chunk slot) + (edge slot)
 constexpr int kParkCapacity = 1 << 20;
 
 template <bool WIDE>
-__global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(const StepArgs a)
+__global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(const StepArgs launch_args)
 {
+    const StepArgs a = resolve_step(launch_args, 1);
     DIAG_STAMP(0);
     const DevParams& P = a.S->P;
     const int lane = threadIdx.x % kBlock, wave = threadIdx.x / kBlock;
@@ -930,6 +978,7 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
         for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
         if (threadIdx.x == 0) *a.threshold_next = total <= kParkCapacity ? 64 : 0;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.tick[0] = a.step_counter + 1;   // the next step's kernel 1 reads this
     if (count > kWavePerPoseFrom * stride) {
         // Many parked poses in this shard (private worlds with the robots near their walls: several rounds for every
         // team): throughput matters more than the latency of one pose, so every WAVE takes poses of its own -- four

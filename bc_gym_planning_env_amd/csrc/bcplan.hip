@@ -54,7 +54,7 @@ struct bcp_handle {
     int device;
     int64_t env_id_base;
     uint64_t seed;
-    uint64_t step_counter;
+    uint64_t* tick;           // owned, device: step counter (two views), noise seed, ticket -- see StepArgs::tick
     bool have_map, have_path, have_state, have_init;
     double resolution;
     uint32_t* bitmap;      // owned
@@ -741,6 +741,11 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->defer = 1;
     h->static_dirty = true;
     fill_dev_params(h);
+    if (hipMalloc((void**)&h->tick, 4 * sizeof(uint64_t)) != hipSuccess || hipMemset(h->tick, 0, 4 * sizeof(uint64_t)) != hipSuccess) {
+        if (h->tick) (void)hipFree(h->tick);
+        delete h;
+        return fail(BCP_E_HIP, "bcp_create: cannot allocate device memory");
+    }
     *out = h;
     return BCP_OK;
 }
@@ -756,6 +761,7 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->edt) (void)hipFree(h->edt);
     if (h->edt_col) (void)hipFree(h->edt_col);
     if (h->pending) (void)hipFree(h->pending);
+    if (h->tick) (void)hipFree(h->tick);
     if (h->pending_count) (void)hipFree(h->pending_count);
     if (h->adapt) (void)hipFree(h->adapt);
     if (h->dev_static) (void)hipFree(h->dev_static);
@@ -770,7 +776,18 @@ extern "C" int bcp_seed(bcp_handle* h, uint64_t seed)
 {
     if (!h) return fail(BCP_E_INVALID, "bcp_seed: null handle");
     h->seed = seed;
-    h->step_counter = 0;
+    // The noise stream restarts: step counter 0 again.  The alternating counter sets of the parking scheme are keyed
+    // by the counter's parity, so they are re-armed with it (rare call: synchronous).
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const uint64_t tick[4] = {0, 0, seed, 0};
+    HIP_TRY(hipMemcpy(h->tick, tick, sizeof(tick), hipMemcpyHostToDevice));
+    if (h->pending_count) HIP_TRY(hipMemset(h->pending_count, 0, 2 * kShards * sizeof(int32_t)));
+    if (h->adapt) {
+        HIP_TRY(hipMemset(h->adapt, 0, (2 + 2 * kShards) * sizeof(int32_t)));
+        const int32_t init[2] = {h->dense_threshold, h->dense_threshold};
+        HIP_TRY(hipMemcpy(h->adapt, init, sizeof(init), hipMemcpyHostToDevice));
+    }
     return BCP_OK;
 }
 
@@ -1154,15 +1171,15 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     a.collided_now = io->collided_now;
     a.err = io->err;
     a.flags = flags;
-    a.seed = h->seed;
-    a.step_counter = h->step_counter;
-    a.pending_count = h->pending_count + (h->step_counter & 1) * kShards;
-    a.pending_next = h->pending_count + ((h->step_counter + 1) & 1) * kShards;
+    // the step counter and the noise seed are read on the device (StepArgs::tick); the kernels resolve these themselves
+    a.seed = a.step_counter = 0;
+    a.pending_count = a.pending_next = nullptr;
+    a.threshold_now = nullptr;
+    a.threshold_next = a.inplace_count = a.inplace_next = nullptr;
     const bool adapt = h->adaptive && h->adapt && S.pending && S.dense_threshold >= 0;
-    a.threshold_now = adapt ? h->adapt + (h->step_counter & 1) : nullptr;
-    a.threshold_next = adapt ? h->adapt + ((h->step_counter + 1) & 1) : nullptr;
-    a.inplace_count = adapt ? h->adapt + 2 + (h->step_counter & 1) * kShards : nullptr;
-    a.inplace_next = adapt ? h->adapt + 2 + ((h->step_counter + 1) & 1) * kShards : nullptr;
+    a.tick = h->tick;
+    a.pending_base = h->pending_count;
+    a.adapt_base = adapt ? h->adapt : nullptr;
     const int blocks = (int)((h->n + kBlock - 1) / kBlock);
     if (S.pending) {
         // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest
@@ -1170,6 +1187,7 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
         const size_t lds2 = (size_t)2 * 4 * (S.wide ? 8 : 3) * 64 * sizeof(uint32_t);
         const int waves = 2048;  // a multiple of kShards: 32 teams per shard, so that a shard rarely needs a second round
         const bool second = !first_only && S.dense_threshold >= 0;  // (threshold < 0: everything settled in place)
+        if (!second) a.flags |= kStepAdvances;   // kernel 1 is the whole step
         // kernel 1 runs with two wavefronts per 64 envs (mover + scorer, step_fast_pair_kernel)
         const size_t lds1p = lds1 + ((size_t)6 * kBlock + 8) * sizeof(double) + 2 * kBlock * sizeof(uint32_t);
         if (S.wide) {
@@ -1181,9 +1199,9 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
         }
     } else {
         const size_t lds = collision_lds_bytes(h->params.n_verts, h->map.in_lds, h->map.rows, h->map.wpr);
+        a.flags |= kStepAdvances;
         hipLaunchKernelGGL(step_kernel, dim3(blocks), dim3(kBlock), lds, s, a);
     }
-    h->step_counter += 1;
     return BCP_OK;
 }
 

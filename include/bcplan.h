@@ -20,8 +20,10 @@
  *   - All launches are asynchronous on the `stream` argument (a hipStream_t, NULL = default stream).
  *     bcp_step()/bcp_reset_masked() never synchronise or copy to the host and allocate nothing once the first step
  *     has run (the first call after a re-bind uploads a 2 KB parameter block; bcp_egocentric_costmaps() allocates its
- *     scratch on first use).  A step's launches carry the step counter (noise stream key, parity of the alternating
- *     counter sets) as kernel arguments, so a captured step must not be replayed as a hipGraph node: launch it.
+ *     scratch on first use).  The step counter (noise stream key, parity of the alternating counter sets) and the
+ *     noise seed live on the device and are advanced by the kernels themselves: a step's launch arguments depend only
+ *     on the pointers in bcp_step_io and the flags, so steps captured into a hipGraph (after one ordinary step has
+ *     uploaded the parameter block) can be replayed.
  *   - One handle per GPU / process rank.  A handle is not thread-safe; different handles are independent.
  *   - There is NO CPU fallback in this library: without a GPU bcp_create() fails with BCP_E_NO_DEVICE.
  */

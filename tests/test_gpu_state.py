@@ -164,3 +164,43 @@ def test_whole_env_serialize_roundtrip(torch_cuda):
         assert torch.equal(env.reward, twin.reward) and torch.equal(env.done, twin.done)
         assert torch.equal(env.state.robot, twin.state.robot)
     assert twin.envs[2].get_state() == env.envs[2].get_state()
+
+
+@pytest.mark.parametrize("kind", ["two-kernel", "single-kernel"])
+def test_steps_replayed_from_a_captured_graph(torch_cuda, kind):
+    """The step counter (noise stream, parity of the parking counters) lives on the device: steps captured into a HIP
+    graph and replayed are the very steps an ordinary launch sequence performs."""
+    torch = torch_cuda
+    n = 3000
+    env, twin = _env(torch, n), _env(torch, n)
+    if kind == "single-kernel":
+        env.set_tuning(defer=0)
+        twin.set_tuning(defer=0)
+    rng = np.random.RandomState(4)
+    acts = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(12)])).cuda()
+    a_static = acts[0].clone()
+    for env_ in (env, twin):                       # ordinary steps first: uploads the parameter block
+        env_.step(a_static)
+        env_.step(a_static)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            env.step(a_static)
+            env.step(a_static)                     # two steps per replay
+    torch.cuda.current_stream().wait_stream(side)
+    # capture does not execute: both envs are still in step; now 6 replays (12 steps) against 12 launched steps
+    for k in range(6):
+        a_static.copy_(acts[2 * k])                # (both steps of a replay read the same action tensor)
+        graph.replay()
+        twin.step(acts[2 * k])
+        twin.step(acts[2 * k])
+        torch.cuda.synchronize()
+        assert torch.equal(env.state.robot, twin.state.robot), k
+        assert torch.equal(env.reward, twin.reward) and torch.equal(env.done, twin.done), k
+        assert torch.equal(env.state.current_iter, twin.state.current_iter), k
+    # and back to ordinary launches
+    env.step(acts[3])
+    twin.step(acts[3])
+    assert torch.equal(env.state.robot, twin.state.robot)
