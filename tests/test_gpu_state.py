@@ -204,3 +204,27 @@ def test_steps_replayed_from_a_captured_graph(torch_cuda, kind):
     env.step(acts[3])
     twin.step(acts[3])
     assert torch.equal(env.state.robot, twin.state.robot)
+
+
+def test_reseed_restarts_the_noise_stream_whatever_the_step_parity(torch_cuda):
+    """seed(s) restarts the step counter; the parity-keyed parking counters are re-armed with it, so an env reseeded
+    after an odd number of steps carries on exactly like one reseeded after an even number"""
+    torch = torch_cuda
+    n = 4096
+    odd, even = _env(torch, n), _env(torch, n)
+    rng = np.random.RandomState(2)
+    acts = torch.from_numpy(np.stack([odd.action_space.sample_batch(n, rng) for _ in range(8)])).cuda()
+    acts[:, :, 0] *= 3.0
+    for k in range(3):
+        odd.step(acts[k])
+    for k in range(4):
+        even.step(acts[k])
+    even.set_state(odd.get_state())
+    odd.seed(77)
+    even.seed(77)
+    for k in range(40):
+        odd.step(acts[k % 8])
+        even.step(acts[k % 8])
+        assert torch.equal(odd.state.robot, even.state.robot), k
+        assert torch.equal(odd.reward, even.reward) and torch.equal(odd.done, even.done), k
+        assert torch.equal(odd.state.robot_collided, even.state.robot_collided), k
