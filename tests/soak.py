@@ -1,5 +1,6 @@
 """Long randomised parity run: the HIP step against the oracle, every step, every env, several configurations.
-Not part of pytest (minutes of CPU oracle time).  Usage: python tools/soak.py [steps] [n_envs] [seed]"""
+Not collected by pytest (minutes of CPU oracle time); it lives under tests/ because it drives the oracle.
+Usage: python tests/soak.py [steps] [n_envs] [seed]   (from the repository root)"""
 import sys, os, time, numpy as np, torch
 sys.path.insert(0, '.')
 import oracle as O
