@@ -548,7 +548,8 @@ class BatchedRandomMiniEnv(BatchedPlanEnv):
         -- its worlds come into reach from the next step on -- and starts the next one.  Nothing blocks on the host; on
         the GPU the steps wait for a previous refresh that has not finished yet, so call it every few hundred steps
         (a refresh takes 2 .. 10 ms) and size `episodes` so that no env gets through `episodes - 1` worlds during two
-        such periods.
+        such periods.  Stepping on a high-priority stream (torch.cuda.Stream(priority=-1)) keeps the refresh kernels
+        from delaying the steps (5 % in tools/bench_endless.py).
 
         :param check bool: wait for the refresh to finish and raise what the reference's sampler would raise
         :return: device int32 [4] = (entries re-sampled, envs that were waiting on their newest world, 0, 0) of the

@@ -28,31 +28,35 @@ for k in range(64):       # warm-up: spread the envs over their episodes
     if k % every == every - 1:
         env.refresh()
 torch.cuda.synchronize()
-for label, do_refresh, overlap in (("step only (envs run into their guards)", False, False),
-                                   ("step + refresh in stream order", True, False),
-                                   ("step + refresh on a side stream", True, True)):
-    new = waiting = 0
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    infos = []
-    dones.zero_()
-    e0.record()
-    for k in range(steps):
-        env.step(acts[k % 16])
-        dones += env.done
-        if do_refresh and k % every == every - 1:
-            info = env.refresh(overlap=overlap)
-            if info is not None:
-                infos.append(info.clone())
-    env.finish_refresh()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1)
-    if infos:
-        inf = torch.stack(infos).cpu().numpy()
-        new, waiting = int(inf[:, 0].sum()), int(inf[:, 1].sum())
-    print("%-42s %.4f ms/step  %.3g env-steps/s  episodes ended %d  refreshes %d  worlds re-sampled %d  "
-          "waiting-at-guard sightings %d" % (label, ms / steps, n * steps / ms * 1e3, int(dones.sum()), len(infos), new,
-                                             waiting), flush=True)
+hi = torch.cuda.Stream(priority=-1)
+hi.wait_stream(torch.cuda.current_stream())
+for label, do_refresh, overlap, prio in (("step only (envs run into their guards)", False, False, False),
+                                         ("step + refresh in stream order", True, False, False),
+                                         ("step + refresh on a side stream", True, True, False),
+                                         ("same, steps on a high-priority stream", True, True, True)):
+  with torch.cuda.stream(hi if prio else torch.cuda.current_stream()):
+      new = waiting = 0
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      infos = []
+      dones.zero_()
+      e0.record()
+      for k in range(steps):
+          env.step(acts[k % 16])
+          dones += env.done
+          if do_refresh and k % every == every - 1:
+              info = env.refresh(overlap=overlap)
+              if info is not None:
+                  infos.append(info.clone())
+      env.finish_refresh()
+      e1.record()
+      torch.cuda.synchronize()
+      ms = e0.elapsed_time(e1)
+      if infos:
+          inf = torch.stack(infos).cpu().numpy()
+          new, waiting = int(inf[:, 0].sum()), int(inf[:, 1].sum())
+      print("%-42s %.4f ms/step  %.3g env-steps/s  episodes ended %d  refreshes %d  worlds re-sampled %d  "
+            "waiting-at-guard sightings %d" % (label, ms / steps, n * steps / ms * 1e3, int(dones.sum()), len(infos), new,
+                                               waiting), flush=True)
 # one refresh in isolation, after `every` steps
 ts = []
 for rep in range(10):
