@@ -422,15 +422,32 @@ __device__ __forceinline__ uint64_t edt_row_window(LdsWords row, int wpr, int st
     return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
 }
 
+typedef unsigned short EdtU16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t __attribute__((aligned(1))) EdtU32Unaligned;
+
+__device__ __forceinline__ EdtU16x2 edt_pair(uint32_t word, uint32_t selector)
+{
+    const uint32_t v = __builtin_amdgcn_perm(0u, word, selector);
+    return __builtin_bit_cast(EdtU16x2, v);
+}
+
 __global__ void __launch_bounds__(256) edt_lds_kernel(const uint32_t* __restrict__ bits, EntrySelect sel, int rows, int cols,
                                                       int wpr, int pad, int clamp, uint8_t* __restrict__ out)
 {
     const int W = cols + 2 * pad, H = rows + 2 * pad, Wq = (W + 3) / 4;
     const LdsU32 bm = (LdsU32)lds_dyn;   // [rows][wpr] lethal mask
     const LdsU32 hq = bm + rows * wpr;   // [H][Wq] h, four cells per dword
+    __attribute__((address_space(3))) uint8_t* const isq =
+        (__attribute__((address_space(3))) uint8_t*)(hq + H * Wq);   // [clamp^2 + 1] min(clamp, floor(sqrt(.)))
     const int tid = threadIdx.x;
     const uint32_t far4 = (uint32_t)clamp * 0x01010101u;
     const int64_t n_sel = sel.size();
+    for (int v = tid; v <= clamp * clamp; v += 256) {
+        int sq = (int)__builtin_amdgcn_sqrtf((float)v);   // v <= 3600: the fix-ups make it exact
+        while (sq * sq > v) --sq;
+        while ((sq + 1) * (sq + 1) <= v) ++sq;
+        isq[v] = (uint8_t)min(sq, clamp);
+    }
     for (int64_t k = blockIdx.x; k < n_sel; k += gridDim.x) {
         const int64_t m = sel.entry(k);
         __syncthreads();   // the previous map's pass 2 is done with the LDS
@@ -459,28 +476,31 @@ __global__ void __launch_bounds__(256) edt_lds_kernel(const uint32_t* __restrict
         }
         __syncthreads();
         uint8_t* field = out + m * (int64_t)W * H;
+        // (two cells per packed 16-bit operation: all values are <= 2 * clamp^2 <= 7200; the square roots come from a
+        //  table; no early exit -- it would cost as much per round as the round itself)
+        const EdtU16x2 far2 = {(unsigned short)clamp, (unsigned short)clamp};
         for (int rp = tid >> 6; rp < H; rp += 4) {
             for (int q = tid & 63; q < Wq; q += 64) {
-                int best[4] = {clamp * clamp, clamp * clamp, clamp * clamp, clamp * clamp};
+                EdtU16x2 best_lo = {(unsigned short)(clamp * clamp), (unsigned short)(clamp * clamp)}, best_hi = best_lo;
                 for (int d = 0; d < clamp; ++d) {
-                    const int dd = d * d;
-                    if (dd >= max(max(best[0], best[1]), max(best[2], best[3]))) break;
+                    const unsigned short dd = (unsigned short)(d * d);
+                    const EdtU16x2 dd2 = {dd, dd};
                     const uint32_t up = rp - d >= 0 ? hq[(rp - d) * Wq + q] : far4;
                     const uint32_t dn = rp + d < H ? hq[(rp + d) * Wq + q] : far4;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int hv = (int)min((up >> (8 * b)) & 0xffu, (dn >> (8 * b)) & 0xffu);
-                        best[b] = min(best[b], dd + hv * hv);
-                    }
+                    // bytes 0, 1 / 2, 3 of a dword, zero-extended to a pair of 16-bit values (v_perm_b32)
+                    const EdtU16x2 h_lo = __builtin_elementwise_min(edt_pair(up, 0x0c010c00u), edt_pair(dn, 0x0c010c00u));
+                    const EdtU16x2 h_hi = __builtin_elementwise_min(edt_pair(up, 0x0c030c02u), edt_pair(dn, 0x0c030c02u));
+                    best_lo = __builtin_elementwise_min(best_lo, (EdtU16x2)(h_lo * h_lo + dd2));
+                    best_hi = __builtin_elementwise_min(best_hi, (EdtU16x2)(h_hi * h_hi + dd2));
                 }
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int cp = q * 4 + b;
-                    if (cp >= W) break;
-                    int sq = (int)__builtin_amdgcn_sqrtf((float)best[b]);   // best <= 3600: the fix-ups make it exact
-                    while (sq * sq > best[b]) --sq;
-                    while ((sq + 1) * (sq + 1) <= best[b]) ++sq;
-                    field[rp * W + cp] = (uint8_t)min(sq, clamp);
+                (void)far2;
+                const uint32_t four = (uint32_t)isq[best_lo.x] | ((uint32_t)isq[best_lo.y] << 8) |
+                                      ((uint32_t)isq[best_hi.x] << 16) | ((uint32_t)isq[best_hi.y] << 24);
+                uint8_t* const dst = field + rp * W + q * 4;
+                if (q * 4 + 3 < W) {
+                    *reinterpret_cast<EdtU32Unaligned*>(dst) = four;
+                } else {
+                    for (int b = 0; q * 4 + b < W; ++b) dst[b] = (uint8_t)(four >> (8 * b));
                 }
             }
         }
@@ -848,7 +868,8 @@ static void launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_en
 {
     const MapDesc& m = h->map;
     const CullDesc& C = h->cull;
-    const size_t lds = ((size_t)m.rows * m.wpr + (size_t)C.height * ((C.width + 3) / 4)) * sizeof(uint32_t);
+    const size_t lds = ((size_t)m.rows * m.wpr + (size_t)C.height * ((C.width + 3) / 4)) * sizeof(uint32_t) +
+                       (((size_t)C.clamp * C.clamp + 1 + 3) & ~(size_t)3);
     // (one workgroup per map: worth it from a few dozen maps on; a lone shared map keeps the two wide kernels)
     if (C.clamp <= 60 && lds <= kMaxDynamicLds && h->edt_in_lds && max_entries >= 32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edt_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
