@@ -551,6 +551,9 @@ class BatchedRandomMiniEnv(BatchedPlanEnv):
         such periods.  Stepping on a high-priority stream (torch.cuda.Stream(priority=-1)) keeps the refresh kernels
         from delaying the steps (5 % in tools/bench_endless.py).
 
+        Snapshots (get_state / set_state) hold pool ENTRIES, not worlds: one taken before a refresh can be restored only
+        as long as the entries it points to have not been re-sampled.
+
         :param check bool: wait for the refresh to finish and raise what the reference's sampler would raise
         :return: device int32 [4] = (entries re-sampled, envs that were waiting on their newest world, 0, 0) of the
             refresh that was completed by this call; with check=True the first two as python ints"""
