@@ -160,3 +160,16 @@ def test_env_params_serialize_roundtrip():
     assert rec['version'] == 1 and rec['reward_provider_params'] == dict(
         spatial_precision=0.3, angular_precision=0.5, spatial_progress_multiplier=2.0, version=1)
     assert EnvParams.deserialize(rec) == p and EnvParams.deserialize(EnvParams().serialize()) == EnvParams()
+
+
+def test_c_client_compiles_against_the_header(tmp_path):
+    """include/bcplan.h is a C header: the plain C11 client of tests/c_abi builds and links against libbcplan.so with gcc
+    (it only runs on a GPU box: tests/test_gpu_c_abi.py)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "bc_gym_planning_env_amd", "libbcplan.so")
+    cmd = ["gcc", "-std=c11", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"),
+           "-I/opt/rocm/include", os.path.join(root, "tests", "c_abi", "step_from_c.c"), lib, "-L/opt/rocm/lib",
+           "-lamdhip64", "-lm", "-o", str(tmp_path / "step_from_c")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
