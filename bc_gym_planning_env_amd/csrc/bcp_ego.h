@@ -68,6 +68,28 @@ __device__ __forceinline__ uint32_t lds_byte_at(uint32_t addr)
 #endif
 }
 
+// A byte of LDS delivered as (byte << 16) (ds_read_u8_d16_hi; no compiler builtin).  Written for targets on which a d16
+// load writes the whole register, the other half zero (SRAM ECC: gfx90a / gfx942 / gfx950); the register is zeroed
+// first, so a target that preserved the other half would give the same value.  The compiler does not see the read as a
+// memory operation: the consumer calls lds_reads_done() (s_waitcnt lgkmcnt(0)) before it touches the result.
+__device__ __forceinline__ uint32_t lds_byte_shifted_16(uint32_t addr)
+{
+    uint32_t v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("ds_read_u8_d16_hi %0, %1" : "+v"(v) : "v"(addr));
+#else
+    (void)addr;
+#endif
+    return v;
+}
+
+__device__ __forceinline__ void lds_reads_done()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
@@ -271,20 +293,33 @@ __device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, 
             uint64_t packed = border8;
             if (rx != kRowOff) {
                 uint32_t half[2] = {0, 0};
+                if (STAGED) {
+                    // Every address on the border ring of the LDS copy is valid: clamp, read.  Packing four pixels
+                    // takes two operations instead of four: the third byte arrives already shifted (ds_read_u8_d16_hi
+                    // puts it into bits 16..23; on this ECC target the low half comes back zero), one v_perm_b32 places
+                    // bytes one and three, one v_or3_b32 joins the three registers.
+                    uint32_t val[PX];
 #pragma unroll
-                for (int j = 0; j < PX; ++j) {
-                    // (saturate_cast<short> never bites: |X|, |Y| < 2^21 and maps are < 2^15)
-                    const int X = (rx + ccx[j]) >> 10, Y = (ry + ccy[j]) >> 10;
-                    uint32_t val;
-                    if (STAGED) {   // clamp onto the border ring of the LDS copy: every address is valid
+                    for (int j = 0; j < PX; ++j) {
+                        // (saturate_cast<short> never bites: |X|, |Y| < 2^21 and maps are < 2^15)
+                        const int X = (rx + ccx[j]) >> 10, Y = (ry + ccy[j]) >> 10;
                         const int xc = clamp_med3(X, x_lo, x_hi), yc = clamp_med3(Y, y_lo, y_hi);
-                        val = lds_byte_at((uint32_t)(__mul24(yc, pitch) + xc));
-                    } else {        // global gather: only the in-map lanes issue a load
-                        val = border;
+                        const uint32_t addr = (uint32_t)(__mul24(yc, pitch) + xc);
+                        val[j] = (j & 3) == 2 ? lds_byte_shifted_16(addr) : lds_byte_at(addr);
+                    }
+                    lds_reads_done();
+#pragma unroll
+                    for (int k = 0; k < PX / 4; ++k)   // (b3 << 24) | (b1 << 8), then | b0 | (b2 << 16)
+                        half[k] = __builtin_amdgcn_perm(val[4 * k + 3], val[4 * k + 1], 0x040c000cu) | val[4 * k] | val[4 * k + 2];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) {   // global gather: only the in-map lanes issue a load
+                        const int X = (rx + ccx[j]) >> 10, Y = (ry + ccy[j]) >> 10;
+                        uint32_t val = border;
                         if ((unsigned)X < (unsigned)I.vc && (unsigned)Y < (unsigned)I.vr)
                             val = (uint32_t)src[(uint32_t)__mul24(Y, a.cols) + (uint32_t)X];
+                        half[j >> 2] |= val << (8 * (j & 3));
                     }
-                    half[j >> 2] |= val << (8 * (j & 3));
                 }
                 packed = ((uint64_t)half[1] << 32) | half[0];
             }
