@@ -68,15 +68,15 @@ __device__ __forceinline__ uint32_t lds_byte_at(uint32_t addr)
 #endif
 }
 
-// A byte of LDS delivered as (byte << 16) (ds_read_u8_d16_hi; no compiler builtin).  Written for targets on which a d16
-// load writes the whole register, the other half zero (SRAM ECC: gfx90a / gfx942 / gfx950); the register is zeroed
-// first, so a target that preserved the other half would give the same value.  The compiler does not see the read as a
+// A byte of LDS delivered as (byte << 16) (ds_read_u8_d16_hi; no compiler builtin).  Relies on what SRAM-ECC targets
+// (gfx90a / gfx942 / gfx950) do with d16 loads: the whole register is written, the other half as zero -- the
+// bit-exact image tests are the check.  The compiler does not see the read as a
 // memory operation: the consumer calls lds_reads_done() (s_waitcnt lgkmcnt(0)) before it touches the result.
 __device__ __forceinline__ uint32_t lds_byte_shifted_16(uint32_t addr)
 {
     uint32_t v = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("ds_read_u8_d16_hi %0, %1" : "+v"(v) : "v"(addr));
+    asm volatile("ds_read_u8_d16_hi %0, %1" : "=v"(v) : "v"(addr));   // (gfx950: the low half is written as zero)
 #else
     (void)addr;
 #endif
@@ -279,7 +279,13 @@ __device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, 
 {
     const uint32_t border = (uint32_t)a.border;
     const uint64_t border8 = (uint64_t)border * 0x0101010101010101ull;
-    const int x_lo = G.x_lo, x_hi = G.x_hi, y_lo = 0, y_hi = G.y_hi, pitch = G.pitch;   // ring coordinates (staged sampling)
+    int x_lo = G.x_lo, x_hi = G.x_hi, y_hi = G.y_hi;   // ring coordinates (staged sampling)
+    const int y_lo = 0, pitch = G.pitch;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_med3 takes one scalar operand at most: keep the clamp bounds in vector registers for the whole image instead of
+    // having them copied there again for every group of pixels
+    asm volatile("" : "+v"(x_lo), "+v"(x_hi), "+v"(y_hi));
+#endif
     for (int xg = PX * cg; xg < a.dcols; xg += 128) {
         const int x0 = min(xg, a.dcols - PX);
         int ccx[PX], ccy[PX];
