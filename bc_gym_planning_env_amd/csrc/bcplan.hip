@@ -478,7 +478,6 @@ __global__ void __launch_bounds__(256) edt_lds_kernel(const uint32_t* __restrict
         uint8_t* field = out + m * (int64_t)W * H;
         // (two cells per packed 16-bit operation: all values are <= 2 * clamp^2 <= 7200; the square roots come from a
         //  table; no early exit -- it would cost as much per round as the round itself)
-        const EdtU16x2 far2 = {(unsigned short)clamp, (unsigned short)clamp};
         for (int rp = tid >> 6; rp < H; rp += 4) {
             for (int q = tid & 63; q < Wq; q += 64) {
                 EdtU16x2 best_lo = {(unsigned short)(clamp * clamp), (unsigned short)(clamp * clamp)}, best_hi = best_lo;
@@ -493,7 +492,6 @@ __global__ void __launch_bounds__(256) edt_lds_kernel(const uint32_t* __restrict
                     best_lo = __builtin_elementwise_min(best_lo, (EdtU16x2)(h_lo * h_lo + dd2));
                     best_hi = __builtin_elementwise_min(best_hi, (EdtU16x2)(h_hi * h_hi + dd2));
                 }
-                (void)far2;
                 const uint32_t four = (uint32_t)isq[best_lo.x] | ((uint32_t)isq[best_lo.y] << 8) |
                                       ((uint32_t)isq[best_hi.x] << 16) | ((uint32_t)isq[best_hi.y] << 24);
                 uint8_t* const dst = field + rp * W + q * 4;
