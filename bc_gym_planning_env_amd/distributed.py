@@ -32,8 +32,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kwargs = {}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            kwargs["device_id"] = torch.device("cuda", local_rank)
+            dev = local_rank % max(1, torch.cuda.device_count())   # (rehearsals may put several ranks on one GPU)
+            torch.cuda.set_device(dev)
+            kwargs["device_id"] = torch.device("cuda", dev)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local_rank
 

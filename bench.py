@@ -197,6 +197,14 @@ def main():
     gather_every = 8
     ring = torch.zeros(gather_every, n, dtype=torch.uint8, device=torch.device("cuda", device)) if world > 1 else None
     gather = bdist.DoneGather(gather_every * n, torch.device("cuda", device)) if world > 1 else None
+    collective = None
+    if world > 1:
+        # the first collectives run here, untimed (communicator set-up)
+        gather.launch(ring.view(-1))
+        gather.flush()
+        dist.barrier()
+        torch.cuda.synchronize()
+        collective = dist.get_backend()
 
     # pre-staged synthetic actions: a pool of 16 batches ~ U(action_space), float32, resident in HBM
     rng = np.random.RandomState(1234 + rank)
@@ -277,8 +285,9 @@ def main():
             "config": {"workload": "C3: RandomMiniEnv seed-0 geometry, %d envs/GPU, tricycle dynamic model + PlanEnv "
                                    "odometry noise (on-device Philox), shared 183x183 costmap, reset on done, steady-state episode phases" % n,
                        "envs_total": total_envs, "envs_per_gpu": n, "actions": "float32 U(action_space), pre-staged",
-                       "sharding": "env blocks per rank, done masks ring-buffered on the device and all-gathered (RCCL) every "
-                                   "8 steps, overlapped with the next steps" if world > 1 else "single GPU"},
+                       "sharding": ("env blocks per rank, done masks ring-buffered on the device and all-gathered (%s) every "
+                                    "8 steps, overlapped with the next steps" % ("RCCL" if collective == "nccl" else collective))
+                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "step_fast_pair_kernel + step_pending_kernel (one step = these two launches)",
