@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # A kernel that never finishes must not hold the whole run: every test gets a generous wall-clock limit
+    # (pytest-timeout, when it is installed; the longest test here takes seconds).
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(600))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
