@@ -139,7 +139,7 @@ def aux_measurements(env, pool, n):
     del penv, worlds
     # ... and worlds that never repeat: one RandomState stream per env, the pool entries of a stream are a ring that is
     # re-sampled behind the env on a side stream while the steps go on (plan / refresh / release)
-    eenv = mini_env.BatchedRandomMiniEnv(n, episodes=4, endless=True, auto_reset=True, seed=3, device=env.device.index or 0)
+    eenv = mini_env.BatchedRandomMiniEnv(n, episodes=8, endless=True, auto_reset=True, seed=3, device=env.device.index or 0)
     eenv.state.current_iter.copy_(torch.from_numpy(rng.randint(0, eenv.params.iteration_timeout, n).astype(np.int32)).to(env.device))
     infos = []
     for k in range(256):
@@ -159,7 +159,7 @@ def aux_measurements(env, pool, n):
     ms_endless = e0.elapsed_time(e1) / 512
     tally = torch.stack(infos).sum(0).cpu().numpy() if infos else np.zeros(4)
     out["endless_geometry_pool"] = {
-        "what": "RandomMiniEnv(seed=i) for every env i, for ever: %d streams x 4 ring entries, refresh(overlap=True) every "
+        "what": "RandomMiniEnv(seed=i) for every env i, for ever: %d streams x 8 ring entries, refresh(overlap=True) every "
                 "128 steps re-samples the worlds the envs have left (MT19937 stream order) on a side stream" % n,
         "ms_per_step": ms_endless, "env_steps_per_s": n / (ms_endless * 1e-3),
         "worlds_resampled_per_refresh": float(tally[0]) / max(len(infos), 1),
