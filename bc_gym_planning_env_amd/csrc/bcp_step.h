@@ -439,6 +439,33 @@ __device__ __forceinline__ void fifo_delay(double* __restrict__ q, int delay, in
     }
 }
 
+// The same in two halves: fifo_peek() reads, before anything is pushed, the element the k-th push will hand back --
+// for k > delay the one it displaces, for 1 < k <= delay the list's first element (slot 0) -- and fifo_push() stores
+// the new element and returns the peeked one (the new element itself for k = 1).  So what State exposes at a step
+// (k > 1) is known before the robot model runs, and pushing twice (kernel 1 optimistically, kernel 2 again with the
+// rolled-back pose after a collision) lands in the same slot and hands back the same element.
+template <int W>
+__device__ __forceinline__ void fifo_peek(const double* __restrict__ q, int delay, int64_t n, int64_t i, int k, double (&peeked)[W])
+{
+    if (delay <= 0 || k <= 1) return;
+    const double* cell = q + ((int64_t)(k > delay ? (k - 1) % delay : 0) * W) * n + i;
+#pragma unroll
+    for (int c = 0; c < W; ++c) peeked[c] = cell[c * n];
+}
+
+template <int W>
+__device__ __forceinline__ void fifo_push(double* __restrict__ q, int delay, int64_t n, int64_t i, int k, double (&v)[W],
+                                          const double (&peeked)[W])
+{
+    if (delay <= 0) return;
+    double* cell = q + ((int64_t)((k - 1) % delay) * W) * n + i;
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+        cell[c * n] = v[c];
+        if (k > 1) v[c] = peeked[c];
+    }
+}
+
 constexpr int kWavePerPoseFrom = 1;   // step_pending_kernel: more than this many rounds of parked poses per team -> a pose per wave
 #ifdef BCP_DIAG
 constexpr int kDiagBlocks = 4096;   // stamps of the first kDiagBlocks workgroups of step_pending_kernel
@@ -558,6 +585,9 @@ struct Pending {
     int32_t collided;   // sticky flag before this step
     int32_t env_lo, env_hi;
     int32_t geom;       // geometry-pool entry of the env during this step (pool mode only)
+    // delays > 0: the elements this step's pushes into the pose / robot-state FIFOs will hand back (fifo_peek: read with
+    // the state, before anything is pushed), so that kernel 2 can redo the pushes of an env kernel 1 finished optimistically
+    double popped_pose[3], popped_state[7];
 };
 
 // entry of the non-shared map / path arrays that env i uses
@@ -598,8 +628,8 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     // State.pose / State.robot_state: what the reward provider and the observation see (env.py:377-394)
     double seen[3] = {r.p.x, r.p.y, r.p.th};
     double seen_rs[7] = {r.p.x, r.p.y, r.p.th, r.v, r.w, r.steer, r.wheel};
-    if (pose_delay) fifo_delay<3>(a.S->st.pose_q, pose_delay, n, i, iter, seen);
-    if (state_delay) fifo_delay<7>(a.S->st.state_q, state_delay, n, i, iter, seen_rs);
+    if (pose_delay) fifo_push<3>(a.S->st.pose_q, pose_delay, n, i, iter, seen, q.popped_pose);
+    if (state_delay) fifo_push<7>(a.S->st.state_q, state_delay, n, i, iter, seen_rs, q.popped_state);
 
     // shared path: uniform pointers (scalar cache); private paths: per-lane pointers
     double rew = 0.0;
@@ -612,7 +642,9 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
         if (!(a.flags & kAblateNoReward)) rew = reward_pure_pursuit(pts, m, seen[0], seen[1], collided, min_dist, target);
         goal = hypot(pts[5 * (m - 1)] - seen[0], pts[5 * (m - 1) + 1] - seen[1]) < 1.0;   // done(), reward.py:141-150
     } else {
-        if (scored && !hit && !pose_delay) {   // the scorer wave has already done it (step_fast_pair_kernel)
+        // the scorer wave has already done it (step_fast_pair_kernel) for the pose State exposes if nothing collides --
+        // which, with a pose delay, is an earlier pose whatever this step's verdict (from the second step of an episode on)
+        if (scored && (!hit || (pose_delay && iter > 1))) {
             rew = scored->rew;
             min_dist = scored->min_dist;
             target = scored->target;
@@ -732,6 +764,10 @@ __device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, bool acti
         cmd0 = cmd[0];
         cmd1 = cmd[1];
     }
+    if (!PLAIN) {   // what this step's pushes will displace (k = iter + 1)
+        fifo_peek<3>(a.hot.st.pose_q, P.pose_delay, a.hot.n, i, q.iter + 1, q.popped_pose);
+        fifo_peek<7>(a.hot.st.state_q, P.state_delay, a.hot.n, i, q.iter + 1, q.popped_state);
+    }
     q.z[0] = q.z[1] = q.z[2] = 0.0;
     if (P.noise_on) {
         if (a.noise_z) {
@@ -787,7 +823,9 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs launch_args
 // scorer runs the reward provider for the free pose meanwhile, and the mover picks the result up for every env that
 // did not collide in place (those redo the reward themselves for the rolled-back pose).
 // LDS: [qverts][shared path][64 x {x, y, theta}][64 x {reward, min_dist, target}]
-template <bool WIDE>
+// PLAIN = false: delay queues and / or the pure-pursuit provider (finalize_env's general form; the scorer wave's
+// result is then only used where it applies: continuous reward, no pose delay).
+template <bool WIDE, bool PLAIN>
 __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepArgs launch_args)
 {
     const StepArgs a = resolve_step(launch_args, 0);
@@ -811,7 +849,7 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
     Pending q;
     double cmd0 = 0.0, cmd1 = 0.0;
     if (mover) {
-        load_env<true>(a, i, active, q, cmd0, cmd1);
+        load_env<PLAIN>(a, i, active, q, cmd0, cmd1);
         if (gi < kShards) a.pending_next[gi] = 0;  // arm the counters of the NEXT step (the two sets alternate)
         if (gi < kShards && a.inplace_next) a.inplace_next[gi] = 0;
     } else {
@@ -860,9 +898,11 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
         q.old = r.p;
         q.drawn = 0;
         q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
-        hand_pose[lane] = r.p.x;
-        hand_pose[kBlock + lane] = r.p.y;
-        hand_pose[2 * kBlock + lane] = r.p.th;
+        // the pose the reward provider will see: the new one, or -- with a pose delay -- the one fifo_peek fetched
+        const bool delayed = !PLAIN && P.pose_delay > 0 && q.iter + 1 > 1;
+        hand_pose[lane] = delayed ? q.popped_pose[0] : r.p.x;
+        hand_pose[kBlock + lane] = delayed ? q.popped_pose[1] : r.p.y;
+        hand_pose[2 * kBlock + lane] = delayed ? q.popped_pose[2] : r.p.th;
     }
     __syncthreads();
 
@@ -941,7 +981,7 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
         sc.rew = hand_score[lane];
         sc.min_dist = hand_score[kBlock + lane];
         sc.target = (int)hand_score[2 * kBlock + lane];
-        finalize_env<true>(a, i, q, hit, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &sc);
+        finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &sc);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) a.tick[1] = a.step_counter;   // for kernel 2 (see StepArgs::tick)
     advance_step_by_ticket(a);   // (only when no kernel 2 follows)
@@ -958,7 +998,7 @@ constexpr int kPendingWaves = 4;  // wave = 2 * (row-chunk slot) + (edge slot)
 // former limit of 8192); the in-place path remains for far denser cases and as BCP_TUNE_DENSE_THRESHOLD.
 constexpr int kParkCapacity = 1 << 20;
 
-template <bool WIDE>
+template <bool WIDE, bool PLAIN>
 __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(const StepArgs launch_args)
 {
     const StepArgs a = resolve_step(launch_args, 1);
@@ -994,7 +1034,7 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
                                           a.hot.map_wpr);
             if (hit && lane == 0) {
                 Pending q = *e;
-                finalize_env<true>(a, i, q, true);
+                finalize_env<PLAIN>(a, i, q, true);
             }
         }
         return;
@@ -1021,7 +1061,7 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
         // kernel 1 already finished this env as "free"; only a collision changes anything
         if (hit && threadIdx.x == 0) {
             Pending q = *e;
-            finalize_env<true>(a, i, q, true);
+            finalize_env<PLAIN>(a, i, q, true);
         }
     }
 }

@@ -1117,14 +1117,16 @@ extern "C" int bcp_broadcast_state(bcp_handle* h, int64_t src, const uint8_t* ma
 }
 
 // (re)builds the device-resident StepStatic block; returns whether the two-kernel (deferring) step is in effect
+// no delay queues and the continuous reward provider: the step kernels compile both out (their PLAIN variants)
+static bool step_is_plain(const bcp_handle* h)
+{
+    const bcp_params& p = h->params;
+    return p.control_delay == 0 && p.pose_delay == 0 && p.state_delay == 0 && p.reward_provider == BCP_REWARD_CONTINUOUS;
+}
+
 static bool step_uses_deferral(const bcp_handle* h)
 {
-    // delays and the pure-pursuit provider run through the general kernel: the optimistic finalisation of the fast
-    // kernel cannot be redone once a FIFO slot has been overwritten
-    const bcp_params& p = h->params;
-    const bool plain = p.control_delay == 0 && p.pose_delay == 0 && p.state_delay == 0 &&
-                       p.reward_provider == BCP_REWARD_CONTINUOUS;
-    return plain && h->defer && h->cull.on && h->exact_mode == 0 && h->pending != nullptr;
+    return h->defer && h->cull.on && h->exact_mode == 0 && h->pending != nullptr;
 }
 
 static int upload_step_static(bcp_handle* h, hipStream_t s)
@@ -1209,12 +1211,25 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
         if (!second) a.flags |= kStepAdvances;   // kernel 1 is the whole step
         // kernel 1 runs with two wavefronts per 64 envs (mover + scorer, step_fast_pair_kernel)
         const size_t lds1p = lds1 + ((size_t)6 * kBlock + 8) * sizeof(double) + 2 * kBlock * sizeof(uint32_t);
-        if (S.wide) {
-            hipLaunchKernelGGL(step_fast_pair_kernel<true>, dim3(blocks), dim3(2 * kBlock), lds1p, s, a);
-            if (second) hipLaunchKernelGGL(step_pending_kernel<true>, dim3(waves), dim3(kBlock * kPendingWaves), lds2, s, a);
-        } else {
-            hipLaunchKernelGGL(step_fast_pair_kernel<false>, dim3(blocks), dim3(2 * kBlock), lds1p, s, a);
-            if (second) hipLaunchKernelGGL(step_pending_kernel<false>, dim3(waves), dim3(kBlock * kPendingWaves), lds2, s, a);
+        const dim3 g1(blocks), b1(2 * kBlock), g2(waves), b2(kBlock * kPendingWaves);
+        const int variant = (S.wide ? 2 : 0) | (step_is_plain(h) ? 1 : 0);
+        switch (variant) {
+            case 3:
+                hipLaunchKernelGGL((step_fast_pair_kernel<true, true>), g1, b1, lds1p, s, a);
+                if (second) hipLaunchKernelGGL((step_pending_kernel<true, true>), g2, b2, lds2, s, a);
+                break;
+            case 2:
+                hipLaunchKernelGGL((step_fast_pair_kernel<true, false>), g1, b1, lds1p, s, a);
+                if (second) hipLaunchKernelGGL((step_pending_kernel<true, false>), g2, b2, lds2, s, a);
+                break;
+            case 1:
+                hipLaunchKernelGGL((step_fast_pair_kernel<false, true>), g1, b1, lds1p, s, a);
+                if (second) hipLaunchKernelGGL((step_pending_kernel<false, true>), g2, b2, lds2, s, a);
+                break;
+            default:
+                hipLaunchKernelGGL((step_fast_pair_kernel<false, false>), g1, b1, lds1p, s, a);
+                if (second) hipLaunchKernelGGL((step_pending_kernel<false, false>), g2, b2, lds2, s, a);
+                break;
         }
     } else {
         const size_t lds = collision_lds_bytes(h->params.n_verts, h->map.in_lds, h->map.rows, h->map.wpr);
