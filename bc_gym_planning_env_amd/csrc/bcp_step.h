@@ -639,7 +639,13 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
     const double* pts = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
     m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
     if (pure_pursuit) {
-        if (!(a.flags & kAblateNoReward)) rew = reward_pure_pursuit(pts, m, seen[0], seen[1], collided, min_dist, target);
+        if (scored && !hit) {   // the scorer wave has already done it (no collision: the flag it assumed stands)
+            rew = scored->rew;
+            min_dist = scored->min_dist;
+            target = scored->target;
+        } else if (!(a.flags & kAblateNoReward)) {
+            rew = reward_pure_pursuit(pts, m, seen[0], seen[1], collided, min_dist, target);
+        }
         goal = hypot(pts[5 * (m - 1)] - seen[0], pts[5 * (m - 1) + 1] - seen[1]) < 1.0;   // done(), reward.py:141-150
     } else {
         // the scorer wave has already done it (step_fast_pair_kernel) for the pose State exposes if nothing collides --
@@ -856,6 +862,7 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
         q.min_dist = a.hot.st.min_dist[i];
         q.target = a.hot.st.target_idx[i];
         q.geom = a.hot.geom_of_env ? a.hot.geom_of_env[i] : 0;
+        q.collided = PLAIN ? 0 : (int32_t)(a.hot.st.collided[i] != 0);   // (the pure-pursuit reward depends on it)
     }
     // the scorer also brings the bounding box and the bucket index of a shared path into LDS while the mover is busy
     // with the robot model (its window look-up then needs no global round trip); a private path's box is fetched now
@@ -966,11 +973,15 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
         double min_dist = q.min_dist;
         int target = q.target;
         double rew;
-        if (lds_path)
+        const double* gpath = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
+        if (!PLAIN && P.reward_provider == BCP_REWARD_PURE_PURSUIT) {   // (no collision this step: the sticky flag as it is)
+            if (lds_path) rew = reward_pure_pursuit(lds_path, m, x, y, q.collided != 0, min_dist, target);
+            else rew = reward_pure_pursuit(gpath, m, x, y, q.collided != 0, min_dist, target);
+        } else if (lds_path) {
             rew = reward_step(P, lds_path, win, m, x, y, th, min_dist, target);
-        else
-            rew = reward_step(P, a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5), win, m, x, y, th,
-                              min_dist, target);
+        } else {
+            rew = reward_step(P, gpath, win, m, x, y, th, min_dist, target);
+        }
         hand_score[lane] = rew;
         hand_score[kBlock + lane] = min_dist;
         hand_score[2 * kBlock + lane] = (double)target;
