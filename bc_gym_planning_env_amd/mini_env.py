@@ -490,7 +490,7 @@ class BatchedRandomMiniEnv(BatchedPlanEnv):
         reference's), "device_resident" (the same, and the pool never leaves the GPU: for 10^5 .. 10^6 worlds) or
         "host" (sample_pool: numpy, bit-identical to the reference, ~3 x 10^3 worlds/s)
     :param draw_new_turn_on_reset bool: False keeps every env on its first world (RandomMiniEnv's flag of that name)
-    :param endless bool: one stream per env (seeds[i] or i), pool kept on the GPU, and the `episodes` entries of an env
+    :param endless bool: one stream per env (seeds[i], by default env_id_base + i), pool kept on the GPU, and the `episodes` entries of an env
         are a ring over its stream that refresh() tops up behind it: env i sees the worlds of RandomMiniEnv(seed=seeds[i])
         for as long as it runs, never an old one again.  Call refresh() every few steps (see there).
     Remaining keyword arguments go to BatchedPlanEnv (auto_reset, seed, noise_parameters, env_id_base, ...).
@@ -502,7 +502,9 @@ class BatchedRandomMiniEnv(BatchedPlanEnv):
         if endless:
             if pool is not None or n_chains not in (None, int(n_envs)) or not draw_new_turn_on_reset or episodes < 2:
                 raise ValueError("endless=True samples its own pool: one stream per env, episodes >= 2")
-            sampler, seeds = "device_resident", (range(int(n_envs)) if seeds is None else seeds)
+            # default streams: seed = GLOBAL env index, so that the ranks of a sharded batch draw different worlds
+            base = int(kw.get("env_id_base", 0))
+            sampler, seeds = "device_resident", (range(base, base + int(n_envs)) if seeds is None else seeds)
             if len(list(seeds)) != int(n_envs):
                 raise ValueError("endless=True needs one seed per env")
         if pool is None:
