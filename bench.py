@@ -294,7 +294,8 @@ def main():
                          "kernel_ms": step_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n,
                          "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
-                         "note": "shared-map config is ALU/latency-bound (SURVEY 8d): the HBM fraction is low by "
+                         "note": "shared-map config is latency-bound (SURVEY 8d; SQ counters in profiles/r01_step_alu_pmc.json: "
+                                 "waves wait 73 % of their cycles at 2 waves per SIMD): the HBM fraction is low by "
                                  "construction; see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
