@@ -11,7 +11,7 @@ MAX_VERTS = 32
 MODEL_TRICYCLE, MODEL_DIFFDRIVE = 0, 1
 REWARD_CONTINUOUS, REWARD_PURE_PURSUIT = 0, 1
 STEP_AUTO_RESET, STEP_ACTIONS_F32 = 1, 2
-ERR_ANGLE_JUMP = 1
+ERR_ANGLE_JUMP, ERR_TIME_ORDER = 1, 2
 TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL, TUNE_DEFER, TUNE_EDT_LDS = 0, 1, 2, 3, 4
 E_NO_DEVICE = -2
 
@@ -80,6 +80,13 @@ SYMBOLS = {
     "bcp_step": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_void_p]),
     "bcp_robot_step": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcp_pose_collides": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bcp_is_robot_colliding": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bcp_is_footprint_colliding": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_uint8,
+                                             C.c_void_p, C.c_void_p]),
+    "bcp_reward": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p]),
+    "bcp_find_last_reached": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bcp_path_velocity": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcp_pixel_footprint": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int32, C.c_void_p,
                                       C.c_void_p]),
     "bcp_normalize_angle": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -99,6 +106,8 @@ SYMBOLS = {
     "bcp_release_mini_worlds": (C.c_int, [_H, C.c_void_p]),
     "bcp_mini_world_paths": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    "bcp_device_normals": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "bcp_step_form": (C.c_int, [_H]),
     "bcp_time_step_kernels": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p,
                                         C.POINTER(C.c_float)]),
     "bcp_time_steps": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]),

@@ -295,7 +295,9 @@ class State(Serializable):
                            control_queue=list(self.control_queue), robot_state=self.robot_state.copy())
 
     def serialize(self):
-        """envs/base/env.py:163-176"""
+        """envs/base/env.py:163-176, key for key.  The reference renders the state with a recursive attr.asdict first,
+        so the entries of robot_state_queue are plain field dicts (no 'version') and those of control_queue are
+        {'command': array} dicts; robot_state and reward_provider_state are then replaced by their own serialize()."""
         resu = attr.asdict(self, recurse=False)
         resu['version'] = self.VERSION
         resu['costmap'] = self.costmap.get_state()
@@ -303,14 +305,17 @@ class State(Serializable):
         resu['reward_provider_state'] = self.reward_provider_state.serialize()
         resu['robot_type_name'] = self.robot_state.get_robot_type_name()
         resu['robot_state'] = self.robot_state.serialize()
-        resu['robot_state_queue'] = [r.serialize() for r in self.robot_state_queue]
-        resu['control_queue'] = [np.asarray(a.command) for a in self.control_queue]
+        resu['robot_state_queue'] = [attr.asdict(r) for r in self.robot_state_queue]
+        resu['control_queue'] = [{'command': np.asarray(a.command)} for a in self.control_queue]
+        resu['poses_queue'] = list(self.poses_queue)
         return resu
 
     @classmethod
     def deserialize(cls, state):
-        """envs/base/env.py:135-161 (the reference writes 'reward_provider_state_type_name' and reads
-        'reward_provider_state_name'; both spellings are accepted here)"""
+        """envs/base/env.py:135-161.  Reads what State.serialize writes -- ours and the reference's own records.  (The
+        reference cannot read its own: it writes 'reward_provider_state_type_name' and pops 'reward_provider_state_name',
+        pops a 'version' the queue entries do not have, and leaves control_queue entries as dicts; all of these forms are
+        accepted here, as are round 1's records with bare command arrays.)"""
         state = dict(state)
         assert state.pop('version') == cls.VERSION
         state['costmap'] = CostMap2D.from_state(state['costmap'])
@@ -321,8 +326,11 @@ class State(Serializable):
         rs_cls = {INDUSTRIAL_TRICYCLE_V1: TricycleRobotState, INDUSTRIAL_DIFFDRIVE_V1: DiffdriveRobotState}[
             state.pop('robot_type_name')]
         state['robot_state'] = rs_cls.deserialize(state['robot_state'])
-        state['robot_state_queue'] = [rs_cls.deserialize(r) for r in state['robot_state_queue']]
-        state['control_queue'] = [Action(command=np.asarray(c)) for c in state['control_queue']]
+        state['robot_state_queue'] = [rs_cls.deserialize(dict(r, version=r.get('version', rs_cls.VERSION)))
+                                      for r in state['robot_state_queue']]
+        state['control_queue'] = [Action(command=np.asarray(c['command'] if isinstance(c, dict) else c))
+                                  for c in state['control_queue']]
+        state['poses_queue'] = [np.asarray(p) for p in state['poses_queue']]
         return cls(**state)
 
     def __eq__(self, other):

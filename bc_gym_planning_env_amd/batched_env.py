@@ -262,11 +262,13 @@ class BatchedPlanEnv(object):
         next_geom[entry] (RandomMiniEnv.reset with draw_new_turn_on_reset, envs/mini_env.py:469-481).  Note that the
         constructor ends with reset(), like the reference's usage `env = RandomMiniEnv(); env.reset()`.
     :param next_geom: optional int array [G], successor of every pool entry; None = stay on the same entry
+    :param map_storage: optional (rows, cols): private costmaps are stored with at least this (padded) shape, e.g.
+        (256, 256) for BASELINE's "per-env 256x256 costmap"; the true shapes still bound the collision test
     """
 
     def __init__(self, costmap, path, params=None, n_envs=1, device=0, robot_name=None, noise_parameters='planenv',
                  auto_reset=False, env_id_base=0, seed=0, footprint_scale=1.0, dynamic_model=True,
-                 model_front_column_pid=True, template_of_env=None, geom_of_env=None, next_geom=None):
+                 model_front_column_pid=True, template_of_env=None, geom_of_env=None, next_geom=None, map_storage=None):
         params = EnvParams() if params is None else params
         self.params = params
         self._pure_pursuit = params.reward_provider_name == CONTINUOUS_REWARD_PURE_PURSUIT
@@ -311,6 +313,7 @@ class BatchedPlanEnv(object):
         self.envs = _EnvViews(self)
         self._keep = {}  # device buffers the library holds pointers to
 
+        self._map_storage = (0, 0) if map_storage is None else (int(map_storage[0]), int(map_storage[1]))
         self._template_of_env = None if template_of_env is None else np.asarray(template_of_env, dtype=np.int64)
         self.geom_of_env = None
         if geom_of_env is not None:
@@ -393,8 +396,8 @@ class BatchedPlanEnv(object):
             if any(float(c.get_resolution()) != res for c in costmaps):
                 raise ValueError("all costmaps must share one resolution")
             self._costmaps, self._shared_map = costmaps, False
-            rows = max(c.get_data().shape[0] for c in costmaps)
-            cols = max(c.get_data().shape[1] for c in costmaps)
+            rows = max(self._map_storage[0], max(c.get_data().shape[0] for c in costmaps))
+            cols = max(self._map_storage[1], max(c.get_data().shape[1] for c in costmaps))
             data = np.zeros((n, rows, cols), dtype=np.uint8)
             vr = np.zeros(n, dtype=np.int32)
             vc = np.zeros(n, dtype=np.int32)
@@ -427,8 +430,8 @@ class BatchedPlanEnv(object):
             idx = torch.from_numpy(self._template_of_env).to(dev)
             assert idx.numel() == n and int(idx.max()) < len(costmaps) == len(paths)
         res = float(costmaps[0].get_resolution())
-        rows = max(c.get_data().shape[0] for c in costmaps)
-        cols = max(c.get_data().shape[1] for c in costmaps)
+        rows = max(self._map_storage[0], max(c.get_data().shape[0] for c in costmaps))
+        cols = max(self._map_storage[1], max(c.get_data().shape[1] for c in costmaps))
         t_data = np.zeros((len(costmaps), rows, cols), dtype=np.uint8)
         t_shape = np.zeros((len(costmaps), 2), dtype=np.int32)
         t_org = np.zeros((len(costmaps), 2), dtype=np.float64)
@@ -703,6 +706,16 @@ class BatchedPlanEnv(object):
         io.reward, io.done = self.reward.data_ptr(), self.done.data_ptr()
         io.collided_now, io.err = self.collided_now.data_ptr(), self.err.data_ptr()
         return a, io, flags
+
+    STEP_FORMS = {0: "step_kernel", 1: "step_fast_pair_kernel",
+                  2: "step_fast_pair_kernel + step_pending_kernel (one step = these two launches)"}
+
+    def step_kernels(self):
+        """The kernels one step() launches as the handle is configured now (bcp_step_form)."""
+        form = self._lib.bcp_step_form(self._h)
+        if form < 0:
+            _lib.check(form)
+        return self.STEP_FORMS[form]
 
     def time_steps(self, actions, steps, noise_z=None):
         """Average device time (ms) of one step over `steps` back-to-back steps, measured with HIP events on the

@@ -102,6 +102,7 @@ struct bcp_handle {
     int32_t ring_episodes;    // of the last bcp_plan_mini_worlds
     bool ring_planned, ring_refreshed;   // plan -> refresh -> release, in that order
     int32_t edt_in_lds;       // distance transform of maps that fit: the LDS-resident kernel (BCP_TUNE_EDT_LDS)
+    int32_t last_step_form;   // 0 none yet, 1 single-kernel step, 2 two-kernel step (parking counters in use)
 };
 
 // number of entries of a non-shared map / path / initial-state array
@@ -254,7 +255,9 @@ __global__ void __launch_bounds__(kBlock) pose_collides_kernel(DevParams P, MapD
                                                                int dense_threshold, int wide,
                                                                const double* __restrict__ poses, int64_t n, int64_t n_envs,
                                                                const int32_t* __restrict__ geom_of_env,
-                                                               uint8_t* __restrict__ out)
+                                                               uint8_t* __restrict__ out, int origin_in_map,
+                                                               const int32_t* __restrict__ valid_rows,
+                                                               const int32_t* __restrict__ valid_cols)
 {
     const int tid = threadIdx.x;
     const int64_t gi = (int64_t)blockIdx.x * kBlock + tid;
@@ -262,8 +265,15 @@ __global__ void __launch_bounds__(kBlock) pose_collides_kernel(DevParams P, MapD
     const int64_t i = active ? gi : n - 1;
     const CollisionLds L = collision_lds_setup(P, map, tid);
     const int64_t env = geom_of_env ? (int64_t)geom_of_env[i % n_envs] : i % n_envs;
-    const bool hit = collides_wave(P, map, cull, L, exact_mode, dense_threshold, wide != 0, active, env, poses[3 * i],
-                                   poses[3 * i + 1], poses[3 * i + 2]);
+    bool hit = collides_wave(P, map, cull, L, exact_mode, dense_threshold, wide != 0, active, env, poses[3 * i],
+                             poses[3 * i + 1], poses[3 * i + 2]);
+    if (origin_in_map) {   // is_robot_colliding: a robot whose own pixel is off the map never collides (costmap_utils.py:127-130)
+        const double ox = map.origins ? map.origins[2 * env] : map.ox, oy = map.origins ? map.origins[2 * env + 1] : map.oy;
+        const int64_t px = (int64_t)rint((poses[3 * i] - ox) * map.inv_res), py = (int64_t)rint((poses[3 * i + 1] - oy) * map.inv_res);
+        const int rows = (!map.shared && valid_rows) ? valid_rows[env] : map.rows;
+        const int cols = (!map.shared && valid_cols) ? valid_cols[env] : map.cols;
+        if (px < 0 || py < 0 || px >= cols || py >= rows) hit = false;
+    }
     if (active) out[i] = (uint8_t)hit;
 }
 
@@ -582,6 +592,119 @@ __global__ void goal_direction_state_kernel(const StepStatic* __restrict__ S, do
     o[2] = S->st.v[i];
     o[3] = S->st.w[i];
     o[4] = S->P.model == BCP_MODEL_TRICYCLE ? S->st.wheel[i] : 0.0;
+}
+
+
+// ---- reward-provider / path-tools operator seams (envs/base/reward.py:184-259, utilities/path_tools.py:298-448) ----
+// reward_provider.reward(state) + .done(state) for n (pose, provider state) pairs; pose i is scored against the path of
+// env i % n_envs (its current pool entry in geometry-pool mode) with the very device functions the step kernels use.
+__global__ void reward_kernel(const StepStatic* __restrict__ S, const double* __restrict__ poses, int64_t n,
+                              double* __restrict__ min_dist_io, int32_t* __restrict__ target_io,
+                              const uint8_t* __restrict__ collided, double* __restrict__ reward, uint8_t* __restrict__ goal)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevParams& P = S->P;
+    const int64_t e = i % S->n;
+    const int64_t g = S->path.shared ? 0 : (S->geom_of_env ? (int64_t)S->geom_of_env[e] : e);
+    const double* pts = S->path.pts + g * (int64_t)S->path.max_len * 5;
+    const int m = S->path.shared ? S->path.max_len : S->path.lens[g];
+    const double x = poses[3 * i], y = poses[3 * i + 1], th = poses[3 * i + 2];
+    double min_dist = min_dist_io[i];
+    int target = target_io[i];
+    double rew;
+    bool reached;
+    if (P.reward_provider == BCP_REWARD_PURE_PURSUIT) {
+        rew = reward_pure_pursuit(pts, m, x, y, collided && collided[i], min_dist, target);
+        reached = hypot(pts[5 * (m - 1)] - x, pts[5 * (m - 1) + 1] - y) < 1.0;   // reward.py:141-150
+    } else {
+        const PathWindow w = path_window(P, S->path.bbox + g * 8, S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+        rew = reward_step(P, pts, w, m, x, y, th, min_dist, target);
+        reached = target > m - 1;                                                 // reward.py:66-69
+    }
+    min_dist_io[i] = min_dist;
+    target_io[i] = target;
+    reward[i] = rew;
+    if (goal) goal[i] = (uint8_t)reached;
+}
+
+// find_last_reached(pose, path, spatial_precision, angular_precision) (path_tools.py:432-448): index of the LAST way
+// point of the whole path the pose has reached, -1 for None
+__global__ void find_last_reached_kernel(const StepStatic* __restrict__ S, const double* __restrict__ poses, int64_t n,
+                                         int32_t* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t e = i % S->n;
+    const int64_t g = S->path.shared ? 0 : (S->geom_of_env ? (int64_t)S->geom_of_env[e] : e);
+    const double* pts = S->path.pts + g * (int64_t)S->path.max_len * 5;
+    const int m = S->path.shared ? S->path.max_len : S->path.lens[g];
+    const double x = poses[3 * i], y = poses[3 * i + 1], th = poses[3 * i + 2];
+    const PathWindow w = path_window(S->P, S->path.bbox + g * 8, S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+    out[i] = last_reached_from(S->P, pts, w, m, 0, x, y, th);
+}
+
+// path_velocity(path) (path_tools.py:298-323) for an n-row (t, x, y, angle) path: row j of the output belongs to the
+// segment j -> j + 1.  err: BCP_ERR_ANGLE_JUMP where the reference raises, BCP_ERR_TIME_ORDER where its assert fires.
+__global__ void path_velocity_kernel(const double* __restrict__ path, int64_t n, double* __restrict__ v,
+                                     double* __restrict__ w, int32_t* __restrict__ err)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n - 1) return;
+    const double* a = path + 4 * j;
+    const double* b = a + 4;
+    const double dt = b[0] - a[0];
+    Pose p0 = {a[1], a[2], a[3]}, p1 = {b[1], b[2], b[3]};
+    double vv, ww;
+    int e = path_velocity(p0, p1, dt, vv, ww);
+    if (!(dt > 0)) e |= BCP_ERR_TIME_ORDER;
+    v[j] = vv;
+    w[j] = ww;
+    if (err) err[j] = e;
+}
+
+// is_footprint_colliding_impl(image_slice, blit_mask, lethal) (costmap_utils.py:106-136): any(image_slice[blit_mask] ==
+// lethal) for n (slice, mask) pairs of one shape; one wavefront per pair, 4 cells per lane and load, wave-wide OR.
+__global__ void __launch_bounds__(256) footprint_colliding_kernel(const uint8_t* __restrict__ slices,
+                                                                  const uint8_t* __restrict__ masks, int64_t n,
+                                                                  int64_t cells, uint32_t lethal, uint8_t* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const uint8_t* s = slices + i * cells;
+    const uint8_t* k = masks + i * cells;
+    // the pair's first byte is only byte aligned: peel up to the first 4-byte boundary of BOTH arrays when they agree,
+    // otherwise go byte by byte (n * cells is rarely worth more)
+    bool hit = false;
+    const bool words = (((uintptr_t)s | (uintptr_t)k) & 3) == 0;
+    const int64_t n4 = words ? cells / 4 : 0;
+    const uint32_t l4 = lethal * 0x01010101u;
+    for (int64_t q = lane; q < n4 && !hit; q += 64) {
+        const uint32_t sv = reinterpret_cast<const uint32_t*>(s)[q], kv = reinterpret_cast<const uint32_t*>(k)[q];
+        const uint32_t x = sv ^ l4;   // a zero byte <=> the cell is lethal
+#pragma unroll
+        for (int b = 0; b < 4; ++b) hit |= ((x >> (8 * b)) & 0xFFu) == 0 && ((kv >> (8 * b)) & 0xFFu) != 0;
+    }
+    for (int64_t q = 4 * n4 + lane; q < cells && !hit; q += 64) hit |= s[q] == lethal && k[q] != 0;
+    hit = __any(hit);
+    if (lane == 0) out[i] = (uint8_t)hit;
+}
+
+
+// the standard normals the step kernels draw for (seed, global env index, step counter): introspection of the noise stream
+__global__ void device_normals_kernel(uint64_t seed, int64_t env_id_base, int64_t n, uint64_t step0, int32_t n_steps,
+                                      double* __restrict__ out)
+{
+    const int64_t total = n * n_steps;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = it / n, i = it % n;
+        double z[3];
+        device_normals(seed, (uint64_t)(env_id_base + i), step0 + (uint64_t)k, z);
+        out[3 * it + 0] = z[0];
+        out[3 * it + 1] = z[1];
+        out[3 * it + 2] = z[2];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host API
@@ -1157,6 +1280,19 @@ static int upload_step_static(bcp_handle* h, hipStream_t s)
     return BCP_OK;
 }
 
+// The parity-keyed parking / adaptation counters are only maintained by the two-kernel step (kernel 1 zeroes the NEXT
+// step's set).  Whenever the step form changes (bcp_set_tuning between steps, a costmap without distance field, ...)
+// both sets are re-armed on the stream of the steps, so the two-kernel step never resumes on stale counts.
+static int rearm_parking(bcp_handle* h, hipStream_t s)
+{
+    if (h->pending_count) HIP_TRY(hipMemsetAsync(h->pending_count, 0, 2 * kShards * sizeof(int32_t), s));
+    if (h->adapt) {
+        HIP_TRY(hipMemsetAsync(h->adapt + 2, 0, 2 * kShards * sizeof(int32_t), s));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)h->adapt, h->dense_threshold, 2, s));
+    }
+    return BCP_OK;
+}
+
 static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hipStream_t s, bool first_only = false)
 {
     if (h->static_dirty) {
@@ -1164,6 +1300,14 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
         if (rc != BCP_OK) return rc;
     }
     const StepStatic& S = h->host_static;
+    const int32_t form = S.pending ? 2 : 1;
+    if (form != h->last_step_form) {
+        if (form == 2 && h->last_step_form != 0) {
+            const int rc = rearm_parking(h, s);
+            if (rc != BCP_OK) return rc;
+        }
+        h->last_step_form = form;
+    }
     StepArgs a;
     a.S = h->dev_static;
     StepHot& hot = a.hot;
@@ -1239,9 +1383,19 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     return BCP_OK;
 }
 
+// Flags a caller may pass.  The ablation switches of bcp_step.h (timing experiments, results wrong by construction)
+// exist only in a -DBCP_DIAG build (tools/); kStepAdvances is internal and never accepted.
+#ifdef BCP_DIAG
+constexpr uint32_t kCallerFlags = BCP_STEP_AUTO_RESET | BCP_STEP_ACTIONS_F32 | kAblateNoCollision | kAblateNoReward |
+                                  kAblateNoCoop | kAblateNoPark | kAblateNoClassify;
+#else
+constexpr uint32_t kCallerFlags = BCP_STEP_AUTO_RESET | BCP_STEP_ACTIONS_F32;
+#endif
+
 static int check_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, const char* who)
 {
     if (!h || !io) return fail(BCP_E_INVALID, "%s: null argument", who);
+    if (flags & ~kCallerFlags) return fail(BCP_E_INVALID, "%s: undefined flag bits 0x%x", who, flags & ~kCallerFlags);
     if (!h->have_map || !h->have_path || !h->have_state)
         return fail(BCP_E_STATE, "%s: costmaps, paths and state must be set first", who);
     if ((flags & BCP_STEP_AUTO_RESET) && !h->have_init)
@@ -1255,9 +1409,17 @@ extern "C" int bcp_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, vo
     int rc = check_step(h, io, flags, "bcp_step");
     if (rc != BCP_OK) return rc;
     HIP_TRY(hipSetDevice(h->device));
-    launch_step(h, io, flags, (hipStream_t)stream);
+    rc = launch_step(h, io, flags, (hipStream_t)stream);
+    if (rc != BCP_OK) return rc;
     HIP_TRY(hipGetLastError());
     return BCP_OK;
+}
+
+extern "C" int bcp_step_form(bcp_handle* h)
+{
+    if (!h) return fail(BCP_E_INVALID, "bcp_step_form: null handle");
+    if (!h->have_map || !h->have_path || !h->have_state) return fail(BCP_E_STATE, "bcp_step_form: costmaps, paths and state must be set first");
+    return step_uses_deferral(h) ? (h->dense_threshold >= 0 ? 2 : 1) : 0;
 }
 
 extern "C" int bcp_time_steps(bcp_handle* h, const bcp_step_io* io, uint32_t flags, int32_t steps, void* stream,
@@ -1272,7 +1434,7 @@ extern "C" int bcp_time_steps(bcp_handle* h, const bcp_step_io* io, uint32_t fla
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, s));
-    for (int k = 0; k < steps; ++k) launch_step(h, io, flags, s);
+    for (int k = 0; k < steps && rc == BCP_OK; ++k) rc = launch_step(h, io, flags, s);
     HIP_TRY(hipEventRecord(e1, s));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
@@ -1280,6 +1442,7 @@ extern "C" int bcp_time_steps(bcp_handle* h, const bcp_step_io* io, uint32_t fla
     HIP_TRY(hipEventDestroy(e0));
     HIP_TRY(hipEventDestroy(e1));
     HIP_TRY(hipGetLastError());
+    if (rc != BCP_OK) return rc;
     *avg_ms = ms / (float)steps;
     return BCP_OK;
 }
@@ -1291,7 +1454,8 @@ static int time_loop(bcp_handle* h, const bcp_step_io* io, uint32_t flags, int s
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, s));
-    for (int k = 0; k < steps; ++k) launch_step(h, io, flags, s, first_only);
+    int rc = BCP_OK;
+    for (int k = 0; k < steps && rc == BCP_OK; ++k) rc = launch_step(h, io, flags, s, first_only);
     HIP_TRY(hipEventRecord(e1, s));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
@@ -1299,6 +1463,7 @@ static int time_loop(bcp_handle* h, const bcp_step_io* io, uint32_t flags, int s
     HIP_TRY(hipEventDestroy(e0));
     HIP_TRY(hipEventDestroy(e1));
     HIP_TRY(hipGetLastError());
+    if (rc != BCP_OK) return rc;
     *avg_ms = ms / (float)steps;
     return BCP_OK;
 }
@@ -1335,18 +1500,29 @@ extern "C" int bcp_robot_step(bcp_handle* h, double* state7_io, int64_t n, const
     return BCP_OK;
 }
 
-extern "C" int bcp_pose_collides(bcp_handle* h, const double* poses, int64_t n, uint8_t* out, void* stream)
+static int pose_collides_launch(bcp_handle* h, const double* poses, int64_t n, uint8_t* out, void* stream, int origin_in_map,
+                                const char* who)
 {
-    if (!h || !poses || !out || n <= 0) return fail(BCP_E_INVALID, "bcp_pose_collides: bad argument");
-    if (!h->have_map) return fail(BCP_E_STATE, "bcp_pose_collides: costmaps not set");
+    if (!h || !poses || !out || n <= 0) return fail(BCP_E_INVALID, "%s: bad argument", who);
+    if (!h->have_map) return fail(BCP_E_STATE, "%s: costmaps not set", who);
     HIP_TRY(hipSetDevice(h->device));
     const int blocks = (int)((n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(pose_collides_kernel, dim3(blocks), dim3(kBlock),
                        collision_lds_bytes(h->params.n_verts, h->map.in_lds, h->map.rows, h->map.wpr),
                        (hipStream_t)stream, h->dev, h->map, h->cull, h->exact_mode, h->dense_threshold, h->wide, poses, n,
-                       h->n, h->geom_of_env, out);
+                       h->n, h->geom_of_env, out, origin_in_map, h->map_valid_rows, h->map_valid_cols);
     HIP_TRY(hipGetLastError());
     return BCP_OK;
+}
+
+extern "C" int bcp_pose_collides(bcp_handle* h, const double* poses, int64_t n, uint8_t* out, void* stream)
+{
+    return pose_collides_launch(h, poses, n, out, stream, 0, "bcp_pose_collides");
+}
+
+extern "C" int bcp_is_robot_colliding(bcp_handle* h, const double* poses, int64_t n, uint8_t* out, void* stream)
+{
+    return pose_collides_launch(h, poses, n, out, stream, 1, "bcp_is_robot_colliding");
 }
 
 extern "C" int bcp_pixel_footprint(bcp_handle* h, const double* angles, int64_t n, double resolution, uint8_t* masks,
@@ -1394,6 +1570,78 @@ extern "C" int bcp_world_to_pixel(bcp_handle* h, const double* xy, int64_t n, co
     HIP_TRY(hipSetDevice(h->device));
     hipLaunchKernelGGL(world_to_pixel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xy, n,
                        origin[0], origin[1], 1.0 / resolution, out);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+
+// ---- reward-provider / path-tools operator seams ---------------------------------------------------------------
+static int ready_static(bcp_handle* h, hipStream_t s, const char* who)
+{
+    if (!h->have_path) return fail(BCP_E_STATE, "%s: paths must be set first", who);
+    if (h->static_dirty) return upload_step_static(h, s);
+    return BCP_OK;
+}
+
+extern "C" int bcp_reward(bcp_handle* h, const double* poses, int64_t n, double* min_spat_dist_so_far, int32_t* target_idx,
+                          const uint8_t* robot_collided, double* reward, uint8_t* goal_reached, void* stream)
+{
+    if (!h || !poses || !min_spat_dist_so_far || !target_idx || !reward || n <= 0)
+        return fail(BCP_E_INVALID, "bcp_reward: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = ready_static(h, s, "bcp_reward");
+    if (rc != BCP_OK) return rc;
+    hipLaunchKernelGGL(reward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dev_static, poses, n,
+                       min_spat_dist_so_far, target_idx, robot_collided, reward, goal_reached);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+extern "C" int bcp_find_last_reached(bcp_handle* h, const double* poses, int64_t n, int32_t* out, void* stream)
+{
+    if (!h || !poses || !out || n <= 0) return fail(BCP_E_INVALID, "bcp_find_last_reached: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = ready_static(h, s, "bcp_find_last_reached");
+    if (rc != BCP_OK) return rc;
+    hipLaunchKernelGGL(find_last_reached_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dev_static, poses, n,
+                       out);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+extern "C" int bcp_path_velocity(bcp_handle* h, const double* path_txyth, int64_t n_rows, double* v, double* w, int32_t* err,
+                                 void* stream)
+{
+    if (!h || !path_txyth || !v || !w || n_rows < 2) return fail(BCP_E_INVALID, "bcp_path_velocity: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(path_velocity_kernel, dim3((unsigned)((n_rows - 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       path_txyth, n_rows, v, w, err);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+extern "C" int bcp_is_footprint_colliding(bcp_handle* h, const uint8_t* image_slices, const uint8_t* blit_masks, int64_t n,
+                                          int32_t rows, int32_t cols, uint8_t lethal, uint8_t* out, void* stream)
+{
+    if (!h || !image_slices || !blit_masks || !out || n <= 0 || rows <= 0 || cols <= 0)
+        return fail(BCP_E_INVALID, "bcp_is_footprint_colliding: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(footprint_colliding_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       image_slices, blit_masks, n, (int64_t)rows * cols, (uint32_t)lethal, out);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+
+extern "C" int bcp_device_normals(bcp_handle* h, int64_t first_env, int64_t n_envs, uint64_t first_step, int32_t n_steps,
+                                  double* out, void* stream)
+{
+    if (!h || !out || n_envs <= 0 || n_steps <= 0 || first_env < 0) return fail(BCP_E_INVALID, "bcp_device_normals: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(device_normals_kernel, dim3(stride_grid(n_envs * n_steps, 256)), dim3(256), 0, (hipStream_t)stream,
+                       h->seed, h->env_id_base + first_env, n_envs, first_step, n_steps, out);
     HIP_TRY(hipGetLastError());
     return BCP_OK;
 }

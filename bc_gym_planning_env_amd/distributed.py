@@ -20,23 +20,44 @@ def env_block(n_total, rank, world_size):
     return first, count
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* when launched by torch.distributed.run.
-    Returns (rank, world_size, local_rank)."""
+def init_from_env(backend=None, timeout_s=180):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run, or bench.py's own
+    launcher).  Returns (rank, world_size, local_rank).
+
+    The transport is an explicit choice: `backend`, else BCP_DIST_BACKEND, else "nccl" (RCCL over xGMI) -- there is no
+    fallback.  RCCL needs one GPU per rank; with fewer GPUs than ranks the call fails at once and names the rehearsal
+    transport (BCP_DIST_BACKEND=gloo: the done masks then travel through the host).  A process group is initialised
+    ONCE per process: a second init_process_group on the same TCPStore after a failed one finds the first attempt's
+    rendezvous keys and the ranks wait on each other until the store times out (the hang of round 1's 2-rank rehearsal).
+    """
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        import datetime
         if backend is None:
-            backend = os.environ.get("BCP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = os.environ.get("BCP_DIST_BACKEND") or "nccl"
+        if backend not in ("nccl", "gloo"):
+            raise RuntimeError("BCP_DIST_BACKEND must be 'nccl' (RCCL) or 'gloo' (rehearsal), got %r" % (backend,))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kwargs = {}
         if backend == "nccl":
-            dev = local_rank % max(1, torch.cuda.device_count())   # (rehearsals may put several ranks on one GPU)
-            torch.cuda.set_device(dev)
-            kwargs["device_id"] = torch.device("cuda", dev)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+            gpus = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            if gpus < local_world:
+                raise RuntimeError(
+                    "RCCL needs one GPU per rank: %d ranks on this node, %d GPU(s) visible.  To rehearse the sharded "
+                    "path on fewer GPUs choose the host transport explicitly: BCP_DIST_BACKEND=gloo" % (local_world, gpus))
+            torch.cuda.set_device(local_rank)
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
     return rank, world, local_rank
+
+
+def local_device(local_rank):
+    """GPU of this rank: its own with RCCL; rank % GPUs in a gloo rehearsal (several ranks may share one GPU)."""
+    return local_rank % max(1, torch.cuda.device_count())
 
 
 class DoneGather(object):

@@ -7,6 +7,8 @@ try/except ImportError), batched over many inputs.
   world_to_pixel        utilities/coordinate_transformations.py:169-205 (world_to_pixel_impl)
   extract_egocentric_costmap   utilities/costmap_utils.py:25-75 (cv2.getRotationMatrix2D + cv2.warpAffine, nearest)
   robot_step            IRobot.step: tricycle_model.py:478-538 / differential_drive.py:236-265
+  is_robot_colliding    utilities/costmap_utils.py:106-164; is_footprint_colliding (is_footprint_colliding_impl, :106-136)
+  reward / find_last_reached / path_velocity   envs/base/reward.py:184-259, utilities/path_tools.py:432-448, :298-323
 """
 import ctypes as C
 
@@ -91,6 +93,82 @@ class NativeOps(object):
         out = torch.empty(p.shape[0], dtype=torch.uint8, device=self.device)
         _lib.check(self._lib.bcp_pose_collides(self._h, p.data_ptr(), p.shape[0], out.data_ptr(), self._stream()))
         return out
+
+    def is_robot_colliding(self, poses):
+        """is_robot_colliding (costmap_utils.py:106-164) for poses [n,3]: pose_collides, but never when the robot's own
+        pixel is off the map -> uint8 [n]."""
+        p = self._dev(poses, torch.float64)
+        out = torch.empty(p.shape[0], dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.bcp_is_robot_colliding(self._h, p.data_ptr(), p.shape[0], out.data_ptr(), self._stream()))
+        return out
+
+    def is_footprint_colliding(self, image_slices, blit_masks, lethal=254):
+        """is_footprint_colliding_impl(image_slice, blit_mask, lethal) for n pairs [n, rows, cols] -> uint8 [n]."""
+        sl = self._dev(image_slices, torch.uint8)
+        mk = self._dev(blit_masks, torch.uint8)
+        if sl.dim() == 2:
+            sl, mk = sl[None], mk[None]
+        assert sl.shape == mk.shape and sl.dim() == 3
+        out = torch.empty(sl.shape[0], dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.bcp_is_footprint_colliding(self._h, sl.data_ptr(), mk.data_ptr(), sl.shape[0], sl.shape[1],
+                                                        sl.shape[2], int(lethal), out.data_ptr(), self._stream()))
+        return out
+
+    def set_path(self, path):
+        """The (already refined) path [m,3] the reward operators below score against."""
+        p = self._dev(path, torch.float64)
+        assert p.dim() == 2 and p.shape[1] == 3
+        self._keep["path"] = p
+        _lib.check(self._lib.bcp_set_paths(self._h, p.data_ptr(), None, p.shape[0], 1, self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def reward(self, poses, min_spat_dist_so_far, target_idx, robot_collided=None):
+        """reward_provider.reward(state) / .done(state) (reward.py:184-259) for n (pose, provider state) pairs ->
+        (reward float64 [n], new min_spat_dist_so_far [n], new target_idx int32 [n], goal_reached uint8 [n])."""
+        p = self._dev(poses, torch.float64)
+        n = p.shape[0]
+        md = self._dev(min_spat_dist_so_far, torch.float64).clone()
+        ti = self._dev(target_idx, torch.int32).clone()
+        col = self._dev(robot_collided, torch.uint8) if robot_collided is not None else None
+        rew = torch.empty(n, dtype=torch.float64, device=self.device)
+        goal = torch.empty(n, dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.bcp_reward(self._h, p.data_ptr(), n, md.data_ptr(), ti.data_ptr(),
+                                        col.data_ptr() if col is not None else None, rew.data_ptr(), goal.data_ptr(),
+                                        self._stream()))
+        return rew, md, ti, goal
+
+    def find_last_reached(self, poses):
+        """find_last_reached (path_tools.py:432-448) for poses [n,3] against the path of set_path -> int32 [n], -1 = None."""
+        p = self._dev(poses, torch.float64)
+        out = torch.empty(p.shape[0], dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.bcp_find_last_reached(self._h, p.data_ptr(), p.shape[0], out.data_ptr(), self._stream()))
+        return out
+
+    def path_velocity(self, path_txyth):
+        """path_velocity (path_tools.py:298-323): rows of (t, x, y, angle) -> (v, w) of the n - 1 segments; raises like
+        the reference on corrupted angle data / non-increasing time stamps."""
+        p = self._dev(path_txyth, torch.float64)
+        n = p.shape[0]
+        v = torch.empty(n - 1, dtype=torch.float64, device=self.device)
+        w = torch.empty(n - 1, dtype=torch.float64, device=self.device)
+        err = torch.zeros(n - 1, dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.bcp_path_velocity(self._h, p.data_ptr(), n, v.data_ptr(), w.data_ptr(), err.data_ptr(),
+                                               self._stream()))
+        e = err.cpu().numpy()
+        assert not (e & _lib.ERR_TIME_ORDER).any()
+        if (e & _lib.ERR_ANGLE_JUMP).any():
+            raise Exception("Path has missing/corrupted angle data at indices: %s." % ((e & _lib.ERR_ANGLE_JUMP).nonzero(),))
+        return v, w
+
+    def device_normals(self, n_envs, first_step=0, n_steps=1, first_env=0):
+        """The standard normals the step kernels would draw (bcp_device_normals) -> float64 [n_steps, n_envs, 3]."""
+        out = torch.empty((int(n_steps), int(n_envs), 3), dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.bcp_device_normals(self._h, int(first_env), int(n_envs), int(first_step), int(n_steps),
+                                                out.data_ptr(), self._stream()))
+        return out
+
+    def seed(self, seed):
+        _lib.check(self._lib.bcp_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
 
     def extract_egocentric_costmap(self, poses, resulting_origin=None, resulting_size=None, border_value=0):
         """The costmap given to set_costmap seen from each of poses [n,3] -> uint8 [n, rows, cols] (robot at (0, 0)

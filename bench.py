@@ -1,17 +1,27 @@
 #!/usr/bin/env python
-"""bench.py -- env-steps/s of the fused PlanEnv.step() kernel on RandomMiniEnv at 65 536 envs per GPU.
+"""bench.py -- env-steps/s of the fused PlanEnv.step() path on RandomMiniEnv at 65 536 envs per GPU.
 
-python bench.py --gpus N --steps K --warmup W     (N > 1: launched through torch.distributed.run, one rank per GPU)
+python bench.py --gpus N --steps K --warmup W
+
+N > 1: either started once per rank by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or -- with WORLD_SIZE unset -- bench.py starts its N
+ranks itself as fresh child processes BEFORE anything in the parent touches the GPU; the parent only relays rank 0's
+JSON line and the exit codes.  One rank per GPU over RCCL; BCP_DIST_BACKEND=gloo is the explicit rehearsal transport
+for boxes with fewer GPUs than ranks (never chosen silently: a failed RCCL set-up is an error).
 
 Workload (BASELINE.json configs[2], "C3"): 65 536 replicas per GPU of the RandomMiniEnv seed-0 geometry (shared
 183x183 uint8 costmap, shared refined path), tricycle dynamic model with PlanEnv's odometry noise drawn on the
 device (Philox4x32-10), float32 actions ~ U(action_space) pre-staged in HBM, reset-on-done inside the kernel.
-A "step" is one fused kernel launch over all envs of the rank.  With N > 1 ranks the env index space is sharded in
-contiguous blocks (weak scaling) and each step ends with ONE RCCL all-gather of the uint8 done mask.
+A "step" is one pass of the hot path over all envs of the rank.  With N > 1 ranks the env index space is sharded in
+contiguous blocks (weak scaling); the done masks go into a device-side ring that is all-gathered every 8 steps.
 """
 import argparse
+import glob
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,13 +31,65 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 65536
-# ALGORITHMIC bytes per env-step (DESIGN.md "Bytes"): SoA state in + out (7 f64 robot + min_dist f64 + target_idx
-# i32 + current_iter i32 + robot_collided u8 = 73 B each way) + action 2 x f32 + reward f64 + done u8.
+# ALGORITHMIC bytes per env-step (DESIGN.md "Bytes"): SoA state in + out (7 f64 robot + min_dist f64 +
+# target_idx i32 + current_iter i32 + robot_collided u8 = 73 B each way) + action 2 x f32 + reward f64 + done u8.
 # The shared costmap / path are LDS- and cache-resident and contribute no compulsory HBM traffic.
 BYTES_PER_ENV_STEP = 73 + 73 + 8 + 8 + 1
+BYTES_PER_ENV_STEP_C2 = 57 + 57 + 8 + 9            # diff-drive: 5 f64 robot state
+BYTES_PER_ENV_STEP_C4 = BYTES_PER_ENV_STEP + 900 + 3120   # + footprint cells of a private map + private 130-point path
 HBM_PEAK_GBS = 8000.0
+METRIC = "env-steps/sec at N=65536 RandomMiniEnv, 1/2/4/8 MI355X; % HBM roofline"
 
 
+# ------------------------------------------------------------------------------------------------ launcher (no GPU)
+def spawn_ranks(args):
+    """Start one fresh process per rank and relay rank 0's output.  Nothing here imports torch or touches the GPU."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, cwd=os.getcwd()))
+    deadline = time.time() + float(os.environ.get("BCP_BENCH_TIMEOUT", "1500"))
+    rc = 0
+    out0 = b""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+            if rc != 0 or time.time() > deadline:
+                if rc == 0:
+                    rc = 124
+                    sys.stderr.write("bench.py: ranks still running at the time limit; stopping them\n")
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:   # exactly the processes started above
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        out0 = procs[0].stdout.read() if procs[0].stdout else b""
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ workloads
 def make_env(n, device, env_id_base, seed):
     from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
     g = np.load(os.path.join(ROOT, "tests", "golden", "g8_traj_mini_00.npz"))
@@ -38,12 +100,24 @@ def make_env(n, device, env_id_base, seed):
     return env, g
 
 
-def cpu_baseline(g, envs=16384, budget_s=12.0):
-    """The oracle (C restatement, kind "port") on the host cores of this box: same workload, bounded sample
-    (about `budget_s` seconds of wall time on at most 16 threads, the CPU share of a one-GPU box)."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(g, envs=ENVS_PER_GPU, budget_s=14.0):
+    """The oracle (C restatement, kind "port") on the host cores of this box, SURVEY 8(d): the C3 workload at the
+    metric's N = 65 536 on all the cores this process may use, and the C1 case (one env, one core).  Bounded samples
+    (about `budget_s` + 3 + 3 seconds of CPU wall time)."""
     import oracle
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(16, avail))
+    threads = max(1, min(64, avail))
     p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE, spatial_precision=0.2, angular_precision=np.pi / 8)
     ref = oracle.OracleBatch(p, envs, g["costmap"], g["origin"], float(g["resolution"]), g["path"])
     ref.reset_from_paths()
@@ -57,23 +131,130 @@ def cpu_baseline(g, envs=16384, budget_s=12.0):
     steps = 0
     t0 = time.perf_counter()
     while True:
-        for k in range(10):
+        for k in range(5):
             ref.step(acts[(steps + k) % 4], zs[(steps + k) % 4], auto_reset=True, threads=threads)
-        steps += 10
+        steps += 5
         dt = time.perf_counter() - t0
         if dt >= budget_s or steps >= 2000:
             break
-    # the same on ONE core, for a per-core figure (about 3 s)
+    # the same batch on ONE core, for a per-core figure (about 3 s)
     one = 0
     t1 = time.perf_counter()
     while time.perf_counter() - t1 < 3.0:
         ref.step(acts[one % 4], zs[one % 4], auto_reset=True, threads=1)
         one += 1
     dt1 = time.perf_counter() - t1
+    # C1 (BASELINE.json configs[0]): ONE RandomMiniEnv, random actions, reset on done -- the reference's own shape
+    ref1 = oracle.OracleBatch(p, 1, g["costmap"], g["origin"], float(g["resolution"]), g["path"])
+    ref1.reset_from_paths()
+    a1 = rng.uniform(lo, hi, (4096, 1, 2)).astype(np.float32).astype(np.float64)
+    z1 = rng.standard_normal((4096, 1, 3))
+    c1 = 0
+    t2 = time.perf_counter()
+    while time.perf_counter() - t2 < 3.0:
+        for k in range(256):
+            ref1.step(a1[(c1 + k) % 4096], z1[(c1 + k) % 4096], auto_reset=True, threads=1)
+        c1 += 256
+    dt2 = time.perf_counter() - t2
     return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": "%d envs x %d steps of the same workload (C oracle restatement, %d threads, %.1f s)"
+            "cpu_model": cpu_model(), "cores_available": avail,
+            "sample": "C3 at N = %d: %d steps of the same workload (C oracle restatement, %d threads, %.1f s)"
                       % (envs, steps, threads, dt),
-            "single_core_value": envs * one / dt1}
+            "single_core_value": envs * one / dt1,
+            "c1_single_env": {"value": c1 / dt2, "unit": "env-steps/s", "cores": 1,
+                              "sample": "C1: one RandomMiniEnv, %d steps through the oracle's batch entry point with "
+                                        "n = 1 (%.1f s; includes the ctypes call per step)" % (c1, dt2)},
+            "reference_python": "genuine reference, 1 core of the build container: about 2.3e3 env-steps/s (BASELINE.md; "
+                                "it cannot travel to the GPU box)"}
+
+
+def newest_profile(pattern):
+    """Newest committed profiles/rNN_<pattern> (by round number): (path, parsed json) or (None, None)."""
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_" + pattern)):
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    if best is None:
+        return None, None
+    try:
+        with open(best[1]) as f:
+            return os.path.relpath(best[1], ROOT), json.load(f)
+    except (OSError, ValueError):
+        return None, None
+
+
+def steady_state(env, pool, rng):
+    """Pre-roll to the steady state of the rollout: random episode phases, then one full timeout's worth of steps."""
+    import torch
+    n = env.n_envs
+    env.state.current_iter.copy_(torch.from_numpy(rng.randint(0, env.params.iteration_timeout, n).astype(np.int32)).to(env.device))
+    for k in range(env.params.iteration_timeout):
+        env.step(pool[k % pool.shape[0]])
+    torch.cuda.synchronize()
+
+
+def aux_other_configs(device):
+    """BASELINE.json configs[1] (C2) and configs[3] (C4), informational lines with their own roofline objects."""
+    import torch
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    G = os.path.join(ROOT, "tests", "golden")
+    out = {}
+    rng = np.random.RandomState(0)
+    # ---- C2: 4096 diff-drive envs, shared 64x64 costmap, noise off
+    g = np.load(os.path.join(G, "g8dd_traj_mini64_00.npz"))
+    res = float(g["resolution"])
+    params = EnvParams(goal_spat_dist=0.2, goal_ang_dist=np.pi / 8, resolution=res, refine_path=False,
+                       robot_name="industrial_diffdrive_v1")
+    n = 4096
+    env = BatchedPlanEnv(CostMap2D(g["costmap"], res, g["origin"]), g["path"], params, n_envs=n, noise_parameters=None,
+                         auto_reset=True, device=device)
+    pool = torch.from_numpy(np.stack([rng.uniform([0.105, -np.pi / 2], [0.524, np.pi / 2], (n, 2)).astype(np.float32)
+                                      for _ in range(8)])).to(env.device)
+    steady_state(env, pool, rng)
+    ms = env.time_steps(pool[0], 200)
+    out["c2_diffdrive_4096_shared_64x64"] = {
+        "what": "BASELINE configs[1]: RandomMiniEnv geometry at 5.5 m / 64 px, 4096 envs, diff-drive model, noise off",
+        "ms_per_step": ms, "env_steps_per_s": n / (ms * 1e-3),
+        "roofline": {"bound": "hbm", "achieved": BYTES_PER_ENV_STEP_C2 * n / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": BYTES_PER_ENV_STEP_C2 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP_C2 * n,
+                     "note": "64 wavefronts of envs: launch-latency bound, the chip is idle"}}
+    env.close()
+    del env, pool
+    # ---- C4: 65 536 AisleTurn envs, PRIVATE costmaps stored [N, 256, 256] (valid 256 x 141) and private 130-point paths
+    names = ["g8_traj_aisle_c4_00.npz", "g8_traj_aisle_c4_10.npz", "g8_traj_aisle_c4_01.npz", "g8_traj_aisle_c4_11.npz"]
+    gs = [np.load(os.path.join(G, nm)) for nm in names]
+    res = float(gs[0]["resolution"])
+    n = ENVS_PER_GPU
+    idx = np.arange(n) % 4
+    params = EnvParams(resolution=res, refine_path=False)
+    cms = [CostMap2D(x["costmap"], res, x["origin"]) for x in gs]
+    t0 = time.perf_counter()
+    env = BatchedPlanEnv(cms, [x["path"] for x in gs], params, n_envs=n, auto_reset=True, template_of_env=idx,
+                         map_storage=(256, 256), device=device, seed=11)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    pool = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(8)])).to(env.device)
+    steady_state(env, pool, rng)
+    ms = env.time_steps(pool[0], 100)
+    path, pmc = newest_profile("c4_pmc_summary.json")
+    traffic = pmc["corrected_bytes_per_step"]["total"] if pmc else None
+    ach = BYTES_PER_ENV_STEP_C4 * n / (ms * 1e-3) / 1e9
+    out["c4_aisle_private_maps"] = {
+        "what": "BASELINE configs[3]: AisleTurnEnv at 10 m / 256 px, 65536 envs, private costmaps stored uint8 "
+                "[N, 256, 256] (valid 256 x 141, 4 templates x flips) + private 130-point paths, tricycle + noise",
+        "map_storage": list(env._keep["map"].shape), "setup_s": t_setup,
+        "ms_per_step": ms, "env_steps_per_s": n / (ms * 1e-3),
+        "collisions_per_step": float(env.collided_now.float().mean()), "done_per_step": float(env.done.float().mean()),
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": path,
+                     "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP_C4 * n,
+                     "note": "algorithmic bytes per SURVEY 8(d): 163 state I/O + 900 footprint cells of the private uint8 "
+                             "map + 3120 of the private path; the kernels read a 1-bit lethal mask, a uint8 distance "
+                             "field and a bucketed path window instead, so the counter traffic is the honest figure"}}
+    env.close()
+    return out
 
 
 def aux_measurements(env, pool, n):
@@ -110,12 +291,11 @@ def aux_measurements(env, pool, n):
         "step_plus_observation_ms": ms_both, "env_steps_per_s_with_observation": n / (ms_both * 1e-3)}
     del wrap
     # a fresh world per episode: RandomMiniEnv.reset() as a device-side walk through a pool of pre-sampled geometries
-    import time as _time
     from bc_gym_planning_env_amd import mini_env
     torch.cuda.synchronize()
-    t0 = _time.perf_counter()
+    t0 = time.perf_counter()
     worlds = mini_env.sample_pool_device(None, list(range(4096)), 4, device=env.device.index or 0)
-    t_pool = _time.perf_counter() - t0
+    t_pool = time.perf_counter() - t0
     penv = mini_env.BatchedRandomMiniEnv(n, pool=worlds, auto_reset=True, seed=3, device=env.device.index or 0)
     rng = np.random.RandomState(7)
     penv.state.current_iter.copy_(torch.from_numpy(rng.randint(0, penv.params.iteration_timeout, n).astype(np.int32)).to(env.device))
@@ -164,47 +344,40 @@ def aux_measurements(env, pool, n):
         "ms_per_step": ms_endless, "env_steps_per_s": n / (ms_endless * 1e-3),
         "worlds_resampled_per_refresh": float(tally[0]) / max(len(infos), 1),
         "envs_seen_waiting_for_worlds": int(tally[1])}
+    del eenv
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-aux", action="store_true", help="skip the informational egocentric-observation timing")
-    args = ap.parse_args()
-
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
     import torch
     import torch.distributed as dist
     from bc_gym_planning_env_amd import distributed as bdist
 
-    rank, world, local_rank = bdist.init_from_env()
+    try:
+        rank, world, local_rank = bdist.init_from_env()
+    except Exception as exc:   # a failed RCCL / rendezvous set-up is an error, never a silent change of transport
+        sys.stderr.write("bench.py: torch.distributed set-up failed: %s\n" % (exc,))
+        raise SystemExit(3)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    device = local_rank % max(1, torch.cuda.device_count())  # (rehearsals may put several ranks on one GPU)
+    device = bdist.local_device(local_rank)
     torch.cuda.set_device(device)
     n = args.envs_per_gpu
     env, g = make_env(n, device, env_id_base=rank * n, seed=2024)
+    backend = dist.get_backend() if world > 1 else None
     # Multi-GPU: the only cross-rank traffic is the done mask.  Every rank writes its mask of step k into row k % 8 of a
     # ring (the step kernel stores it there directly) and the ring is all-gathered every 8 steps, asynchronously
     # (the gather of one block of 8 steps overlaps the kernels of the next): 1/8 collective per step.
     gather_every = 8
     ring = torch.zeros(gather_every, n, dtype=torch.uint8, device=torch.device("cuda", device)) if world > 1 else None
     gather = bdist.DoneGather(gather_every * n, torch.device("cuda", device)) if world > 1 else None
-    collective = None
     if world > 1:
         # the first collectives run here, untimed (communicator set-up)
         gather.launch(ring.view(-1))
         gather.flush()
         dist.barrier()
         torch.cuda.synchronize()
-        collective = dist.get_backend()
 
     # pre-staged synthetic actions: a pool of 16 batches ~ U(action_space), float32, resident in HBM
     rng = np.random.RandomState(1234 + rank)
@@ -227,10 +400,7 @@ def main():
     # Pre-roll to the steady state of the rollout (untimed set-up): every env gets a random episode phase, then one
     # full timeout's worth of steps runs, so that at any timed step the batch holds envs at all stages of an
     # episode (fresh, en route, off the map, about to time out) instead of 65 536 envs marching in lock-step.
-    phase = torch.from_numpy(rng.randint(0, env.params.iteration_timeout, n).astype(np.int32)).to(env.device)
-    env.state.current_iter.copy_(phase)
-    for k in range(env.params.iteration_timeout):
-        env.step(pool[k % 16])
+    steady_state(env, pool, rng)
     if gather is not None:   # first collectives outside the timed region whatever --warmup says (communicator set-up)
         for _ in range(2):
             gather.launch(ring.view(-1))
@@ -250,27 +420,27 @@ def main():
     elapsed = time.perf_counter() - t0
     stream_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=env.device if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=env.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     env.check_errors()
 
-    # One step = two launches on one stream: step_fast_pair_kernel (all envs: robot model, O(1) collision classification,
-    # reward, done) and step_pending_kernel (the ~1.5 % of envs whose collision needs the exact rasteriser).  Their
-    # combined average duration is measured live with HIP events recorded on the launch stream around the timed
-    # region (at N=1 the region holds nothing but these launches, back to back); the per-kernel split of the same
-    # command is in profiles/ (rocprofv3 --kernel-trace --stats).
+    # The step's launches run back to back on one stream; their combined average duration is measured live with HIP
+    # events recorded on the launch stream around the timed region (at N=1 the region holds nothing but these
+    # launches).  The per-kernel split of the same command is in profiles/ (rocprofv3 --kernel-trace --stats).
     step_ms = stream_ms / args.steps if world == 1 else env.time_steps(pool[0], max(20, min(args.steps, 200)))
     achieved = BYTES_PER_ENV_STEP * n / (step_ms * 1e-3) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(pmc) and n == ENVS_PER_GPU:  # PMC passes cannot run inside bench.py; committed per round
-        traffic = json.load(open(pmc))["corrected_bytes_per_step"]["total"]
+    traffic = traffic_src = None
+    if n == ENVS_PER_GPU:   # PMC passes cannot run inside bench.py; the newest committed summary is quoted and named
+        traffic_src, pmc = newest_profile("pmc_summary.json")
+        if pmc:
+            traffic = pmc["corrected_bytes_per_step"]["total"]
 
     if rank == 0:
         total_envs = n * world
+        kernels = env.step_kernels()
         out = {
-            "metric": "env-steps/sec at N=65536 RandomMiniEnv, 1/2/4/8 MI355X; % HBM roofline",
+            "metric": METRIC,
             "value": total_envs * args.steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -286,29 +456,48 @@ def main():
                                    "odometry noise (on-device Philox), shared 183x183 costmap, reset on done, steady-state episode phases" % n,
                        "envs_total": total_envs, "envs_per_gpu": n, "actions": "float32 U(action_space), pre-staged",
                        "sharding": ("env blocks per rank, done masks ring-buffered on the device and all-gathered (%s) every "
-                                    "8 steps, overlapped with the next steps" % ("RCCL" if collective == "nccl" else collective))
+                                    "8 steps, overlapped with the next steps"
+                                    % ("RCCL" if backend == "nccl" else "gloo through the host: REHEARSAL transport, not a scaling number"))
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "step_fast_pair_kernel + step_pending_kernel (one step = these two launches)",
-                         "kernel_ms": step_ms,
+                         "kernel": kernels, "kernel_ms": step_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n,
-                         "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
-                         "note": "shared-map config is latency-bound (SURVEY 8d; SQ counters in profiles/r01_step_alu_pmc.json: "
-                                 "waves wait 73 % of their cycles at 2 waves per SIMD): the HBM fraction is low by "
-                                 "construction; see DESIGN.md"},
+                         "traffic_source": traffic_src,
+                         "note": "shared-map config is latency-bound (SURVEY 8d): the HBM fraction is low by "
+                                 "construction; see DESIGN.md.  The HBM-bound config is aux.c4_aisle_private_maps"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g)
         if world == 1 and not args.no_aux:
             try:  # informational only: never let it cost the metric line
-                out["aux"] = aux_measurements(env, pool, n)
+                aux = aux_measurements(env, pool, n)
+                env.close()
+                del env
+                torch.cuda.empty_cache()
+                aux.update(aux_other_configs(device))
+                out["aux"] = aux
             except Exception as exc:  # noqa: BLE001
                 out["aux"] = {"error": repr(exc)}
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the informational legs (observation, pools, C2 / C4)")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -55,7 +55,8 @@ enum {
 
 /* per-env error bits written to bcp_step_io.err (mirror of the reference's Python exceptions) */
 enum {
-    BCP_ERR_ANGLE_JUMP = 1 /* path_velocity raises when |dtheta| >= pi, utilities/path_tools.py:319-322 */
+    BCP_ERR_ANGLE_JUMP = 1, /* path_velocity raises when |dtheta| >= pi, utilities/path_tools.py:319-322 */
+    BCP_ERR_TIME_ORDER = 2  /* path_velocity's `assert (dt > 0).all()`, utilities/path_tools.py:307 (bcp_path_velocity only) */
 };
 
 /* bcp_step flags */
@@ -222,6 +223,29 @@ int bcp_robot_step(bcp_handle *h, double *state7_io, int64_t n, const double *ac
 /* pose_collides(x, y, angle, robot, costmap) (env.py:464-489; twin costmap_utils.py:178-203) for n poses
  * [n,3]; pose i is tested against env (i % n_envs)'s current costmap.  out: uint8 [n]. */
 int bcp_pose_collides(bcp_handle *h, const double *poses, int64_t n, uint8_t *out, void *stream);
+/* is_robot_colliding(robot_pose, footprint, costmap_data, origin, resolution) (utilities/costmap_utils.py:106-164):
+ * pose_collides, except that a robot whose own pixel lies outside the map never collides (in_costmap_bounds, :127-130).
+ * Same arguments as bcp_pose_collides. */
+int bcp_is_robot_colliding(bcp_handle *h, const double *poses, int64_t n, uint8_t *out, void *stream);
+/* is_footprint_colliding_impl(image_slice, blit_mask, lethal) (the native hook of utilities/costmap_utils.py:106-136;
+ * Python fallback :163-164: np.any(values == LETHAL)) for n (slice, mask) pairs of one shape: image_slices, blit_masks
+ * uint8 [n, rows, cols] (mask: non-zero = footprint cell); out uint8 [n] = any(slice[mask] == lethal). */
+int bcp_is_footprint_colliding(bcp_handle *h, const uint8_t *image_slices, const uint8_t *blit_masks, int64_t n,
+                               int32_t rows, int32_t cols, uint8_t lethal, uint8_t *out, void *stream);
+/* The reward-provider seam (envs/base/reward.py:184-259): reward_provider.reward(state) and .done(state) for n
+ * (pose, provider state) pairs against the paths given to bcp_set_paths (pose i: the path of env i % n_envs), with this
+ * handle's provider (RewardParams / BCP_REWARD_*).  poses double [n,3]; min_spat_dist_so_far double [n] and target_idx
+ * int32 [n] are the provider state, updated in place; robot_collided uint8 [n] or NULL (only the pure-pursuit provider
+ * reads it); reward double [n]; goal_reached uint8 [n] or NULL = provider.done(). */
+int bcp_reward(bcp_handle *h, const double *poses, int64_t n, double *min_spat_dist_so_far, int32_t *target_idx,
+               const uint8_t *robot_collided, double *reward, uint8_t *goal_reached, void *stream);
+/* find_last_reached(pose, segment, spatial_precision, angular_precision) (utilities/path_tools.py:432-448) for n poses
+ * against the bound paths: out int32 [n] = index of the last way point reached, -1 for None. */
+int bcp_find_last_reached(bcp_handle *h, const double *poses, int64_t n, int32_t *out, void *stream);
+/* path_velocity(path) (utilities/path_tools.py:298-323): path_txyth double [n_rows,4] rows of (t, x, y, angle) ->
+ * v, w double [n_rows - 1]; err int32 [n_rows - 1] or NULL: BCP_ERR_* bits where the reference raises / asserts. */
+int bcp_path_velocity(bcp_handle *h, const double *path_txyth, int64_t n_rows, double *v, double *w, int32_t *err,
+                      void *stream);
 /* get_pixel_footprint_impl(angle, footprint, resolution, fill=True) (path_tools.py:101-162) for n angles.
  * masks: uint8 [n, side, side] (side >= 2*half+1 for every angle), zero-filled then 255 inside; the kernel
  * image of angle i occupies the top-left shape_hw[i] = {2*half_y+1, 2*half_x+1} corner. */
@@ -315,7 +339,20 @@ int bcp_refresh_mini_worlds(bcp_handle *h, const bcp_mini_world_params *p /*host
                             int32_t *path_status, void *stream);
 int bcp_release_mini_worlds(bcp_handle *h, void *stream);
 
+/* ---- the on-device noise stream (introspection) --------------------------------------------------------------- */
+/* The standard normals a step draws when bcp_step_io.noise_z is NULL (the stand-in for np.random.normal of
+ * robot_models/differential_drive.py:43-52): out double [n_steps][n_envs][3] = the three slots of envs first_env ..
+ * first_env + n_envs - 1 of this handle at step counters first_step .. first_step + n_steps - 1, for the handle's seed
+ * and env_id_base.  (A step consumes slot k only when variance_k > 0, like the reference.)  Any n_envs, not only the
+ * handle's. */
+int bcp_device_normals(bcp_handle *h, int64_t first_env, int64_t n_envs, uint64_t first_step, int32_t n_steps, double *out,
+                       void *stream);
+
 /* ---- measurement -------------------------------------------------------------------------------------- */
+/* Which kernels a bcp_step() of this handle launches, as configured now: 0 = step_kernel alone (no distance field, or a
+ * forced mode), 1 = step_fast_pair_kernel alone (every undecided pose settled in place), 2 = step_fast_pair_kernel +
+ * step_pending_kernel.  Negative: BCP_E_*. */
+int bcp_step_form(bcp_handle *h);
 /* Runs `steps` bcp_step() launches back to back on `stream` bracketed by HIP events recorded on that stream and
  * returns the average kernel-launch duration in milliseconds (synchronises).  Used by bench.py for
  * roofline.achieved. */

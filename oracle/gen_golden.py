@@ -12,6 +12,8 @@ Fixture list:
   g6_pose_collides.npz      pose_collides verdicts on random poses (fill = oracle restatement, see harness note)
   g7_reward.npz             ContinuousRewardProvider traces
   g8_traj_*.npz             full PlanEnv.step trajectories (RandomMiniEnv seeds, AisleTurnEnv variants)
+  g9 .. g12                 RandomMiniEnv worlds, egocentric observations, delays / pure pursuit, coloured ego costmap
+  g13_serialized_*.npz      PlanEnv.serialize() records taken mid-episode + the next 100 steps of the live env
 """
 import os
 import sys
@@ -559,6 +561,49 @@ def gen_delays_and_pure_pursuit():
             tag, rec["reward"].min(), rec["reward"].max(), rec["collided"].sum(), np.argmax(rec["done"])))
 
 
+def gen_serialized_records():
+    """G13: genuine PlanEnv.serialize() records (env.py:251-261, State.serialize :163-176) taken mid-episode -- with delay
+    queues filled and with both reward providers -- followed by the next 100 steps of the SAME live env.  The record is
+    what a batch is rebuilt from (BatchedPlanEnv.deserialize); the continuation is what it must then reproduce."""
+    import copy
+    from oracle import records
+    from bc_gym_planning_env.envs.mini_env import RandomMiniEnv, RandomMiniEnvParams
+    from bc_gym_planning_env.envs.synth_turn_env import AisleTurnEnv, AisleTurnEnvParams
+    from bc_gym_planning_env.envs.base.params import EnvParams
+    from bc_gym_planning_env.envs.base import spaces
+
+    def mini(seed, **kw):
+        params = RandomMiniEnvParams(env_params=EnvParams(goal_ang_dist=np.pi / 8., goal_spat_dist=0.2, **kw))
+        env = RandomMiniEnv(params=params, rng=np.random.RandomState(seed), draw_new_turn_on_reset=False)
+        return env, env._env
+
+    def aisle(**kw):
+        env = AisleTurnEnv(AisleTurnEnvParams(env_params=EnvParams(reward_provider_name='continuous_reward_pure_pursuit', **kw)))
+        return env, env
+
+    cases = [("plain", lambda: mini(3), 37, 1.0),
+             ("delay_p1s1", lambda: mini(2, pose_delay=1, state_delay=1), 23, 1.0),
+             ("delay_c2p3s1", lambda: mini(4, control_delay=2, pose_delay=3, state_delay=1), 41, 1.0),
+             ("delay_c2p3", lambda: mini(5, control_delay=2, pose_delay=3), 29, 1.0),   # no state delay: State holds the robot's true state
+             ("delay_filling", lambda: mini(6, control_delay=3, pose_delay=2, state_delay=3), 2, 1.0),   # queues not full yet
+             ("delay_fresh", lambda: mini(7, control_delay=1, pose_delay=1, state_delay=1), 0, 1.0),    # empty queues
+             ("pp", lambda: aisle(), 60, 2.0),
+             ("pp_delay", lambda: aisle(pose_delay=1, control_delay=1), 35, 2.0)]
+    for tag, make, before, speed in cases:
+        env, plan_env = make()
+        spaces.SPACE_LOCAL_RANDOM_STATE.seed(900)
+        np.random.seed(901)
+        for _ in range(before):
+            a = env.action_space.sample()
+            env.step(type(a)(command=np.array([a.command[0] * speed, a.command[1]], dtype=np.float32)))
+        skeleton, arrays = records.pack(copy.deepcopy(plan_env.serialize()))
+        rec = record_delayed(env, plan_env, 100, 910, 911, speed)
+        cont = dict(("cont_" + k, v) for k, v in rec.items() if k in (
+            "actions", "z", "true_states", "seen_pose", "seen_states", "reward", "done", "collided", "target_idx",
+            "min_dist", "obs_path_len"))
+        save("g13_serialized_%s.npz" % tag, record=np.array(skeleton), steps_before=np.int32(before), **dict(arrays, **cont))
+
+
 def gen_colored_ego():
     """G12: ColoredEgoCostmapRandomAisleTurnEnv observations (envs/synth_turn_env.py:376-451): 133 x 133 egocentric
     costmap + the 5-vector (unit goal direction, v, w, wheel angle), along a sampled-action trajectory."""
@@ -641,6 +686,7 @@ def main():
     gen_egocentric()
     gen_colored_ego()
     gen_delays_and_pure_pursuit()
+    gen_serialized_records()
     gen_diffdrive_trajectories()
     gen_trajectories()
 

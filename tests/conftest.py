@@ -10,8 +10,36 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+_LAUNCHER = None
+
+
+def _get_launcher():
+    global _LAUNCHER
+    if _LAUNCHER is None:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from launcher import Launcher
+        _LAUNCHER = Launcher()
+    return _LAUNCHER
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # GPU session: the helper that starts child processes for the tests must exist before anything in this process
+    # touches the GPU (tests/launcher.py says why)
+    expr = config.getoption("markexpr", "") or ""
+    if "gpu" in expr and "not gpu" not in expr:
+        _get_launcher()
+
+
+def pytest_unconfigure(config):
+    if _LAUNCHER is not None:
+        _LAUNCHER.close()
+
+
+@pytest.fixture(scope="session")
+def launcher():
+    """tests/launcher.py client: run child processes without forking this (GPU-initialised) process."""
+    return _get_launcher()
 
 
 def pytest_collection_modifyitems(config, items):

@@ -1,7 +1,6 @@
 """The C ABI on its own: a plain C11 program (tests/c_abi/step_from_c.c, gcc, no Python / torch / C++ in the process)
 drives libbcplan.so through include/bcplan.h; its results must be those of the Python host layer on the same scene."""
 import os
-import subprocess
 
 import numpy as np
 import pytest
@@ -11,21 +10,24 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _compile(tmp_path):
+def _compile(tmp_path, launcher):
     exe = str(tmp_path / "step_from_c")
     lib = os.path.join(ROOT, "bc_gym_planning_env_amd", "libbcplan.so")
     cmd = ["gcc", "-std=c11", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
            "-I/opt/rocm/include", os.path.join(ROOT, "tests", "c_abi", "step_from_c.c"), lib, "-L/opt/rocm/lib",
            "-lamdhip64", "-lm", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + os.path.dirname(lib), "-o", exe]
-    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    r = launcher.run(cmd, timeout=300)
+    assert r["rc"] == 0, r["err"]
     return exe
 
 
-def test_plain_c_client_matches_the_python_host_layer(torch_cuda, tmp_path):
+def test_plain_c_client_matches_the_python_host_layer(torch_cuda, tmp_path, launcher):
     torch = torch_cuda
     from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
-    exe = _compile(tmp_path)
-    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout.splitlines()
+    exe = _compile(tmp_path, launcher)
+    r = launcher.run([exe], timeout=120)
+    assert r["rc"] == 0, r["err"]
+    out = r["out"].splitlines()
     assert out[0].startswith("episodes_ended ")
     episodes = int(out[0].split()[1])
     rows = [line.split() for line in out[1:]]

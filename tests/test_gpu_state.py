@@ -166,6 +166,49 @@ def test_whole_env_serialize_roundtrip(torch_cuda):
     assert twin.envs[2].get_state() == env.envs[2].get_state()
 
 
+# records whose State holds the robot's true state (no state delay): the rebuilt env must reproduce the live env's
+# next 100 steps.  With a state delay State.robot_state is the DELAYED state, and set_state hands exactly that to the
+# robot (env.py:278-285) -- the reference's own deserialize would do the same -- so only the record itself is compared.
+G13_EXACT = ["plain", "delay_c2p3", "delay_fresh", "pp", "pp_delay"]
+G13_ALL = G13_EXACT + ["delay_p1s1", "delay_c2p3s1", "delay_filling"]
+
+
+@pytest.mark.parametrize("tag", G13_ALL)
+def test_reference_serialize_record_rebuilds_the_env(torch_cuda, tag):
+    """PlanEnv.serialize() records made by the GENUINE reference mid-episode (g13) -> BatchedPlanEnv.deserialize:
+    EnvView.serialize() of the rebuilt env is the reference's record key for key, and the env carries on as the
+    reference's live env did (true state, what State exposes, reward, done, provider state) for 100 steps."""
+    torch = torch_cuda
+    from oracle import records
+    from bc_gym_planning_env_amd import BatchedPlanEnv
+    from util import ATOL, GOLDEN, z_in
+    g = np.load(os.path.join(GOLDEN, "g13_serialized_%s.npz" % tag))
+    rec = records.unpack(g["record"], g)
+    env = BatchedPlanEnv.deserialize([records.unpack(g["record"], g), records.unpack(g["record"], g)])
+    for i in range(2):
+        assert records.same(rec, env.envs[i].serialize()) == []
+    if tag not in G13_EXACT:
+        return
+    sd = env.params.state_delay
+    for t in range(len(g["cont_actions"])):
+        a = np.repeat(g["cont_actions"][t][None], 2, axis=0)
+        z = np.repeat(z_in(g["cont_z"][t])[None], 2, axis=0)
+        obs, rew, done, _ = env.step(a, noise_z=z)
+        st = env.state.robot.cpu().numpy()
+        np.testing.assert_allclose(st[:, 0], g["cont_true_states"][t], rtol=0, atol=ATOL, err_msg="%s step %d" % (tag, t))
+        assert (st[:, 0] == st[:, 1]).all()
+        np.testing.assert_allclose(obs.pose.cpu().numpy()[:, 0], g["cont_seen_pose"][t], rtol=0, atol=ATOL)
+        seen = (env.state.robot_state_seen if sd else env.state.robot).cpu().numpy()[:, 0]
+        np.testing.assert_allclose(seen, g["cont_seen_states"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(rew.cpu().numpy(), g["cont_reward"][t], rtol=0, atol=ATOL)
+        assert (done.cpu().numpy() == g["cont_done"][t]).all()
+        assert (env.state.robot_collided.cpu().numpy() == g["cont_collided"][t]).all()
+        assert (env.state.target_idx.cpu().numpy() == g["cont_target_idx"][t]).all()
+        np.testing.assert_allclose(env.state.min_spat_dist_so_far.cpu().numpy(), g["cont_min_dist"][t], rtol=0, atol=ATOL)
+        if t in (0, 30, 99):
+            assert len(env.envs[0].observation().path) == int(g["cont_obs_path_len"][t])
+
+
 @pytest.mark.parametrize("kind", ["two-kernel", "single-kernel"])
 def test_steps_replayed_from_a_captured_graph(torch_cuda, kind):
     """The step counter (noise stream, parity of the parking counters) lives on the device: steps captured into a HIP

@@ -148,6 +148,32 @@ def test_state_serialization_round_trip():
         assert cp != st
 
 
+G13 = ["plain", "delay_p1s1", "delay_c2p3s1", "delay_c2p3", "delay_filling", "delay_fresh", "pp", "pp_delay"]
+
+
+@pytest.mark.parametrize("tag", G13)
+def test_reference_serialize_records_are_read_and_written_key_for_key(tag):
+    """g13: records the genuine reference's PlanEnv.serialize() produced mid-episode (delay queues filled, both reward
+    providers).  State / EnvParams / CostMap2D read them and write them back key for key, value for value."""
+    from oracle import records
+    from bc_gym_planning_env_amd import api
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g13_serialized_%s.npz" % tag))
+    rec = records.unpack(g["record"], g)
+    assert set(rec) == {'version', 'state', 'params', 'path', 'costmap'}
+    st = api.State.deserialize(rec['state'])
+    params = api.EnvParams.deserialize(rec['params'])
+    assert records.same(rec['state'], st.serialize()) == []
+    assert records.same(rec['params'], params.serialize(), 'params') == []
+    assert records.same(rec['costmap'], api.CostMap2D.from_state(rec['costmap']).get_state(), 'costmap') == []
+    it = int(rec['state']['current_iter'])
+    assert it == int(g["steps_before"])
+    assert len(st.poses_queue) == min(it, params.pose_delay) and len(st.control_queue) == min(it, params.control_delay)
+    assert len(st.robot_state_queue) == min(it, params.state_delay)
+    assert all(isinstance(a, api.Action) for a in st.control_queue)
+    assert all(isinstance(r, api.TricycleRobotState) for r in st.robot_state_queue)
+    assert st.copy() == st
+
+
 def test_env_params_serialize_roundtrip():
     """EnvParams / RewardParams as the reference's Serializable (envs/base/params.py:46-59): nested dict of basic types"""
     import pickle
