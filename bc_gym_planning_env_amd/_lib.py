@@ -12,7 +12,7 @@ MODEL_TRICYCLE, MODEL_DIFFDRIVE = 0, 1
 REWARD_CONTINUOUS, REWARD_PURE_PURSUIT = 0, 1
 STEP_AUTO_RESET, STEP_ACTIONS_F32 = 1, 2
 ERR_ANGLE_JUMP, ERR_TIME_ORDER = 1, 2
-TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL, TUNE_DEFER, TUNE_EDT_LDS = 0, 1, 2, 3, 4
+TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL, TUNE_DEFER, TUNE_EDT_LDS, TUNE_FUSED = 0, 1, 2, 3, 4, 5
 E_NO_DEVICE = -2
 
 _f64p = C.POINTER(C.c_double)
@@ -108,6 +108,7 @@ SYMBOLS = {
                                        C.c_void_p, C.c_void_p]),
     "bcp_device_normals": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
     "bcp_step_form": (C.c_int, [_H]),
+    "bcp_step_health": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
     "bcp_time_step_kernels": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p,
                                         C.POINTER(C.c_float)]),
     "bcp_time_steps": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]),

@@ -565,10 +565,11 @@ class BatchedPlanEnv(object):
             env.envs[i].set_state(State.deserialize(r['state']))
         return env
 
-    def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None, defer=None, edt_lds=None):
+    def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None, defer=None, edt_lds=None, fused=None):
         """Execution knobs of libbcplan (bcp_set_tuning); results never depend on them."""
         for key, val in ((_lib.TUNE_EXACT_MODE, exact_mode), (_lib.TUNE_DENSE_THRESHOLD, dense_threshold),
-                         (_lib.TUNE_CULL, cull), (_lib.TUNE_DEFER, defer), (_lib.TUNE_EDT_LDS, edt_lds)):
+                         (_lib.TUNE_CULL, cull), (_lib.TUNE_DEFER, defer), (_lib.TUNE_EDT_LDS, edt_lds),
+                         (_lib.TUNE_FUSED, fused)):
             if val is not None:
                 _lib.check(self._lib.bcp_set_tuning(self._h, key, int(val)))
 
@@ -691,6 +692,11 @@ class BatchedPlanEnv(object):
 
     def check_errors(self):
         """Raise what the reference would have raised during the last step (synchronises)."""
+        events = C.c_uint64()
+        _lib.check(self._lib.bcp_step_health(self._h, C.byref(events)))
+        if events.value:
+            raise RuntimeError("libbcplan: %d in-kernel wait(s) of the single-launch step hit the watchdog; results are "
+                               "incomplete" % events.value)
         bad = torch.nonzero(self.err).flatten()
         if len(bad):
             raise Exception("Path has missing/corrupted angle data at env indices: %s" % bad.cpu().numpy())
@@ -708,7 +714,8 @@ class BatchedPlanEnv(object):
         return a, io, flags
 
     STEP_FORMS = {0: "step_kernel", 1: "step_fast_pair_kernel",
-                  2: "step_fast_pair_kernel + step_pending_kernel (one step = these two launches)"}
+                  2: "step_fast_pair_kernel + step_pending_kernel (one step = these two launches)",
+                  3: "step_fused_kernel"}
 
     def step_kernels(self):
         """The kernels one step() launches as the handle is configured now (bcp_step_form)."""

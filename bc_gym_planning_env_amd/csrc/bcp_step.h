@@ -109,10 +109,15 @@ struct StepArgs {
     // the single-kernel step) reads it, tick[1] = as kernel 2 reads it, tick[2] = seed, tick[3] = ticket of the
     // single-kernel step.  Two-kernel step: kernel 1 copies tick[0] to tick[1], kernel 2 stores tick[1] + 1 to tick[0]
     // -- each word is only written while no kernel that reads it is running.  Single-kernel step: the last workgroup
-    // to finish (ticket) advances tick[0].
+    // to finish (ticket) advances tick[0].  tick[4] = watchdog events of the single-launch step (see wait_ready).
     uint64_t* tick;
     int32_t* pending_base;     // [2][kShards] or nullptr
     int32_t* adapt_base;       // [2] thresholds + [2][kShards] in-place counters, or nullptr (no adaptation)
+    // single-launch step (step_fused_kernel)
+    struct StepQueue* queues;  // [2], alternating by step parity
+    struct Parked* parked;     // [kQShards][parked_cap]
+    int32_t parked_cap;        // slots per shard
+    int32_t n_producers;       // workgroups that step envs (the rest of the grid only settles parked poses)
 };
 
 constexpr uint32_t kStepAdvances = 1u << 24;   // internal flag: this launch is the last kernel of its step
@@ -590,6 +595,40 @@ struct Pending {
     double popped_pose[3], popped_state[7];
 };
 
+// reward-provider outcome for the pose as it is when nothing collides, computed ahead of the collision verdict
+struct ScoredFree {
+    double rew, min_dist;
+    int target;
+};
+
+// ---- single-launch step: parked envs travel from the wave that stepped them to the team that settles them -----------
+// One queue per shard (shard = env block % kQShards).  Producers reserve slots with one atomic add per wavefront, write
+// the record with write-through (sc1) stores, drain them (s_waitcnt vmcnt(0)) and only then store the slot's `ready`
+// stamp (sc1); consumers claim RESERVED slots (compare-and-swap on `head`, so no claim ever refers to a slot nobody will
+// fill), poll the stamp with sc1 loads and read the record with sc1 loads -- no fence, no L2 write-back or invalidate
+// (MI355X: per-XCD L2s are not coherent; sc1 stores / loads are served by the memory side).  The stamp is the step
+// counter + 1, so slots never need clearing (bcp_seed, which restarts the counter, clears them).
+constexpr int kQShards = 8;
+constexpr int kWaveModeBacklog = 12;   // this many claimable poses in a shard: a pose per WAVE instead of one per team
+
+struct alignas(128) QueueLine {
+    int32_t v;
+    int32_t pad[31];
+};
+
+struct StepQueue {                 // one per step parity; the step zeroes the next step's copy
+    QueueLine reserve[kQShards];   // slots handed out to producers
+    QueueLine head[kQShards];      // slots claimed by consumers
+    QueueLine done;                // producer workgroups that have published all their records
+};
+
+struct alignas(16) Parked {
+    Pending q;
+    ScoredFree sc;                 // the scorer wave's result for the un-rolled-back pose
+    int32_t pad_;
+    unsigned long long ready;      // step counter + 1 once the record is complete
+};
+
 // entry of the non-shared map / path arrays that env i uses
 __device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const Pending& q)
 {
@@ -600,14 +639,9 @@ __device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const
 // (:377-396), reward (:352), done (:407-419), outputs, optional reset, state write-back.  Runs on one lane for env i.
 // PLAIN = true (the two-kernel step: no delays, continuous reward provider -- see step_uses_deferral) compiles the
 // delay queues and the pure-pursuit branch out.
-// reward-provider outcome for the pose as it is when nothing collides, computed ahead of the collision verdict
-struct ScoredFree {
-    double rew, min_dist;
-    int target;
-};
-
-template <bool PLAIN>
-__device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
+// (A: StepArgs, or the slim StepOut of the single-launch step -- only a.S, the output pointers and a.flags are used)
+template <bool PLAIN, typename A>
+__device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
                                              const PathWindow* free_window = nullptr, const ScoredFree* scored = nullptr)
 {
     const DevParams& P = a.S->P;
@@ -737,8 +771,9 @@ __device__ __forceinline__ void finalize_env(const StepArgs& a, int64_t i, Pendi
 }
 
 // ---- loads shared by the step kernels ------------------------------------------------------------------------
-template <bool PLAIN>
-__device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, bool active, Pending& q, double& cmd0, double& cmd1)
+template <bool PLAIN, typename A>
+__device__ __forceinline__ void load_env(const A& a, uint64_t seed, uint64_t step_counter, int64_t i, bool active,
+                                         Pending& q, double& cmd0, double& cmd1)
 {
     const DevParams& P = a.S->P;
     Robot& r = q.r;
@@ -781,9 +816,15 @@ __device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, bool acti
             q.z[1] = a.noise_z[3 * i + 1];
             q.z[2] = a.noise_z[3 * i + 2];
         } else {
-            device_normals(a.seed, (uint64_t)(a.S->env_id_base + i), a.step_counter, q.z);
+            device_normals(seed, (uint64_t)(a.S->env_id_base + i), step_counter, q.z);
         }
     }
+}
+
+template <bool PLAIN>
+__device__ __forceinline__ void load_env(const StepArgs& a, int64_t i, bool active, Pending& q, double& cmd0, double& cmd1)
+{
+    load_env<PLAIN>(a, a.seed, a.step_counter, i, active, q, cmd0, cmd1);
 }
 
 // General step kernel: robot model, collision settled in place by collides_wave (distance-field classification when
@@ -1077,3 +1118,429 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The step as ONE launch.  Workgroups of four wavefronts: two (mover, scorer) pairs, 128 envs per workgroup and round.
+//   producer part -- step_fast_pair_kernel's, except that an undecided env is not finished optimistically: once the
+//     scorer's result is in, its whole record (state after the robot model + that result) is parked in the shard queue
+//     with write-through stores and the env is left to whoever settles the pose;
+//   consumer part -- every workgroup, once it has stepped its envs, takes parked poses that are claimable NOW (a team of
+//     four waves per pose, or a wave per pose when a shard is crowded), rasterises them exactly (coop_collides) and
+//     finishes the env (finalize_env: rollback on a hit, reward, done, reset, stores); the grid's extra workgroups
+//     (blockIdx >= n_producers) do only that, from the start, and stay until every producer has published
+//     (queue.done == n_producers) and every queue is drained.  Producers never wait for anything, and a claim always
+//     refers to a slot whose owner is already running, so the launch cannot deadlock whatever the dispatch order; the
+//     host keeps the number of waiting workgroups far below what is resident at once.
+// No kernel boundary between classification and exact test (the second launch cost 13 of the step's 30 us on the metric
+// workload: boundary, cold caches, ramp-up for ~1000 poses), no agent-scope fence (which would write back / invalidate
+// the XCD's L2): records and stamps are sc1 stores drained with s_waitcnt vmcnt(0), reads are sc1 loads.
+template <typename T>
+__device__ __forceinline__ void st_sc1(T* p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T>
+__device__ __forceinline__ T ld_sc1(const T* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// a record, field by field (every byte that is read back is written here, write-through); the stamp goes separately
+template <bool PLAIN>
+__device__ __forceinline__ void park_store(Parked* e, const Pending& q, const ScoredFree& sc)
+{
+    st_sc1(&e->q.c, q.c);
+    st_sc1(&e->q.s, q.s);
+    st_sc1(&e->q.px, q.px);
+    st_sc1(&e->q.py, q.py);
+    st_sc1(&e->q.r.p.x, q.r.p.x);
+    st_sc1(&e->q.r.p.y, q.r.p.y);
+    st_sc1(&e->q.r.p.th, q.r.p.th);
+    st_sc1(&e->q.r.v, q.r.v);
+    st_sc1(&e->q.r.w, q.r.w);
+    st_sc1(&e->q.r.steer, q.r.steer);
+    st_sc1(&e->q.r.wheel, q.r.wheel);
+    st_sc1(&e->q.old.x, q.old.x);
+    st_sc1(&e->q.old.y, q.old.y);
+    st_sc1(&e->q.old.th, q.old.th);
+    st_sc1(&e->q.min_dist, q.min_dist);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st_sc1(&e->q.z[k], q.z[k]);
+    st_sc1(&e->q.target, q.target);
+    st_sc1(&e->q.iter, q.iter);
+    st_sc1(&e->q.err, q.err);
+    st_sc1(&e->q.drawn, q.drawn);
+    st_sc1(&e->q.collided, q.collided);
+    st_sc1(&e->q.env_lo, q.env_lo);
+    st_sc1(&e->q.env_hi, q.env_hi);
+    st_sc1(&e->q.geom, q.geom);
+    if (!PLAIN) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st_sc1(&e->q.popped_pose[k], q.popped_pose[k]);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) st_sc1(&e->q.popped_state[k], q.popped_state[k]);
+    }
+    st_sc1(&e->sc.rew, sc.rew);
+    st_sc1(&e->sc.min_dist, sc.min_dist);
+    st_sc1(&e->sc.target, sc.target);
+}
+
+template <bool PLAIN>
+__device__ __forceinline__ void park_load(const Parked* e, Pending& q, ScoredFree& sc)
+{
+    q.c = ld_sc1(&e->q.c);
+    q.s = ld_sc1(&e->q.s);
+    q.px = ld_sc1(&e->q.px);
+    q.py = ld_sc1(&e->q.py);
+    q.r.p.x = ld_sc1(&e->q.r.p.x);
+    q.r.p.y = ld_sc1(&e->q.r.p.y);
+    q.r.p.th = ld_sc1(&e->q.r.p.th);
+    q.r.v = ld_sc1(&e->q.r.v);
+    q.r.w = ld_sc1(&e->q.r.w);
+    q.r.steer = ld_sc1(&e->q.r.steer);
+    q.r.wheel = ld_sc1(&e->q.r.wheel);
+    q.old.x = ld_sc1(&e->q.old.x);
+    q.old.y = ld_sc1(&e->q.old.y);
+    q.old.th = ld_sc1(&e->q.old.th);
+    q.min_dist = ld_sc1(&e->q.min_dist);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q.z[k] = ld_sc1(&e->q.z[k]);
+    q.target = ld_sc1(&e->q.target);
+    q.iter = ld_sc1(&e->q.iter);
+    q.err = ld_sc1(&e->q.err);
+    q.drawn = ld_sc1(&e->q.drawn);
+    q.collided = ld_sc1(&e->q.collided);
+    q.env_lo = ld_sc1(&e->q.env_lo);
+    q.env_hi = ld_sc1(&e->q.env_hi);
+    q.geom = ld_sc1(&e->q.geom);
+    if (!PLAIN) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q.popped_pose[k] = ld_sc1(&e->q.popped_pose[k]);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) q.popped_state[k] = ld_sc1(&e->q.popped_state[k]);
+    }
+    sc.rew = ld_sc1(&e->sc.rew);
+    sc.min_dist = ld_sc1(&e->sc.min_dist);
+    sc.target = ld_sc1(&e->sc.target);
+}
+
+// what finalize_env needs of the launch arguments (passed BY VALUE to the out-of-line parts of the single-launch step)
+struct StepOut {
+    const StepStatic* S;
+    double* reward;
+    uint8_t* done;
+    uint8_t* collided_now;
+    int32_t* err;
+    double* noise_z_out;
+    uint32_t flags;
+};
+
+template <typename A>
+__device__ __forceinline__ StepOut step_out_of(const A& a)
+{
+    StepOut o;
+    o.S = a.S;
+    o.reward = a.reward;
+    o.done = a.done;
+    o.collided_now = a.collided_now;
+    o.err = a.err;
+    o.noise_z_out = a.noise_z_out;
+    o.flags = a.flags;
+    return o;
+}
+
+// Watchdog of the two waits of the single-launch step (a record's stamp, the producers' done count).  Neither can last:
+// a claimed slot's owner is running, and producers never wait -- but a wait that a bug or a broken device turned into an
+// endless one would hang the GPU, so both give up after kWatchdogTicks of the 100 MHz real-time counter, count the event
+// in tick[4] (bcp_step_health; the step's results are then incomplete) and let the launch end.
+constexpr unsigned long long kWatchdogTicks = 200000000ull;   // 2 s
+
+__device__ __forceinline__ bool wait_ready(const Parked* e, unsigned long long stamp, uint64_t* tick)
+{
+    if (ld_sc1(&e->ready) == stamp) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(2);   // the slot's owner is running: a few hundred cycles
+        if (ld_sc1(&e->ready) == stamp) return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kWatchdogTicks) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(tick + 4), 1ull);
+            return false;
+        }
+    }
+}
+
+// finishing a parked env once its pose is settled (one lane)
+template <bool PLAIN>
+__device__ __forceinline__ void finish_parked(const StepOut& o, const Parked* e, bool hit)
+{
+    Pending q;
+    ScoredFree sc;
+    park_load<PLAIN>(e, q, sc);
+    const int64_t i = ((int64_t)q.env_hi << 32) | (uint32_t)q.env_lo;
+    finalize_env<PLAIN>(o, i, q, hit, nullptr, nullptr, (o.flags & kAblateNoReward) ? nullptr : &sc);
+}
+
+// Both halves of the kernel read the launch arguments where they lie -- in the kernel-argument segment, through a
+// constant-address-space reference: scalar loads on demand instead of several hundred bytes of arguments pinned in SGPRs
+// (a by-value copy of StepArgs spilled ~500 of them).
+typedef const __attribute__((address_space(4))) StepArgs& KernArgs;
+
+template <bool WIDE, bool PLAIN>
+__device__ __forceinline__ void fused_produce(const __attribute__((address_space(4))) StepArgs* ap, uint64_t step_counter,
+                                           uint64_t seed)
+{
+    KernArgs a = *ap;
+    const DevParams& P = a.S->P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = wave >> 1;
+    const bool mover = (wave & 1) == 0;
+    StepQueue* const Q = a.queues + (int)(step_counter & 1u);
+    const unsigned long long stamp = step_counter + 1;
+
+    // ---- LDS: [qverts][shared path][2 x {hand_pose 3x64, hand_score 3x64}][box 8][index 128 words]; the consumer part
+    //      re-uses it from the start (the claim, then the exchange buffers of the team rasteriser)
+    __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
+    const int nq = 2 * P.n_verts;
+    const LdsF64 lds_path = a.hot.lds_path_doubles ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
+    __attribute__((address_space(3))) double* hand_pose = qv + nq + a.hot.lds_path_doubles + pair * 6 * kBlock;
+    __attribute__((address_space(3))) double* hand_score = hand_pose + 3 * kBlock;
+    __attribute__((address_space(3))) double* lds_box = qv + nq + a.hot.lds_path_doubles + 12 * kBlock;   // [8]
+    __attribute__((address_space(3))) uint32_t* lds_index = (__attribute__((address_space(3))) uint32_t*)(lds_box + 8);  // [128]
+
+    const int64_t n_blocks = (a.hot.n + 2 * kBlock - 1) / (2 * kBlock);
+    // staging, once per workgroup: footprint vertices, the shared path, its bounding box and bucket index
+    if (tid < nq) qv[tid] = P.qverts[tid >> 1][tid & 1];
+    for (int k = tid; k < a.hot.lds_path_doubles; k += 4 * kBlock) qv[nq + k] = a.hot.path_pts[k];
+    if (a.hot.path_shared) {
+        if (tid < 8) lds_box[tid] = a.hot.path_bbox[tid];
+        if (tid >= 64 && tid < 64 + 128) lds_index[tid - 64] = reinterpret_cast<const uint32_t*>(a.hot.path_index)[tid - 64];
+    }
+    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += a.n_producers) {
+        const int64_t gi = blk * (2 * kBlock) + pair * kBlock + lane;
+        const bool active = gi < a.hot.n;
+        const int64_t i = active ? gi : a.hot.n - 1;
+        // (1) the mover's state / action / noise, the scorer's reward-state words
+        Pending q;
+        double cmd0 = 0.0, cmd1 = 0.0;
+        double box[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (mover) {
+            load_env<PLAIN>(a, seed, step_counter, i, active, q, cmd0, cmd1);
+        } else {
+            q.min_dist = a.hot.st.min_dist[i];
+            q.target = a.hot.st.target_idx[i];
+            q.geom = a.hot.geom_of_env ? a.hot.geom_of_env[i] : 0;
+            q.collided = PLAIN ? 0 : (int32_t)(a.hot.st.collided[i] != 0);
+            if (!a.hot.path_shared) {
+                const int64_t g = a.hot.geom_of_env ? (int64_t)q.geom : i;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) box[k] = a.hot.path_bbox[g * 8 + k];
+            }
+        }
+        // (2) mover: the robot model; the pose the reward provider will see goes to the scorer
+        Robot& r = q.r;
+        if (mover) {
+            q.old = r.p;
+            q.drawn = 0;
+            q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
+            const bool delayed = !PLAIN && P.pose_delay > 0 && q.iter + 1 > 1;
+            hand_pose[lane] = delayed ? q.popped_pose[0] : r.p.x;
+            hand_pose[kBlock + lane] = delayed ? q.popped_pose[1] : r.p.y;
+            hand_pose[2 * kBlock + lane] = delayed ? q.popped_pose[2] : r.p.th;
+        }
+        __syncthreads();
+        bool hit = false, park = false;
+        if (mover) {
+            // (3a) collision: distance-field classification; an undecided env is parked below
+            const int64_t g = slot_of(a.S, i, q);
+            double ox = a.S->map.ox, oy = a.S->map.oy;
+            if (a.S->map.origins) {
+                ox = a.S->map.origins[2 * g + 0];
+                oy = a.S->map.origins[2 * g + 1];
+            }
+            const int px = (int)rint((r.p.x - ox) * a.S->map.inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
+            const int py = (int)rint((r.p.y - oy) * a.S->map.inv_res);
+            const double c = cos(r.p.th), s = sin(r.p.th);
+            const int64_t map_env = a.S->map.shared ? 0 : g;
+            OuterLookups look;
+            look.off_map = true;
+            if (!(a.flags & (kAblateNoCollision | kAblateNoClassify)))
+                look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
+            const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
+            if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
+                park = true;
+                q.c = c;
+                q.s = s;
+                q.px = px;
+                q.py = py;
+                q.env_lo = (int32_t)(uint32_t)i;
+                q.env_hi = (int32_t)(i >> 32);
+            }
+        } else if (!(a.flags & kAblateNoReward)) {
+            // (3b) scorer: the reward provider for the pose as it stands if nothing collides
+            const double x = hand_pose[lane], y = hand_pose[kBlock + lane], th = hand_pose[2 * kBlock + lane];
+            const int64_t g = slot_of(a.S, i, q);
+            PathWindow win;
+            if (a.S->path.shared)
+                win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
+            else
+                win = path_window(P, box, a.S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+            const int m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
+            double min_dist = q.min_dist;
+            int target = q.target;
+            double rew;
+            const double* gpath = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
+            if (!PLAIN && P.reward_provider == BCP_REWARD_PURE_PURSUIT) {
+                if (lds_path) rew = reward_pure_pursuit(lds_path, m, x, y, q.collided != 0, min_dist, target);
+                else rew = reward_pure_pursuit(gpath, m, x, y, q.collided != 0, min_dist, target);
+            } else if (lds_path) {
+                rew = reward_step(P, lds_path, win, m, x, y, th, min_dist, target);
+            } else {
+                rew = reward_step(P, gpath, win, m, x, y, th, min_dist, target);
+            }
+            hand_score[lane] = rew;
+            hand_score[kBlock + lane] = min_dist;
+            hand_score[2 * kBlock + lane] = (double)target;
+        }
+        __syncthreads();
+        if (mover) {
+            ScoredFree sc;
+            sc.rew = hand_score[lane];
+            sc.min_dist = hand_score[kBlock + lane];
+            sc.target = (int)hand_score[2 * kBlock + lane];
+            // (4) park the undecided envs first (somebody is waiting for them), then finish the decided ones
+            const uint64_t parking = __ballot(park);
+            if (parking) {
+                const int shard = (int)(blk % kQShards);
+                const int first = (int)__ffsll((unsigned long long)parking) - 1;
+                int base = 0;
+                if (lane == first) base = atomicAdd(&Q->reserve[shard].v, (int)__popcll(parking));   // one atomic per wave
+                base = bcast_i(base, first);
+                if (park) {
+                    Parked* e = a.parked + (int64_t)shard * a.parked_cap + base + (int)__popcll(parking & ((1ull << lane) - 1ull));
+                    park_store<PLAIN>(e, q, sc);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has left before the stamp goes
+                    st_sc1(&e->ready, stamp);
+                }
+            }
+            if (active && !park)
+                finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &sc);
+        }
+    }
+    // every record and stamp of this workgroup has left (each storing wave drains its own stores, then the barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) atomicAdd(&Q->done.v, 1);
+}
+
+template <bool WIDE, bool PLAIN>
+__device__ __forceinline__ void fused_consume(const __attribute__((address_space(4))) StepArgs* ap, uint64_t step_counter,
+                                           bool producer)
+{
+    KernArgs a = *ap;
+    const DevParams& P = a.S->P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    StepQueue* const Q = a.queues + (int)(step_counter & 1u);
+    const unsigned long long stamp = step_counter + 1;
+    __attribute__((address_space(3))) int32_t* ctl = (__attribute__((address_space(3))) int32_t*)lds_dyn;   // [4]
+    const LdsU32 xch = (LdsU32)lds_dyn + 16;
+    const int home = (int)(blockIdx.x % kQShards);
+    for (;;) {
+        __syncthreads();   // (the previous round is done with ctl / xch; first round: the producer part is done with LDS)
+        if (tid == 0) {
+            int c_shard = 0, c_slot = 0, c_take = 0;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                for (int o = 0; o < kQShards && c_take == 0; ++o) {
+                    const int sh = (home + o) % kQShards;
+                    int h = ld_sc1(&Q->head[sh].v);
+                    for (;;) {
+                        const int avail = ld_sc1(&Q->reserve[sh].v) - h;
+                        if (avail <= 0) break;
+                        const int take = avail >= kWaveModeBacklog ? 4 : 1;
+                        const int old = atomicCAS(&Q->head[sh].v, h, h + take);
+                        if (old == h) {
+                            c_shard = sh;
+                            c_slot = h;
+                            c_take = take;
+                            break;
+                        }
+                        h = old;
+                    }
+                }
+                if (c_take != 0 || producer) break;   // a producer only takes what is there now, and leaves otherwise
+                // dedicated consumer: stay until every producer has published and every queue is drained
+                if (ld_sc1(&Q->done.v) >= a.n_producers) {
+                    bool left = false;   // (the reserve counters are final now)
+                    for (int sh = 0; sh < kQShards; ++sh) left |= ld_sc1(&Q->head[sh].v) < ld_sc1(&Q->reserve[sh].v);
+                    if (!left) break;
+                } else if (__builtin_amdgcn_s_memrealtime() - t0 > kWatchdogTicks) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 4), 1ull);
+                    break;
+                } else {
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            if (c_take == 1) wait_ready(a.parked + (int64_t)c_shard * a.parked_cap + c_slot, stamp, a.tick);
+            ctl[0] = c_shard;
+            ctl[1] = c_slot;
+            ctl[2] = c_take;
+        }
+        __syncthreads();
+        const int shard = ctl[0], slot = ctl[1], take = ctl[2];
+        if (take == 0) break;
+        // take == 1: the team on one pose (wave = 2 * (row-chunk slot) + (edge slot)); take == 4: a crowded shard, waves
+        // 0 .. take-1 on a pose each through the single-wave rasteriser
+        const bool team = take == 1;
+        const Parked* e = a.parked + (int64_t)shard * a.parked_cap + slot + (team ? 0 : wave);
+        bool hit = false;
+        if (team || wave < take) {
+            if (!team) {
+                if (lane == 0) wait_ready(e, stamp, a.tick);
+                __builtin_amdgcn_wave_barrier();
+            }
+            const double c = ld_sc1(&e->q.c), s = ld_sc1(&e->q.s);
+            const int px = ld_sc1(&e->q.px), py = ld_sc1(&e->q.py);
+            const int64_t g = a.hot.map_shared ? 0
+                              : (a.hot.geom_of_env ? (int64_t)ld_sc1(&e->q.geom)
+                                                   : (((int64_t)ld_sc1(&e->q.env_hi) << 32) | (uint32_t)ld_sc1(&e->q.env_lo)));
+            const uint32_t* words = a.hot.map_bits + g * a.hot.map_env_stride;
+            const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
+            if (!(a.flags & kAblateNoCoop)) {
+                if (team)
+                    hit = coop_collides_quad<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols,
+                                                   a.hot.map_wpr, wave, xch);
+                else
+                    hit = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr);
+            }
+        }
+        if (team) hit = __syncthreads_or(hit);   // (take is workgroup-uniform)
+        if (team ? tid == 0 : (wave < take && lane == 0)) finish_parked<PLAIN>(step_out_of(a), e, hit);
+    }
+}
+
+template <bool WIDE, bool PLAIN>
+__global__ void __launch_bounds__(4 * kBlock, 4) step_fused_kernel(const StepArgs a)
+{
+    const __attribute__((address_space(4))) StepArgs* ap =
+        (const __attribute__((address_space(4))) StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    // the step counter and the noise seed live on the device (StepArgs::tick)
+    const uint64_t step_counter = a.tick[0], seed = a.tick[2];
+    const int par = (int)(step_counter & 1u);
+    if (blockIdx.x == 0) {
+        // arm the counters of the NEXT step (the two copies alternate; nobody touches that copy during this step)
+        for (int k = threadIdx.x; k < (int)(sizeof(StepQueue) / sizeof(int32_t)); k += 4 * kBlock)
+            reinterpret_cast<int32_t*>(a.queues + (par ^ 1))[k] = 0;
+    }
+    const bool producer = (int)blockIdx.x < a.n_producers;
+    if (producer) fused_produce<WIDE, PLAIN>(ap, step_counter, seed);
+    fused_consume<WIDE, PLAIN>(ap, step_counter, producer);
+    if ((a.flags & kStepAdvances) && threadIdx.x == 0) {   // the last workgroup to get here moves the step counter on
+        unsigned int* ticket = reinterpret_cast<unsigned int*>(a.tick + 3);
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            *ticket = 0u;
+            a.tick[0] = step_counter + 1;
+        }
+    }
+}

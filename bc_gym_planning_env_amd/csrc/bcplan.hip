@@ -103,6 +103,11 @@ struct bcp_handle {
     bool ring_planned, ring_refreshed;   // plan -> refresh -> release, in that order
     int32_t edt_in_lds;       // distance transform of maps that fit: the LDS-resident kernel (BCP_TUNE_EDT_LDS)
     int32_t last_step_form;   // 0 none yet, 1 single-kernel step, 2 two-kernel step (parking counters in use)
+    int32_t fused;            // settle parked poses inside the step launch (step_fused_kernel) instead of a second launch
+    StepQueue* queues;        // owned: [2] queue counters of the single-launch step, alternating by step parity
+    Parked* parked;           // owned: [kQShards][parked_cap]
+    int32_t parked_cap;
+    int32_t fused_grid[4];    // resident workgroups of step_fused_kernel per variant (0 = not asked yet)
 };
 
 // number of entries of a non-shared map / path / initial-state array
@@ -880,9 +885,10 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->adaptive = 1;
     h->cull_enabled = 1;
     h->defer = 1;
+    h->fused = 1;
     h->static_dirty = true;
     fill_dev_params(h);
-    if (hipMalloc((void**)&h->tick, 4 * sizeof(uint64_t)) != hipSuccess || hipMemset(h->tick, 0, 4 * sizeof(uint64_t)) != hipSuccess) {
+    if (hipMalloc((void**)&h->tick, 8 * sizeof(uint64_t)) != hipSuccess || hipMemset(h->tick, 0, 8 * sizeof(uint64_t)) != hipSuccess) {
         if (h->tick) (void)hipFree(h->tick);
         delete h;
         return fail(BCP_E_HIP, "bcp_create: cannot allocate device memory");
@@ -905,6 +911,8 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->tick) (void)hipFree(h->tick);
     if (h->pending_count) (void)hipFree(h->pending_count);
     if (h->adapt) (void)hipFree(h->adapt);
+    if (h->queues) (void)hipFree(h->queues);
+    if (h->parked) (void)hipFree(h->parked);
     if (h->dev_static) (void)hipFree(h->dev_static);
     if (h->ego_bins) (void)hipFree(h->ego_bins);
     if (h->ego_order) (void)hipFree(h->ego_order);
@@ -924,6 +932,8 @@ extern "C" int bcp_seed(bcp_handle* h, uint64_t seed)
     const uint64_t tick[4] = {0, 0, seed, 0};
     HIP_TRY(hipMemcpy(h->tick, tick, sizeof(tick), hipMemcpyHostToDevice));
     if (h->pending_count) HIP_TRY(hipMemset(h->pending_count, 0, 2 * kShards * sizeof(int32_t)));
+    if (h->queues) HIP_TRY(hipMemset(h->queues, 0, 2 * sizeof(StepQueue)));
+    if (h->parked) HIP_TRY(hipMemset(h->parked, 0, (size_t)kQShards * h->parked_cap * sizeof(Parked)));   // the `ready` stamps
     if (h->adapt) {
         HIP_TRY(hipMemset(h->adapt, 0, (2 + 2 * kShards) * sizeof(int32_t)));
         const int32_t init[2] = {h->dense_threshold, h->dense_threshold};
@@ -966,6 +976,9 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
             return BCP_OK;
         case BCP_TUNE_EDT_LDS:
             h->edt_in_lds = value ? 1 : 0;
+            return BCP_OK;
+        case BCP_TUNE_FUSED:
+            h->fused = value ? 1 : 0;
             return BCP_OK;
         case BCP_TUNE_CULL:
             h->cull_enabled = value ? 1 : 0;
@@ -1110,6 +1123,15 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
             const int32_t init[2] = {h->dense_threshold, h->dense_threshold};
             HIP_TRY(hipMemcpyAsync(h->adapt, init, sizeof(init), hipMemcpyHostToDevice, s));
             HIP_TRY(hipStreamSynchronize(s));   // (`init` is on the stack)
+        }
+        if (!h->parked) {
+            // single-launch step: every env of a shard's 128-env blocks may be parked at once
+            const int64_t blocks128 = (h->n + 2 * kBlock - 1) / (2 * kBlock);
+            h->parked_cap = (int32_t)(((blocks128 + kQShards - 1) / kQShards) * 2 * kBlock);
+            HIP_TRY(hipMalloc((void**)&h->parked, (size_t)kQShards * h->parked_cap * sizeof(Parked)));
+            HIP_TRY(hipMemsetAsync(h->parked, 0, (size_t)kQShards * h->parked_cap * sizeof(Parked), s));
+            HIP_TRY(hipMalloc((void**)&h->queues, 2 * sizeof(StepQueue)));
+            HIP_TRY(hipMemsetAsync(h->queues, 0, 2 * sizeof(StepQueue), s));
         }
     }
     h->have_map = true;
@@ -1300,12 +1322,15 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
         if (rc != BCP_OK) return rc;
     }
     const StepStatic& S = h->host_static;
-    const int32_t form = S.pending ? 2 : 1;
+    // (an explicit BCP_TUNE_DENSE_THRESHOLD asks for poses to be settled inside the stepping wave: the two-launch form has that path)
+    const bool fused = S.pending && h->fused && h->parked && h->adaptive;
+    const int32_t form = fused ? 3 : (S.pending ? 2 : 1);
     if (form != h->last_step_form) {
         if (form == 2 && h->last_step_form != 0) {
             const int rc = rearm_parking(h, s);
             if (rc != BCP_OK) return rc;
         }
+        if (form == 3 && h->last_step_form != 0) HIP_TRY(hipMemsetAsync(h->queues, 0, 2 * sizeof(StepQueue), s));
         h->last_step_form = form;
     }
     StepArgs a;
@@ -1345,8 +1370,46 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     a.tick = h->tick;
     a.pending_base = h->pending_count;
     a.adapt_base = adapt ? h->adapt : nullptr;
+    a.queues = h->queues;
+    a.parked = h->parked;
+    a.parked_cap = h->parked_cap;
+    a.n_producers = 0;
     const int blocks = (int)((h->n + kBlock - 1) / kBlock);
-    if (S.pending) {
+    if (fused) {
+        // the whole step as one launch: workgroups step 128 envs each, then -- together with the grid's extra
+        // workgroups -- settle the parked poses (step_fused_kernel)
+        const int variant = (S.wide ? 2 : 0) | (step_is_plain(h) ? 1 : 0);
+        const void* fn = variant == 3 ? (const void*)step_fused_kernel<true, true>
+                       : variant == 2 ? (const void*)step_fused_kernel<true, false>
+                       : variant == 1 ? (const void*)step_fused_kernel<false, true>
+                                      : (const void*)step_fused_kernel<false, false>;
+        const size_t lds_prod = ((size_t)h->params.n_verts * 2 + S.lds_path_doubles + 12 * kBlock + 8) * sizeof(double) +
+                                2 * kBlock * sizeof(uint32_t);
+        const size_t lds_cons = (16 + (size_t)2 * 4 * (S.wide ? 8 : 3) * 64) * sizeof(uint32_t);
+        const size_t lds = std::max(lds_prod, lds_cons);
+        if (!h->fused_grid[variant]) {
+            int per_cu = 0, cus = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 4 * kBlock, lds));
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+            h->fused_grid[variant] = std::max(per_cu, 1) * std::max(cus, 1);
+        }
+        // Workgroups that only settle parked poses WAIT (for producers to publish); producers never do.  At most half
+        // of what is resident at once waits, so producers always find room, whatever the dispatch order.
+        const int capacity = h->fused_grid[variant];
+        const int64_t blocks128 = (h->n + 2 * kBlock - 1) / (2 * kBlock);
+        int64_t waiting = std::max<int64_t>(capacity / 4, capacity - blocks128);
+        waiting = std::min<int64_t>(waiting, capacity / 2);
+        waiting = std::min<int64_t>(waiting, std::max<int64_t>(8, blocks128));
+        a.n_producers = (int32_t)std::min<int64_t>(blocks128, capacity - waiting);
+        a.flags |= kStepAdvances;
+        const dim3 grid((unsigned)(a.n_producers + waiting)), block(4 * kBlock);
+        switch (variant) {
+            case 3: hipLaunchKernelGGL((step_fused_kernel<true, true>), grid, block, lds, s, a); break;
+            case 2: hipLaunchKernelGGL((step_fused_kernel<true, false>), grid, block, lds, s, a); break;
+            case 1: hipLaunchKernelGGL((step_fused_kernel<false, true>), grid, block, lds, s, a); break;
+            default: hipLaunchKernelGGL((step_fused_kernel<false, false>), grid, block, lds, s, a); break;
+        }
+    } else if (S.pending) {
         // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest
         const size_t lds1 = ((size_t)h->params.n_verts * 2 + S.lds_path_doubles) * sizeof(double);
         const size_t lds2 = (size_t)2 * 4 * (S.wide ? 8 : 3) * 64 * sizeof(uint32_t);
@@ -1415,11 +1478,21 @@ extern "C" int bcp_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, vo
     return BCP_OK;
 }
 
+extern "C" int bcp_step_health(bcp_handle* h, uint64_t* watchdog_events)
+{
+    if (!h || !watchdog_events) return fail(BCP_E_INVALID, "bcp_step_health: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(watchdog_events, h->tick + 4, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return BCP_OK;
+}
+
 extern "C" int bcp_step_form(bcp_handle* h)
 {
     if (!h) return fail(BCP_E_INVALID, "bcp_step_form: null handle");
     if (!h->have_map || !h->have_path || !h->have_state) return fail(BCP_E_STATE, "bcp_step_form: costmaps, paths and state must be set first");
-    return step_uses_deferral(h) ? (h->dense_threshold >= 0 ? 2 : 1) : 0;
+    if (!step_uses_deferral(h)) return 0;
+    if (h->dense_threshold < 0) return 1;
+    return (h->fused && h->parked && h->adaptive) ? 3 : 2;
 }
 
 extern "C" int bcp_time_steps(bcp_handle* h, const bcp_step_io* io, uint32_t flags, int32_t steps, void* stream,

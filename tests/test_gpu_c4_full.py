@@ -1,0 +1,126 @@
+"""BASELINE.json configs[3] ("C4") at its full size: 65 536 AisleTurnEnv replicas (envs/synth_turn_env.py:110-216,
+10 m / 256 px, the four flip variants) with PRIVATE costmaps stored uint8 [N, 256, 256] (valid region 256 x 141, the
+padding poisoned with lethal cells: it must never be read as in-map) and PRIVATE 130-point paths, tricycle + noise.
+The full batch is checked through size-independent properties; a 2048-env sample against the oracle, step by step."""
+import os
+
+import numpy as np
+import pytest
+
+from util import ATOL, GOLDEN, z_in
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["g8_traj_aisle_c4_00.npz", "g8_traj_aisle_c4_10.npz", "g8_traj_aisle_c4_01.npz", "g8_traj_aisle_c4_11.npz"]
+
+
+def test_c4_private_256x256_maps_full_size(torch_cuda, oracle):
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    gs = [np.load(os.path.join(GOLDEN, nm)) for nm in NAMES]
+    res = float(gs[0]["resolution"])
+    n, steps = 65536, 24
+    rng = np.random.RandomState(31)
+    idx = (np.arange(n) % 4).astype(np.int64)
+    params = EnvParams(resolution=res, refine_path=False)
+    env = BatchedPlanEnv([CostMap2D(x["costmap"], res, x["origin"]) for x in gs], [x["path"] for x in gs], params, n_envs=n,
+                         auto_reset=True, template_of_env=idx, map_storage=(256, 256), seed=13)
+    assert tuple(env._keep["map"].shape) == (n, 256, 256)
+    assert all(x["costmap"].shape == (256, 141) for x in gs) and all(len(x["path"]) == 130 for x in gs)
+    # the same maps with the padding poisoned (cells beyond the true shape are lethal): 4.3 GB built on the device
+    t_maps = np.full((4, 256, 256), 254, dtype=np.uint8)
+    for t, x in enumerate(gs):
+        t_maps[t, :256, :141] = x["costmap"]
+    idx_d = torch.from_numpy(idx).cuda()
+    origins = torch.from_numpy(np.stack([x["origin"] for x in gs])).cuda()[idx_d].contiguous()
+    vr = torch.full((n,), 256, dtype=torch.int32, device="cuda")
+    vc = torch.full((n,), 141, dtype=torch.int32, device="cuda")
+    env.set_costmap_tensors(torch.from_numpy(t_maps).cuda()[idx_d].contiguous(), origins, res, vr, vc)
+    assert env._keep["map"].numel() == n * 65536
+
+    # random mid-episode states: poses scattered along each env's own path, a third of them next to a wall
+    st = np.zeros((7, n))
+    tgt = np.zeros(n, dtype=np.int32)
+    md = np.zeros(n)
+    for t, x in enumerate(gs):
+        sel = np.nonzero(idx == t)[0]
+        m = len(sel)
+        path = x["path"]
+        k = rng.randint(0, len(path), m)
+        st[0, sel] = path[k, 0] + rng.normal(0, 0.15, m)
+        st[1, sel] = path[k, 1] + rng.normal(0, 0.15, m)
+        st[2, sel] = path[k, 2] + rng.normal(0, 0.3, m)
+        ly, lx = np.nonzero(x["costmap"] == 254)
+        near = rng.rand(m) < 0.33
+        pick = rng.randint(0, len(ly), m)
+        ang, rad = rng.uniform(-np.pi, np.pi, m), rng.uniform(0.4, 1.2, m)
+        st[0, sel] = np.where(near, x["origin"][0] + lx[pick] * res + rad * np.cos(ang), st[0, sel])
+        st[1, sel] = np.where(near, x["origin"][1] + ly[pick] * res + rad * np.sin(ang), st[1, sel])
+        tgt[sel] = np.clip(k + rng.randint(-3, 4, m), 1, len(path) - 1)
+        md[sel] = np.hypot(path[tgt[sel], 0] - st[0, sel], path[tgt[sel], 1] - st[1, sel]) + rng.uniform(-0.01, 0.05, m)
+    st[3] = rng.uniform(0, 0.5, n)
+    st[4] = rng.uniform(-0.5, 0.5, n)
+    st[6] = rng.uniform(-1.0, 1.0, n)
+    it = rng.randint(0, 1200, n).astype(np.int32)
+    it[:16] = 1199   # time out on the first step
+    # envs 0 .. 1023: replicas of envs 0 .. 3 (same template every 4th env)
+    for f in range(7):
+        st[f, :1024] = st[f, np.arange(1024) % 4]
+    md[:1024], tgt[:1024], it[:1024] = md[np.arange(1024) % 4], tgt[np.arange(1024) % 4], it[np.arange(1024) % 4]
+    env.state.robot.copy_(torch.from_numpy(st))
+    env.state.min_spat_dist_so_far.copy_(torch.from_numpy(md))
+    env.state.target_idx.copy_(torch.from_numpy(tgt))
+    env.state.current_iter.copy_(torch.from_numpy(it))
+
+    sample = np.sort(rng.choice(np.arange(1024, n), 2048, replace=False))
+    p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE)
+    s_maps = t_maps[idx[sample]]
+    s_paths = np.stack([gs[t]["path"] for t in idx[sample]])
+    ref = oracle.OracleBatch(p, len(sample), s_maps, np.stack([gs[t]["origin"] for t in idx[sample]]), res, s_paths,
+                             lens=[130] * len(sample), rows=np.full(len(sample), 256, np.int32),
+                             cols=np.full(len(sample), 141, np.int32))
+    ref.reset_from_paths()
+    np.testing.assert_array_equal(ref.init_target_idx, env._initial_state.target_idx.cpu().numpy()[sample])
+    for f in range(7):
+        ref.st[f][:] = st[f, sample]
+    ref.min_dist[:], ref.target_idx[:], ref.cur_iter[:] = md[sample], tgt[sample], it[sample]
+
+    zout = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    init_pose = env._initial_state.robot.cpu().numpy()
+    tot_coll = tot_done = tot_rew = 0
+    for t in range(steps):
+        a = env.action_space.sample_batch(n, rng)
+        a[:, 0] *= 1.5
+        a[:1024] = a[np.arange(1024) % 4]
+        zin = None
+        if t < steps // 2:   # first half: injected normals (replicas share them); second half: the on-device stream
+            zin = rng.standard_normal((n, 3))
+            zin[:1024] = zin[np.arange(1024) % 4]
+        env.step(a, noise_z=zin, noise_z_out=zout)
+        zs = zout.cpu().numpy()
+        rob = env.state.robot.cpu().numpy()
+        done = env.done.cpu().numpy().astype(bool)
+        hit = env.collided_now.cpu().numpy().astype(bool)
+        if zin is not None:   # replicas stay bit-identical
+            assert (rob[:, :1024] == rob[:, np.arange(1024) % 4]).all()
+            assert (done[:1024] == done[np.arange(1024) % 4]).all()
+        # done law + in-kernel reset: a finished env is back on its initial state, a colliding one always finishes
+        assert (done | ~hit).all()
+        assert (rob[:3, done] == init_pose[:3, done]).all() and (rob[3:5, done] == 0).all()
+        assert (env.state.current_iter.cpu().numpy()[done] == 0).all()
+        assert (env.state.robot_collided.cpu().numpy()[~done] == 0).all()
+        assert np.isfinite(rob).all() and np.isfinite(env.reward.cpu().numpy()).all()
+        # oracle on the sample
+        ref.step(a[sample].astype(np.float64), z_in(zs[sample]), auto_reset=True, threads=8)
+        np.testing.assert_array_equal(done[sample], ref.done.astype(bool), err_msg="step %d" % t)
+        np.testing.assert_array_equal(hit[sample], ref.collided_now.astype(bool))
+        np.testing.assert_array_equal(env.state.target_idx.cpu().numpy()[sample], ref.target_idx)
+        np.testing.assert_array_equal(env.state.current_iter.cpu().numpy()[sample], ref.cur_iter)
+        np.testing.assert_allclose(rob[:, sample], np.stack(ref.st), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(env.reward.cpu().numpy()[sample], ref.reward, rtol=0, atol=ATOL)
+        tot_coll += int(hit.sum())
+        tot_done += int(done.sum())
+        tot_rew += int((env.reward.cpu().numpy() == 1.0).sum())
+    assert tot_coll > 5000 and tot_done > tot_coll and tot_rew > 5000, (tot_coll, tot_done, tot_rew)
+    env.check_errors()
+    env.close()

@@ -1,0 +1,93 @@
+"""The on-device odometry-noise stream (the stand-in for np.random.normal of robot_models/differential_drive.py:43-52):
+what the step kernels draw when no normals are injected must be N(0, 1), slot by slot, and independent across slots,
+envs and steps.  Drawn in bulk through bcp_device_normals, reduced on the GPU."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _phi(x):
+    return 0.5 * (1.0 + math.erf(x / math.sqrt(2.0)))
+
+
+def test_device_normals_are_standard_normal(torch_cuda):
+    """10^7 draws per slot: moments to the 4th, Kolmogorov-Smirnov distance, slot / step / env correlations; then
+    6.7 x 10^8 draws per slot for the mass beyond 3, 4 and 5 sigma."""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import NativeOps
+    ops = NativeOps()
+    ops.seed(20241004)
+    n_envs, n_steps = 65536, 160   # 1.05e7 triples
+    z = ops.device_normals(n_envs, first_step=1000, n_steps=n_steps)   # [steps, envs, 3]
+    n = n_envs * n_steps
+    flat = z.reshape(-1, 3)
+    k = 5.0   # tolerance in standard errors (three slots x a dozen statistics: false alarm ~ 1e-5)
+    for slot in range(3):
+        x = flat[:, slot]
+        m1, m2 = float(x.mean()), float((x * x).mean())
+        m3, m4 = float((x ** 3).mean()), float((x ** 4).mean())
+        assert abs(m1) < k / math.sqrt(n), (slot, m1)
+        assert abs(m2 - 1.0) < k * math.sqrt(2.0 / n), (slot, m2)
+        assert abs(m3) < k * math.sqrt(15.0 / n), (slot, m3)
+        assert abs(m4 - 3.0) < k * math.sqrt(96.0 / n), (slot, m4)
+        # Kolmogorov-Smirnov against Phi, evaluated at 32768 bin edges over [-8, 8] (exact at the edges)
+        bins = 32768
+        hist = torch.histc(x.to(torch.float64), bins=bins, min=-8.0, max=8.0)
+        assert int(hist.sum()) == n   # nothing outside +-8
+        ecdf = (torch.cumsum(hist, 0) / n).cpu().numpy()
+        edges = -8.0 + 16.0 * np.arange(1, bins + 1) / bins
+        cdf = np.array([_phi(e) for e in edges])
+        d = float(np.abs(ecdf - cdf).max())
+        assert d < 1.95 / math.sqrt(n), (slot, d)   # alpha = 1e-3 critical value
+    # independence: slots of one draw, consecutive steps of one env, neighbouring envs of one step
+    se = k / math.sqrt(n)
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        assert abs(float((flat[:, a] * flat[:, b]).mean())) < se
+        assert abs(float((flat[:, a] ** 2 * flat[:, b] ** 2).mean()) - 1.0) < k * math.sqrt(8.0 / n)   # (z0, z1 share a radius)
+    for slot in range(3):
+        assert abs(float((z[1:, :, slot] * z[:-1, :, slot]).mean())) < se * 1.01
+        assert abs(float((z[:, 1:, slot] * z[:, :-1, slot]).mean())) < se * 1.01
+    del z, flat
+    # tails: 64 chunks of 1.05e7 draws per slot
+    counts = torch.zeros(3, 4, dtype=torch.int64, device="cuda")
+    biggest = torch.zeros(3, dtype=torch.float64, device="cuda")
+    chunks = 64
+    for c in range(chunks):
+        zc = ops.device_normals(n_envs, first_step=10000 + c * n_steps, n_steps=n_steps).reshape(-1, 3).abs()
+        for j, thr in enumerate((3.0, 4.0, 5.0, 6.0)):
+            counts[:, j] += (zc > thr).sum(0)
+        biggest = torch.maximum(biggest, zc.max(0).values)
+    total = n * chunks
+    counts = counts.cpu().numpy()
+    for j, thr in enumerate((3.0, 4.0, 5.0)):
+        p = 2.0 * (1.0 - _phi(thr))
+        exp, sd = p * total, math.sqrt(p * total)
+        assert (np.abs(counts[:, j] - exp) < k * sd + 1).all(), (thr, counts[:, j], exp)
+    assert (counts[:, 3] <= 25).all()               # 1.3 expected beyond 6 sigma
+    assert (biggest.cpu().numpy() > 5.5).all()      # the tails are there ...
+    assert (biggest.cpu().numpy() < 6.8).all()      # ... up to the lattice of the 32-bit uniforms
+
+
+def test_step_consumes_the_stream_it_reports(torch_cuda):
+    """The normals a step reports through noise_z_out are those of bcp_device_normals for (seed, global env, step)."""
+    torch = torch_cuda
+    import os
+    from util import GOLDEN, env_from_traj
+    g = np.load(os.path.join(GOLDEN, "g8_traj_mini_00.npz"))
+    n = 5000
+    env = env_from_traj(g, "g8_traj_mini_00.npz", n_envs=n, env_id_base=123456, seed=77)
+    from bc_gym_planning_env_amd import _lib
+    out = torch.empty(6, n, 3, dtype=torch.float64, device="cuda")
+    _lib.check(env._lib.bcp_device_normals(env._h, 0, n, 0, 6, out.data_ptr(), None))
+    zout = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    rng = np.random.RandomState(0)
+    drawn = 0
+    for t in range(6):
+        env.step(env.action_space.sample_batch(n, rng), noise_z_out=zout)
+        used = ~torch.isnan(zout)
+        assert torch.equal(zout[used], out[t][used])
+        drawn += int(used.sum())
+    assert drawn > 6 * n   # (slot 0 is never drawn with PlanEnv's alphas; slots 1 and 2 are once the robot moves)

@@ -274,7 +274,7 @@ def _random_batch(oracle, rng, n, g, name):
     return st, md, tgt, it
 
 
-STEP_MODES = [dict(), dict(defer=0), dict(exact_mode=1), dict(exact_mode=2), dict(cull=0, exact_mode=1),
+STEP_MODES = [dict(), dict(fused=0), dict(defer=0), dict(exact_mode=1), dict(exact_mode=2), dict(cull=0, exact_mode=1),
               dict(cull=0, exact_mode=2), dict(defer=0, dense_threshold=0), dict(dense_threshold=0),
               dict(dense_threshold=64)]
 
@@ -367,7 +367,7 @@ def test_diffdrive_shared_64x64_vs_oracle(torch_cuda, oracle):
     assert tot > 100
 
 
-@pytest.mark.parametrize("mode", [dict(), dict(defer=0), dict(cull=0, exact_mode=1), dict(cull=0, exact_mode=2),
+@pytest.mark.parametrize("mode", [dict(), dict(fused=0), dict(defer=0), dict(cull=0, exact_mode=1), dict(cull=0, exact_mode=2),
                                   dict(dense_threshold=0), dict(dense_threshold=64)],
                          ids=lambda m: "-".join("%s%d" % (k[:4], v) for k, v in sorted(m.items())) or "default")
 def test_private_maps_and_paths_vs_oracle(torch_cuda, oracle, mode):

@@ -174,12 +174,15 @@ def test_step_rejects_undefined_flag_bits(torch_cuda):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("base", [dict(), dict(fused=0)], ids=["one_launch", "two_launches"])
 @pytest.mark.parametrize("pattern", [(("defer", 0), 1), (("defer", 0), 3), (("exact_mode", 1), 1), (("exact_mode", 2), 3),
-                                     (("cull", 0), 1), (("cull", 0), 2)], ids=lambda p: "%s=%d_x%d" % (p[0][0], p[0][1], p[1]))
-def test_switching_the_step_form_mid_episode(torch_cuda, oracle, pattern):
-    """bcp_set_tuning between steps moves the batch between the two-kernel and the single-kernel step; the parity-keyed
-    parking counters must be re-armed when the two-kernel step resumes (an odd number of single-kernel steps used to
-    leave it on a stale counter set).  Every step is compared with the oracle."""
+                                     (("cull", 0), 1), (("cull", 0), 2), (("fused", 0), 1), (("fused", 0), 3)],
+                         ids=lambda p: "%s=%d_x%d" % (p[0][0], p[0][1], p[1]))
+def test_switching_the_step_form_mid_episode(torch_cuda, oracle, pattern, base):
+    """bcp_set_tuning between steps moves the batch between the step forms (one launch with parked poses settled inside
+    it, two launches, the general single kernel); the parity-keyed parking counters / queues must be re-armed when a
+    form that uses them resumes (an odd number of single-kernel steps used to leave the two-launch step on a stale
+    counter set).  Every step is compared with the oracle."""
     import torch
     (key, val), single_steps = pattern
     g = load("g8_traj_mini_03.npz")
@@ -190,7 +193,9 @@ def test_switching_the_step_form_mid_episode(torch_cuda, oracle, pattern):
     ref.reset_from_paths()
     rng = np.random.RandomState(3)
     zout = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
-    defaults = dict(defer=1, exact_mode=0, cull=1)
+    defaults = dict(defer=1, exact_mode=0, cull=1, fused=1)
+    defaults.update(base)
+    env.set_tuning(**base)
     collisions = 0
     # drive towards the walls so that parked poses really collide: the stale-counter bug needs hits among them
     schedule = ([None] * 40 + [(key, val)] * single_steps) * 4 + [None] * 20
