@@ -601,25 +601,33 @@ struct ScoredFree {
     int target;
 };
 
-// ---- single-launch step: parked envs travel from the wave that stepped them to the team that settles them -----------
+// ---- single-launch step: parked envs travel from the wave that stepped them to a wave that settles them -------------
 // One queue per shard (shard = env block % kQShards).  Producers reserve slots with one atomic add per wavefront, write
 // the record with write-through (sc1) stores, drain them (s_waitcnt vmcnt(0)) and only then store the slot's `ready`
 // stamp (sc1); consumers claim RESERVED slots (compare-and-swap on `head`, so no claim ever refers to a slot nobody will
 // fill), poll the stamp with sc1 loads and read the record with sc1 loads -- no fence, no L2 write-back or invalidate
 // (MI355X: per-XCD L2s are not coherent; sc1 stores / loads are served by the memory side).  The stamp is the step
 // counter + 1, so slots never need clearing (bcp_seed, which restarts the counter, clears them).
+// Waves that have run out of work do not poll the queue lines (the producers' atomics live there): the running totals
+// -- slots reserved, slots claimed, producer waves finished -- are kept in kReplicas copies, each on a line of its own,
+// every update is ONE wave instruction with a lane per copy, and an idle wave watches one copy.
 constexpr int kQShards = 8;
-constexpr int kWaveModeBacklog = 12;   // this many claimable poses in a shard: a pose per WAVE instead of one per team
+constexpr int kReplicas = 32;
 
 struct alignas(128) QueueLine {
     int32_t v;
     int32_t pad[31];
 };
 
+struct alignas(128) TallyLine {
+    int32_t reserved, claimed, done;
+    int32_t pad[29];
+};
+
 struct StepQueue {                 // one per step parity; the step zeroes the next step's copy
     QueueLine reserve[kQShards];   // slots handed out to producers
     QueueLine head[kQShards];      // slots claimed by consumers
-    QueueLine done;                // producer workgroups that have published all their records
+    TallyLine tally[kReplicas];    // totals over the shards + mover waves that have published everything
 };
 
 struct alignas(16) Parked {
@@ -1124,13 +1132,11 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
 //   producer part -- step_fast_pair_kernel's, except that an undecided env is not finished optimistically: once the
 //     scorer's result is in, its whole record (state after the robot model + that result) is parked in the shard queue
 //     with write-through stores and the env is left to whoever settles the pose;
-//   consumer part -- every workgroup, once it has stepped its envs, takes parked poses that are claimable NOW (a team of
-//     four waves per pose, or a wave per pose when a shard is crowded), rasterises them exactly (coop_collides) and
-//     finishes the env (finalize_env: rollback on a hit, reward, done, reset, stores); the grid's extra workgroups
-//     (blockIdx >= n_producers) do only that, from the start, and stay until every producer has published
-//     (queue.done == n_producers) and every queue is drained.  Producers never wait for anything, and a claim always
-//     refers to a slot whose owner is already running, so the launch cannot deadlock whatever the dispatch order; the
-//     host keeps the number of waiting workgroups far below what is resident at once.
+//   consumer part -- every WAVE, once its producer role is over (a scorer right after its last reward scan, a mover
+//     after its last finalisation), takes parked poses one at a time, rasterises them exactly (coop_collides) and
+//     finishes the env (finalize_env: rollback on a hit, reward, done, reset, stores), until every mover wave has
+//     reported and every reserved slot has been claimed.  Producers never wait for anything and every workgroup steps
+//     envs first, so the launch cannot deadlock whatever the dispatch order or the residency.
 // No kernel boundary between classification and exact test (the second launch cost 13 of the step's 30 us on the metric
 // workload: boundary, cold caches, ramp-up for ~1000 poses), no agent-scope fence (which would write back / invalidate
 // the XCD's L2): records and stamps are sc1 stores drained with s_waitcnt vmcnt(0), reads are sc1 loads.
@@ -1250,23 +1256,39 @@ __device__ __forceinline__ StepOut step_out_of(const A& a)
     return o;
 }
 
-// Watchdog of the two waits of the single-launch step (a record's stamp, the producers' done count).  Neither can last:
-// a claimed slot's owner is running, and producers never wait -- but a wait that a bug or a broken device turned into an
-// endless one would hang the GPU, so both give up after kWatchdogTicks of the 100 MHz real-time counter, count the event
-// in tick[4] (bcp_step_health; the step's results are then incomplete) and let the launch end.
+// Watchdog of the waits of the single-launch step (a record's stamp, the movers' done count, a claim another wave has
+// won but not yet reported).  None of them can last: a claimed slot's owner is running, and producers never wait -- but a
+// wait that a bug or a broken device turned into an endless one would hang the GPU, so each gives up after
+// kWatchdogTicks of the 100 MHz real-time counter (or kWatchdogSpins polls, whatever the clock does), counts the event in
+// tick[4..6] (bcp_step_health; the step's results are then incomplete) and lets the launch end.
 constexpr unsigned long long kWatchdogTicks = 200000000ull;   // 2 s
+constexpr unsigned kWatchdogSpins = 1u << 20;
+
+// All waits and claims below run with WAVE-UNIFORM control flow: one lane touches memory, the value is broadcast
+// (v_readfirstlane) and every branch is a scalar one.  (A loop that only lane 0 runs, with the rest of the wave waiting
+// at its end, is legal HIP -- but the structuriser then has to thread execution masks through the enclosing loop, and
+// the masks it built for this kernel dropped lanes from the tally updates.)
+template <typename T>
+__device__ __forceinline__ int uniform_ld(const T* p)
+{
+    int v = 0;
+    if (lane_id() == 0) v = (int)ld_sc1(p);
+    return __builtin_amdgcn_readfirstlane(v);
+}
 
 __device__ __forceinline__ bool wait_ready(const Parked* e, unsigned long long stamp, uint64_t* tick)
 {
-    if (ld_sc1(&e->ready) == stamp) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
-        __builtin_amdgcn_s_sleep(2);   // the slot's owner is running: a few hundred cycles
-        if (ld_sc1(&e->ready) == stamp) return true;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > kWatchdogTicks) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(tick + 4), 1ull);
+    for (unsigned spins = 0;; ++spins) {
+        unsigned long long got = 0;
+        if (lane_id() == 0) got = ld_sc1(&e->ready);
+        const bool ready = __builtin_amdgcn_readfirstlane((int)(got == stamp)) != 0;
+        if (ready) return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kWatchdogTicks || spins > kWatchdogSpins) {
+            if (lane_id() == 0) atomicAdd(reinterpret_cast<unsigned long long*>(tick + 4), 1ull);
             return false;
         }
+        __builtin_amdgcn_s_sleep(2);   // the slot's owner is running: a few hundred cycles
     }
 }
 
@@ -1413,9 +1435,11 @@ __device__ __forceinline__ void fused_produce(const __attribute__((address_space
             if (parking) {
                 const int shard = (int)(blk % kQShards);
                 const int first = (int)__ffsll((unsigned long long)parking) - 1;
+                const int count = (int)__popcll(parking);
                 int base = 0;
-                if (lane == first) base = atomicAdd(&Q->reserve[shard].v, (int)__popcll(parking));   // one atomic per wave
+                if (lane == first) base = atomicAdd(&Q->reserve[shard].v, count);   // one atomic per wave
                 base = bcast_i(base, first);
+                if (lane < kReplicas) atomicAdd(&Q->tally[lane].reserved, count);   // (after the reservation itself)
                 if (park) {
                     Parked* e = a.parked + (int64_t)shard * a.parked_cap + base + (int)__popcll(parking & ((1ull << lane) - 1ull));
                     park_store<PLAIN>(e, q, sc);
@@ -1427,100 +1451,89 @@ __device__ __forceinline__ void fused_produce(const __attribute__((address_space
                 finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &sc);
         }
     }
-    // every record and stamp of this workgroup has left (each storing wave drains its own stores, then the barrier)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) atomicAdd(&Q->done.v, 1);
+    if (mover) {
+        // every record, stamp and tally update of this wave has been acknowledged: it has nothing more to publish
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane < kReplicas) atomicAdd(&Q->tally[lane].done, 1);
+    }
 }
 
+// The consumer half, per WAVE: settle parked poses (exact test through the single-wave rasteriser, then the env's
+// finalisation) for as long as there are any, then leave.  "Any" is judged from one copy of the tallies: work exists
+// while reserved > claimed; nothing more can come once every mover wave has reported (done == n_movers) -- `done` is read
+// BEFORE `reserved` (a mover reports only after its reservations were acknowledged on every copy, so `reserved` is then
+// final) and `claimed` after it.
 template <bool WIDE, bool PLAIN>
-__device__ __forceinline__ void fused_consume(const __attribute__((address_space(4))) StepArgs* ap, uint64_t step_counter,
-                                           bool producer)
+__device__ __forceinline__ void fused_consume(const __attribute__((address_space(4))) StepArgs* ap, uint64_t step_counter)
 {
     KernArgs a = *ap;
     const DevParams& P = a.S->P;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = lane_id();
+    const int wave_id = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     StepQueue* const Q = a.queues + (int)(step_counter & 1u);
     const unsigned long long stamp = step_counter + 1;
-    __attribute__((address_space(3))) int32_t* ctl = (__attribute__((address_space(3))) int32_t*)lds_dyn;   // [4]
-    const LdsU32 xch = (LdsU32)lds_dyn + 16;
-    const int home = (int)(blockIdx.x % kQShards);
+    const int n_movers = 2 * a.n_producers;
+    const TallyLine* const tally = &Q->tally[wave_id % kReplicas];
+    const int home = wave_id % kQShards;
+    const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
     for (;;) {
-        __syncthreads();   // (the previous round is done with ctl / xch; first round: the producer part is done with LDS)
-        if (tid == 0) {
-            int c_shard = 0, c_slot = 0, c_take = 0;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                for (int o = 0; o < kQShards && c_take == 0; ++o) {
+        // ---- find work (wave-uniform): a claimable slot, or the certainty that there will be none
+        int c_shard = -1, c_slot = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spins = 0; c_shard < 0; ++spins) {
+            const int done = uniform_ld(&tally->done);          // (in this order: see above)
+            const int reserved = uniform_ld(&tally->reserved);
+            const int claimed = uniform_ld(&tally->claimed);
+            if (reserved > claimed) {
+                for (int o = 0; o < kQShards && c_shard < 0; ++o) {
                     const int sh = (home + o) % kQShards;
-                    int h = ld_sc1(&Q->head[sh].v);
-                    for (;;) {
-                        const int avail = ld_sc1(&Q->reserve[sh].v) - h;
-                        if (avail <= 0) break;
-                        const int take = avail >= kWaveModeBacklog ? 4 : 1;
-                        const int old = atomicCAS(&Q->head[sh].v, h, h + take);
+                    int h = uniform_ld(&Q->head[sh].v);
+                    while (h < uniform_ld(&Q->reserve[sh].v)) {
+                        int old = 0;
+                        if (lane == 0) old = atomicCAS(&Q->head[sh].v, h, h + 1);
+                        old = __builtin_amdgcn_readfirstlane(old);
                         if (old == h) {
                             c_shard = sh;
                             c_slot = h;
-                            c_take = take;
                             break;
                         }
                         h = old;
                     }
                 }
-                if (c_take != 0 || producer) break;   // a producer only takes what is there now, and leaves otherwise
-                // dedicated consumer: stay until every producer has published and every queue is drained
-                if (ld_sc1(&Q->done.v) >= a.n_producers) {
-                    bool left = false;   // (the reserve counters are final now)
-                    for (int sh = 0; sh < kQShards; ++sh) left |= ld_sc1(&Q->head[sh].v) < ld_sc1(&Q->reserve[sh].v);
-                    if (!left) break;
-                } else if (__builtin_amdgcn_s_memrealtime() - t0 > kWatchdogTicks) {
-                    atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 4), 1ull);
+                if (c_shard >= 0) break;
+                if (spins > kWatchdogSpins) {
+                    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 5), 1ull);
                     break;
-                } else {
-                    __builtin_amdgcn_s_sleep(8);
                 }
+                __builtin_amdgcn_s_sleep(4);    // (somebody else took it: its tally update is on the way)
+            } else if (done >= n_movers) {
+                break;                          // every slot ever reserved has been claimed
+            } else if (__builtin_amdgcn_s_memrealtime() - t0 > kWatchdogTicks || spins > kWatchdogSpins) {
+                if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 6), 1ull);
+                break;
+            } else {
+                __builtin_amdgcn_s_sleep(32);   // movers are still stepping
             }
-            if (c_take == 1) wait_ready(a.parked + (int64_t)c_shard * a.parked_cap + c_slot, stamp, a.tick);
-            ctl[0] = c_shard;
-            ctl[1] = c_slot;
-            ctl[2] = c_take;
         }
-        __syncthreads();
-        const int shard = ctl[0], slot = ctl[1], take = ctl[2];
-        if (take == 0) break;
-        // take == 1: the team on one pose (wave = 2 * (row-chunk slot) + (edge slot)); take == 4: a crowded shard, waves
-        // 0 .. take-1 on a pose each through the single-wave rasteriser
-        const bool team = take == 1;
-        const Parked* e = a.parked + (int64_t)shard * a.parked_cap + slot + (team ? 0 : wave);
+        if (c_shard < 0) break;
+        if (lane < kReplicas) atomicAdd(&Q->tally[lane].claimed, 1);
+        const Parked* e = a.parked + (int64_t)c_shard * a.parked_cap + c_slot;
+        wait_ready(e, stamp, a.tick);
+        const double c = ld_sc1(&e->q.c), s = ld_sc1(&e->q.s);
+        const int px = ld_sc1(&e->q.px), py = ld_sc1(&e->q.py);
+        const int64_t g = a.hot.map_shared ? 0
+                          : (a.hot.geom_of_env ? (int64_t)ld_sc1(&e->q.geom)
+                                               : (((int64_t)ld_sc1(&e->q.env_hi) << 32) | (uint32_t)ld_sc1(&e->q.env_lo)));
+        const uint32_t* words = a.hot.map_bits + g * a.hot.map_env_stride;
         bool hit = false;
-        if (team || wave < take) {
-            if (!team) {
-                if (lane == 0) wait_ready(e, stamp, a.tick);
-                __builtin_amdgcn_wave_barrier();
-            }
-            const double c = ld_sc1(&e->q.c), s = ld_sc1(&e->q.s);
-            const int px = ld_sc1(&e->q.px), py = ld_sc1(&e->q.py);
-            const int64_t g = a.hot.map_shared ? 0
-                              : (a.hot.geom_of_env ? (int64_t)ld_sc1(&e->q.geom)
-                                                   : (((int64_t)ld_sc1(&e->q.env_hi) << 32) | (uint32_t)ld_sc1(&e->q.env_lo)));
-            const uint32_t* words = a.hot.map_bits + g * a.hot.map_env_stride;
-            const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
-            if (!(a.flags & kAblateNoCoop)) {
-                if (team)
-                    hit = coop_collides_quad<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols,
-                                                   a.hot.map_wpr, wave, xch);
-                else
-                    hit = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr);
-            }
-        }
-        if (team) hit = __syncthreads_or(hit);   // (take is workgroup-uniform)
-        if (team ? tid == 0 : (wave < take && lane == 0)) finish_parked<PLAIN>(step_out_of(a), e, hit);
+        if (!(a.flags & kAblateNoCoop))
+            hit = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr);
+        if (lane == 0) finish_parked<PLAIN>(step_out_of(a), e, hit);
     }
 }
 
 template <bool WIDE, bool PLAIN>
-__global__ void __launch_bounds__(4 * kBlock, 4) step_fused_kernel(const StepArgs a)
+__global__ void __launch_bounds__(4 * kBlock, 2) step_fused_kernel(const StepArgs a)
 {
     const __attribute__((address_space(4))) StepArgs* ap =
         (const __attribute__((address_space(4))) StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1532,12 +1545,10 @@ __global__ void __launch_bounds__(4 * kBlock, 4) step_fused_kernel(const StepArg
         for (int k = threadIdx.x; k < (int)(sizeof(StepQueue) / sizeof(int32_t)); k += 4 * kBlock)
             reinterpret_cast<int32_t*>(a.queues + (par ^ 1))[k] = 0;
     }
-    const bool producer = (int)blockIdx.x < a.n_producers;
-    if (producer) fused_produce<WIDE, PLAIN>(ap, step_counter, seed);
-    fused_consume<WIDE, PLAIN>(ap, step_counter, producer);
+    fused_produce<WIDE, PLAIN>(ap, step_counter, seed);
+    fused_consume<WIDE, PLAIN>(ap, step_counter);
     if ((a.flags & kStepAdvances) && threadIdx.x == 0) {   // the last workgroup to get here moves the step counter on
         unsigned int* ticket = reinterpret_cast<unsigned int*>(a.tick + 3);
-        __threadfence();
         if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
             *ticket = 0u;
             a.tick[0] = step_counter + 1;

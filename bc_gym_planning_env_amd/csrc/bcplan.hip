@@ -1383,26 +1383,21 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
                        : variant == 2 ? (const void*)step_fused_kernel<true, false>
                        : variant == 1 ? (const void*)step_fused_kernel<false, true>
                                       : (const void*)step_fused_kernel<false, false>;
-        const size_t lds_prod = ((size_t)h->params.n_verts * 2 + S.lds_path_doubles + 12 * kBlock + 8) * sizeof(double) +
-                                2 * kBlock * sizeof(uint32_t);
-        const size_t lds_cons = (16 + (size_t)2 * 4 * (S.wide ? 8 : 3) * 64) * sizeof(uint32_t);
-        const size_t lds = std::max(lds_prod, lds_cons);
+        const size_t lds = ((size_t)h->params.n_verts * 2 + S.lds_path_doubles + 12 * kBlock + 8) * sizeof(double) +
+                           2 * kBlock * sizeof(uint32_t);
         if (!h->fused_grid[variant]) {
             int per_cu = 0, cus = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 4 * kBlock, lds));
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
             h->fused_grid[variant] = std::max(per_cu, 1) * std::max(cus, 1);
         }
-        // Workgroups that only settle parked poses WAIT (for producers to publish); producers never do.  At most half
-        // of what is resident at once waits, so producers always find room, whatever the dispatch order.
-        const int capacity = h->fused_grid[variant];
+        // every workgroup steps envs (128 per round) and then helps settling parked poses: nobody waits for a workgroup
+        // that has not started, so the grid may exceed what is resident -- it is capped there only to keep the
+        // consumers' totals (n_producers) small
         const int64_t blocks128 = (h->n + 2 * kBlock - 1) / (2 * kBlock);
-        int64_t waiting = std::max<int64_t>(capacity / 4, capacity - blocks128);
-        waiting = std::min<int64_t>(waiting, capacity / 2);
-        waiting = std::min<int64_t>(waiting, std::max<int64_t>(8, blocks128));
-        a.n_producers = (int32_t)std::min<int64_t>(blocks128, capacity - waiting);
+        a.n_producers = (int32_t)std::min<int64_t>(blocks128, h->fused_grid[variant]);
         a.flags |= kStepAdvances;
-        const dim3 grid((unsigned)(a.n_producers + waiting)), block(4 * kBlock);
+        const dim3 grid((unsigned)a.n_producers), block(4 * kBlock);
         switch (variant) {
             case 3: hipLaunchKernelGGL((step_fused_kernel<true, true>), grid, block, lds, s, a); break;
             case 2: hipLaunchKernelGGL((step_fused_kernel<true, false>), grid, block, lds, s, a); break;
@@ -1482,7 +1477,33 @@ extern "C" int bcp_step_health(bcp_handle* h, uint64_t* watchdog_events)
 {
     if (!h || !watchdog_events) return fail(BCP_E_INVALID, "bcp_step_health: null argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpy(watchdog_events, h->tick + 4, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    uint64_t ev[3] = {0, 0, 0};   // a record's stamp / a claim that never came / the movers' done count
+    HIP_TRY(hipMemcpy(ev, h->tick + 4, sizeof(ev), hipMemcpyDeviceToHost));
+    *watchdog_events = ev[0] + ev[1] + ev[2];
+    if (*watchdog_events) fail(BCP_OK, "watchdog: %llu stamp waits, %llu claim waits, %llu done waits",
+                               (unsigned long long)ev[0], (unsigned long long)ev[1], (unsigned long long)ev[2]);
+    return BCP_OK;
+}
+
+extern "C" int bcp_step_queues(bcp_handle* h, int32_t* out)
+{
+    if (!h || !out) return fail(BCP_E_INVALID, "bcp_step_queues: null argument");
+    if (!h->queues) return fail(BCP_E_STATE, "bcp_step_queues: the single-launch step has not been set up");
+    HIP_TRY(hipSetDevice(h->device));
+    StepQueue q[2];
+    HIP_TRY(hipMemcpy(q, h->queues, sizeof(q), hipMemcpyDeviceToHost));
+    for (int p = 0; p < 2; ++p) {
+        int32_t* o = out + p * (2 * kQShards + 3 * kReplicas);
+        for (int k = 0; k < kQShards; ++k) {
+            o[k] = q[p].reserve[k].v;
+            o[kQShards + k] = q[p].head[k].v;
+        }
+        for (int k = 0; k < kReplicas; ++k) {
+            o[2 * kQShards + 3 * k + 0] = q[p].tally[k].reserved;
+            o[2 * kQShards + 3 * k + 1] = q[p].tally[k].claimed;
+            o[2 * kQShards + 3 * k + 2] = q[p].tally[k].done;
+        }
+    }
     return BCP_OK;
 }
 

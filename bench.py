@@ -111,59 +111,75 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(g, envs=ENVS_PER_GPU, budget_s=14.0):
-    """The oracle (C restatement, kind "port") on the host cores of this box, SURVEY 8(d): the C3 workload at the
-    metric's N = 65 536 on all the cores this process may use, and the C1 case (one env, one core).  Bounded samples
-    (about `budget_s` + 3 + 3 seconds of CPU wall time)."""
-    import oracle
+def usable_cores():
+    """Cores this process may really use: the affinity mask, cut by the cgroup's CPU quota when there is one."""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(64, avail))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                fields = f.read().split()
+            if path.endswith("cpu.max"):
+                if fields[0] != "max":
+                    avail = min(avail, max(1, int(int(fields[0]) / int(fields[1]))))
+            else:
+                quota = int(fields[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                    period = int(f2.read().split()[0])
+                if quota > 0:
+                    avail = min(avail, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return avail
+
+
+def cpu_baseline(g, envs=ENVS_PER_GPU, budget_s=12.0):
+    """The oracle (C restatement, kind "port") on the host cores of this box, SURVEY 8(d): the C3 workload at the
+    metric's N = 65 536, and the C1 case (one env, one core).  Every thread takes its block of envs through all the
+    steps of a sample inside one library call (bco_run_steps): no Python and no thread start per step.  Bounded samples
+    (a few seconds per thread count tried + about `budget_s` for the best one)."""
+    import oracle
+    avail = usable_cores()
     p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE, spatial_precision=0.2, angular_precision=np.pi / 8)
     ref = oracle.OracleBatch(p, envs, g["costmap"], g["origin"], float(g["resolution"]), g["path"])
     ref.reset_from_paths()
     rng = np.random.RandomState(1)
     lo = np.array([np.pi / 30, -np.pi / 2])
     hi = np.array([np.pi / 6, np.pi / 2])
-    acts = [rng.uniform(lo, hi, (envs, 2)).astype(np.float32).astype(np.float64) for _ in range(4)]
-    zs = [rng.standard_normal((envs, 3)) for _ in range(4)]
-    for k in range(20):  # de-synchronise the replicas as the GPU warm-up does
-        ref.step(acts[k % 4], zs[k % 4], auto_reset=True, threads=threads)
-    steps = 0
+    acts = rng.uniform(lo, hi, (8, envs, 2)).astype(np.float32).astype(np.float64)
+    zs = rng.standard_normal((8, envs, 3))
+    ref.run_steps(acts, zs, 16, threads=min(avail, 16))  # de-synchronise the replicas as the GPU warm-up does
+
+    def rate(threads, steps):
+        t0 = time.perf_counter()
+        ref.run_steps(acts, zs, steps, threads=threads)
+        return envs * steps / (time.perf_counter() - t0)
+
+    one = rate(1, 8)                       # about 2 s on one core
+    tried = {}
+    for t in sorted(set([min(avail, c) for c in (16, 32, 64, 128)])):   # the mask may be wider than what the box grants
+        tried[t] = rate(t, max(8, int(2.0 * one * min(t, 16) / envs)))
+    threads = max(tried, key=tried.get)
+    steps = max(16, int(budget_s * tried[threads] / envs))
     t0 = time.perf_counter()
-    while True:
-        for k in range(5):
-            ref.step(acts[(steps + k) % 4], zs[(steps + k) % 4], auto_reset=True, threads=threads)
-        steps += 5
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or steps >= 2000:
-            break
-    # the same batch on ONE core, for a per-core figure (about 3 s)
-    one = 0
-    t1 = time.perf_counter()
-    while time.perf_counter() - t1 < 3.0:
-        ref.step(acts[one % 4], zs[one % 4], auto_reset=True, threads=1)
-        one += 1
-    dt1 = time.perf_counter() - t1
+    ref.run_steps(acts, zs, steps, threads=threads)
+    dt = time.perf_counter() - t0
     # C1 (BASELINE.json configs[0]): ONE RandomMiniEnv, random actions, reset on done -- the reference's own shape
     ref1 = oracle.OracleBatch(p, 1, g["costmap"], g["origin"], float(g["resolution"]), g["path"])
     ref1.reset_from_paths()
     a1 = rng.uniform(lo, hi, (4096, 1, 2)).astype(np.float32).astype(np.float64)
     z1 = rng.standard_normal((4096, 1, 3))
-    c1 = 0
+    c1_steps = max(4096, int(3.0 * one))
     t2 = time.perf_counter()
-    while time.perf_counter() - t2 < 3.0:
-        for k in range(256):
-            ref1.step(a1[(c1 + k) % 4096], z1[(c1 + k) % 4096], auto_reset=True, threads=1)
-        c1 += 256
+    ref1.run_steps(a1, z1, c1_steps, threads=1)
     dt2 = time.perf_counter() - t2
     return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "cpu_model": cpu_model(), "cores_available": avail,
+            "cpu_model": cpu_model(), "cores_usable": avail,
             "sample": "C3 at N = %d: %d steps of the same workload (C oracle restatement, %d threads, %.1f s)"
                       % (envs, steps, threads, dt),
-            "single_core_value": envs * one / dt1,
-            "c1_single_env": {"value": c1 / dt2, "unit": "env-steps/s", "cores": 1,
-                              "sample": "C1: one RandomMiniEnv, %d steps through the oracle's batch entry point with "
-                                        "n = 1 (%.1f s; includes the ctypes call per step)" % (c1, dt2)},
+            "thread_counts_tried": dict((str(k), v) for k, v in tried.items()),
+            "single_core_value": one,
+            "c1_single_env": {"value": c1_steps / dt2, "unit": "env-steps/s", "cores": 1,
+                              "sample": "C1: one RandomMiniEnv, %d steps, reset on done (%.1f s)" % (c1_steps, dt2)},
             "reference_python": "genuine reference, 1 core of the build container: about 2.3e3 env-steps/s (BASELINE.md; "
                                 "it cannot travel to the GPU box)"}
 

@@ -356,6 +356,11 @@ int bcp_device_normals(bcp_handle *h, int64_t first_env, int64_t n_envs, uint64_
  * stamp, for the producers' done count -- hit its 2 s watchdog since bcp_create.  0 on a healthy device; anything else
  * means steps ended with parked envs left unfinished. */
 int bcp_step_health(bcp_handle *h, uint64_t *watchdog_events /*host*/);
+/* Introspection of the single-launch step's queues (synchronises; tests and debugging): out, host int32 [2][8 + 8 + 32 * 3],
+ * receives for both step parities the slots reserved and the slots claimed per shard (8 + 8) and the 32 copies of the
+ * totals {reserved, claimed, mover waves done}.  After a step all copies of a parity agree, reserved == claimed == the
+ * number of poses the step parked, and done == twice the number of stepping workgroups. */
+int bcp_step_queues(bcp_handle *h, int32_t *out /*host*/);
 /* Which kernels a bcp_step() of this handle launches, as configured now: 0 = step_kernel alone (no distance field, or a
  * forced mode), 1 = step_fast_pair_kernel alone (every undecided pose settled in place), 2 = step_fast_pair_kernel +
  * step_pending_kernel, 3 = step_fused_kernel (one launch).  Negative: BCP_E_*. */

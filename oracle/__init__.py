@@ -132,6 +132,8 @@ def lib():
         L.bco_initial_pure_pursuit_state.argtypes = [_f64p, C.c_int, _f64p, _i32p]
         L.bco_step_batch.argtypes = [C.POINTER(Params), C.POINTER(Batch), C.c_int]
         L.bco_step_batch.restype = C.c_int
+        L.bco_run_steps.argtypes = [C.POINTER(Params), C.POINTER(Batch), C.c_int, C.c_int, _f64p, _f64p, C.c_int]
+        L.bco_run_steps.restype = C.c_int
         _lib = L
     return _lib
 
@@ -479,7 +481,25 @@ class OracleBatch(object):
         self.init_min_dist = self.min_dist.copy()
         self.init_target_idx = self.target_idx.copy()
 
+    def run_steps(self, actions_pool, z_pool, steps, auto_reset=True, threads=1):
+        """`steps` steps inside ONE library call (bco_run_steps: persistent threads, no per-step thread start); step k
+        takes actions_pool[k % len] / z_pool[k % len]."""
+        ap = _f64(actions_pool)
+        assert ap.ndim == 3 and ap.shape[1:] == (self.n, 2)
+        zp = None if z_pool is None else _f64(z_pool)
+        assert zp is None or zp.shape == (ap.shape[0], self.n, 3)
+        b = self._batch(ap[0], None if zp is None else zp[0], auto_reset)
+        rc = lib().bco_run_steps(C.byref(self.params), C.byref(b), int(threads), int(steps), _p(ap, _f64p),
+                                 _p(zp, _f64p) if zp is not None else None, ap.shape[0])
+        assert rc == 0
+
     def step(self, actions, z=None, auto_reset=False, threads=1):
+        b = self._batch(actions, z, auto_reset)
+        rc = lib().bco_step_batch(C.byref(self.params), C.byref(b), int(threads))
+        assert rc == 0
+        return self.reward, self.done
+
+    def _batch(self, actions, z, auto_reset):
         actions = _f64(actions)
         assert actions.shape == (self.n, 2)
         b = Batch()
@@ -527,6 +547,5 @@ class OracleBatch(object):
                 b.init_st[f] = _p(self.init_st[f], _f64p)
             b.init_min_dist = _p(self.init_min_dist, _f64p)
             b.init_target_idx = _p(self.init_target_idx, _i32p)
-        rc = lib().bco_step_batch(C.byref(self.params), C.byref(b), int(threads))
-        assert rc == 0
-        return self.reward, self.done
+        self._alive = (actions, zz)   # the struct holds raw pointers into these
+        return b

@@ -894,3 +894,61 @@ int bco_step_batch(const bco_params *p, const bco_batch *b, int threads)
     for (int t = 0; t < started; ++t) pthread_join(tid[t], NULL);
     return 0;
 }
+
+/* Many steps back to back (bench.py's cpu_baseline): envs are independent, so every thread takes a block of envs
+ * through ALL the steps on its own -- no thread is created or joined per step.  Step k reads actions_pool / z_pool
+ * batch k % pool_len ([pool_len][n][2] / [pool_len][n][3], z_pool may be NULL). */
+typedef struct {
+    const bco_params *p;
+    bco_batch b;
+    int64_t lo, hi;
+    int steps, pool_len;
+    const double *actions_pool, *z_pool;
+} run_job;
+
+static void *run_worker(void *arg)
+{
+    run_job *j = (run_job *)arg;
+    for (int s = 0; s < j->steps; ++s) {
+        const int k = s % j->pool_len;
+        j->b.actions = j->actions_pool + (int64_t)k * j->b.n * 2;
+        j->b.z = j->z_pool ? j->z_pool + (int64_t)k * j->b.n * 3 : NULL;
+        batch_job job = {j->p, &j->b, j->lo, j->hi};
+        batch_worker(&job);
+    }
+    return NULL;
+}
+
+int bco_run_steps(const bco_params *p, const bco_batch *b, int threads, int steps, const double *actions_pool,
+                  const double *z_pool, int pool_len)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    if (steps < 0 || pool_len < 1 || !actions_pool) return -1;
+    static run_job jobs[256];
+    pthread_t tid[256];
+    int64_t chunk = (b->n + threads - 1) / threads;
+    int started = 0;
+    for (int t = 0; t < threads; ++t) {
+        int64_t lo = t * chunk, hi = lo + chunk;
+        if (lo >= b->n) break;
+        if (hi > b->n) hi = b->n;
+        jobs[t].p = p;
+        jobs[t].b = *b;
+        jobs[t].lo = lo;
+        jobs[t].hi = hi;
+        jobs[t].steps = steps;
+        jobs[t].pool_len = pool_len;
+        jobs[t].actions_pool = actions_pool;
+        jobs[t].z_pool = z_pool;
+        if (threads == 1) {
+            run_worker(&jobs[t]);
+            return 0;
+        }
+        if (pthread_create(&tid[t], NULL, run_worker, &jobs[t]) != 0) return -1;
+        ++started;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(tid[t], NULL);
+    return 0;
+}
+

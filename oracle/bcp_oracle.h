@@ -213,6 +213,10 @@ typedef struct bco_batch {
     double *control_q, *pose_q, *state_q, *obs_pose, *obs_state;
 } bco_batch;
 int bco_step_batch(const bco_params *p, const bco_batch *b, int threads);
+/* `steps` steps back to back, every thread taking its block of envs through all of them (no per-step thread start):
+ * step k reads batch k % pool_len of actions_pool [pool_len][n][2] / z_pool [pool_len][n][3] (NULL: no noise input). */
+int bco_run_steps(const bco_params *p, const bco_batch *b, int threads, int steps, const double *actions_pool,
+                  const double *z_pool, int pool_len);
 
 #ifdef __cplusplus
 }

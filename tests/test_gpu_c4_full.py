@@ -74,7 +74,11 @@ def test_c4_private_256x256_maps_full_size(torch_cuda, oracle):
 
     sample = np.sort(rng.choice(np.arange(1024, n), 2048, replace=False))
     p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE)
-    s_maps = t_maps[idx[sample]]
+    # (the oracle reads a private map tightly packed -- row pitch = its true cols -- inside its 65 536-byte slot)
+    t_tight = np.full((4, 256 * 256), 254, dtype=np.uint8)
+    for t, x in enumerate(gs):
+        t_tight[t, :256 * 141] = x["costmap"].reshape(-1)
+    s_maps = t_tight[idx[sample]].reshape(-1, 256, 256)
     s_paths = np.stack([gs[t]["path"] for t in idx[sample]])
     ref = oracle.OracleBatch(p, len(sample), s_maps, np.stack([gs[t]["origin"] for t in idx[sample]]), res, s_paths,
                              lens=[130] * len(sample), rows=np.full(len(sample), 256, np.int32),
