@@ -107,9 +107,7 @@ SYMBOLS = {
     "bcp_mini_world_paths": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "bcp_device_normals": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
-    "bcp_step_queues": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "bcp_step_form": (C.c_int, [_H]),
-    "bcp_step_health": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
     "bcp_time_step_kernels": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p,
                                         C.POINTER(C.c_float)]),
     "bcp_time_steps": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]),

@@ -692,11 +692,6 @@ class BatchedPlanEnv(object):
 
     def check_errors(self):
         """Raise what the reference would have raised during the last step (synchronises)."""
-        events = C.c_uint64()
-        _lib.check(self._lib.bcp_step_health(self._h, C.byref(events)))
-        if events.value:
-            raise RuntimeError("libbcplan: %d in-kernel wait(s) of the single-launch step hit the watchdog; results are "
-                               "incomplete" % events.value)
         bad = torch.nonzero(self.err).flatten()
         if len(bad):
             raise Exception("Path has missing/corrupted angle data at env indices: %s" % bad.cpu().numpy())
@@ -715,7 +710,7 @@ class BatchedPlanEnv(object):
 
     STEP_FORMS = {0: "step_kernel", 1: "step_fast_pair_kernel",
                   2: "step_fast_pair_kernel + step_pending_kernel (one step = these two launches)",
-                  3: "step_fused_kernel"}
+                  3: "step_local_kernel"}
 
     def step_kernels(self):
         """The kernels one step() launches as the handle is configured now (bcp_step_form)."""

@@ -109,15 +109,10 @@ struct StepArgs {
     // the single-kernel step) reads it, tick[1] = as kernel 2 reads it, tick[2] = seed, tick[3] = ticket of the
     // single-kernel step.  Two-kernel step: kernel 1 copies tick[0] to tick[1], kernel 2 stores tick[1] + 1 to tick[0]
     // -- each word is only written while no kernel that reads it is running.  Single-kernel step: the last workgroup
-    // to finish (ticket) advances tick[0].  tick[4] = watchdog events of the single-launch step (see wait_ready).
+    // to finish (ticket) advances tick[0].
     uint64_t* tick;
     int32_t* pending_base;     // [2][kShards] or nullptr
     int32_t* adapt_base;       // [2] thresholds + [2][kShards] in-place counters, or nullptr (no adaptation)
-    // single-launch step (step_fused_kernel)
-    struct StepQueue* queues;  // [2], alternating by step parity
-    struct Parked* parked;     // [kQShards][parked_cap]
-    int32_t parked_cap;        // slots per shard
-    int32_t n_producers;       // workgroups that step envs (the rest of the grid only settles parked poses)
 };
 
 constexpr uint32_t kStepAdvances = 1u << 24;   // internal flag: this launch is the last kernel of its step
@@ -601,40 +596,10 @@ struct ScoredFree {
     int target;
 };
 
-// ---- single-launch step: parked envs travel from the wave that stepped them to a wave that settles them -------------
-// One queue per shard (shard = env block % kQShards).  Producers reserve slots with one atomic add per wavefront, write
-// the record with write-through (sc1) stores, drain them (s_waitcnt vmcnt(0)) and only then store the slot's `ready`
-// stamp (sc1); consumers claim RESERVED slots (compare-and-swap on `head`, so no claim ever refers to a slot nobody will
-// fill), poll the stamp with sc1 loads and read the record with sc1 loads -- no fence, no L2 write-back or invalidate
-// (MI355X: per-XCD L2s are not coherent; sc1 stores / loads are served by the memory side).  The stamp is the step
-// counter + 1, so slots never need clearing (bcp_seed, which restarts the counter, clears them).
-// Waves that have run out of work do not poll the queue lines (the producers' atomics live there): the running totals
-// -- slots reserved, slots claimed, producer waves finished -- are kept in kReplicas copies, each on a line of its own,
-// every update is ONE wave instruction with a lane per copy, and an idle wave watches one copy.
-constexpr int kQShards = 8;
-constexpr int kReplicas = 32;
-
-struct alignas(128) QueueLine {
-    int32_t v;
-    int32_t pad[31];
-};
-
-struct alignas(128) TallyLine {
-    int32_t reserved, claimed, done;
-    int32_t pad[29];
-};
-
-struct StepQueue {                 // one per step parity; the step zeroes the next step's copy
-    QueueLine reserve[kQShards];   // slots handed out to producers
-    QueueLine head[kQShards];      // slots claimed by consumers
-    TallyLine tally[kReplicas];    // totals over the shards + mover waves that have published everything
-};
-
-struct alignas(16) Parked {
+// One env's parked record of the single-launch step (LDS): the state after the robot model + the scorer wave's result
+struct ParkedLocal {
     Pending q;
-    ScoredFree sc;                 // the scorer wave's result for the un-rolled-back pose
-    int32_t pad_;
-    unsigned long long ready;      // step counter + 1 once the record is complete
+    ScoredFree sc;
 };
 
 // entry of the non-shared map / path arrays that env i uses
@@ -645,9 +610,9 @@ __device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const
 
 // Everything of PlanEnv.step() that follows pose_collides(): rollback (env.py:458-459), bookkeeping and delay queues
 // (:377-396), reward (:352), done (:407-419), outputs, optional reset, state write-back.  Runs on one lane for env i.
-// PLAIN = true (the two-kernel step: no delays, continuous reward provider -- see step_uses_deferral) compiles the
-// delay queues and the pure-pursuit branch out.
-// (A: StepArgs, or the slim StepOut of the single-launch step -- only a.S, the output pointers and a.flags are used)
+// PLAIN = true (no delays, continuous reward provider -- see step_is_plain) compiles the delay queues and the
+// pure-pursuit branch out.
+// (A: StepArgs by value, or by reference into the kernel-argument segment -- only a.S, the output pointers and a.flags are used)
 template <bool PLAIN, typename A>
 __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
                                              const PathWindow* free_window = nullptr, const ScoredFree* scored = nullptr)
@@ -1128,426 +1093,222 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The step as ONE launch.  Workgroups of four wavefronts: two (mover, scorer) pairs, 128 envs per workgroup and round.
-//   producer part -- step_fast_pair_kernel's, except that an undecided env is not finished optimistically: once the
-//     scorer's result is in, its whole record (state after the robot model + that result) is parked in the shard queue
-//     with write-through stores and the env is left to whoever settles the pose;
-//   consumer part -- every WAVE, once its producer role is over (a scorer right after its last reward scan, a mover
-//     after its last finalisation), takes parked poses one at a time, rasterises them exactly (coop_collides) and
-//     finishes the env (finalize_env: rollback on a hit, reward, done, reset, stores), until every mover wave has
-//     reported and every reserved slot has been claimed.  Producers never wait for anything and every workgroup steps
-//     envs first, so the launch cannot deadlock whatever the dispatch order or the residency.
-// No kernel boundary between classification and exact test (the second launch cost 13 of the step's 30 us on the metric
-// workload: boundary, cold caches, ramp-up for ~1000 poses), no agent-scope fence (which would write back / invalidate
-// the XCD's L2): records and stamps are sc1 stores drained with s_waitcnt vmcnt(0), reads are sc1 loads.
-template <typename T>
-__device__ __forceinline__ void st_sc1(T* p, T v)
+// The step as ONE launch: step_local_kernel.  The hand-off of undecided poses stays inside the workgroup.
+//
+// Round 1 settled them in a second launch (step_pending_kernel: 13 of the step's 30 us on the metric workload -- kernel
+// boundary, cold caches, ramp-up -- for ~1000 poses).  A global hand-off inside one launch (queues in HBM, write-through
+// stores, sc1 polls, no fences) was built and measured in round 2: 13 - 25 x SLOWER, every parked pose costs device-scope
+// atomics and polls on a few hot lines that the memory side serves one after the other (profiles/r02_queue_handoff_attempt.txt).
+// So nothing leaves the CU here:
+//   * a workgroup = 256 envs = 4 (mover, scorer) wave pairs as in step_fast_pair_kernel + 8 helper waves: 16 waves, one
+//     workgroup per CU, four waves per SIMD;
+//   * movers park the records of their undecided envs (state after the robot model + the scorer's result) in LDS;
+//   * after the third barrier ALL 16 waves draw tickets (an LDS counter) and settle one parked pose each -- exact test
+//     through the single-wave rasteriser, then the env's finalisation (rollback on a hit, reward, done, reset, stores) by
+//     lane 0 -- while the movers first finish their decided envs.  With ~4 parked poses per 256 envs and 16 waves the
+//     exact tests of a workgroup run side by side, right after the classification, on a warm CU.
+// No queue, no atomic in global memory, no poll, no second launch; load balance comes from the workgroup being large
+// (the sum of 256 envs' luck) and from the helper waves.
+constexpr int kLocalPairs = 4;
+constexpr int kLocalWaves = 16;
+constexpr int kLocalEnvs = kLocalPairs * kBlock;
+
+typedef const __attribute__((address_space(4))) StepArgs& KernArgs;   // the launch arguments where they lie: scalar loads on
+                                                                      // demand instead of ~500 bytes pinned in SGPRs
+
+static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    size_t bytes = ((size_t)2 * n_verts + lds_path_doubles + (size_t)kLocalPairs * 6 * kBlock + 8) * sizeof(double);
+    bytes += 2 * kBlock * sizeof(uint32_t);          // bucket index of the shared path
+    bytes += 4 * sizeof(int32_t);                    // parked count, ticket counter
+    bytes = (bytes + 15) & ~(size_t)15;
+    return bytes + (size_t)kLocalEnvs * sizeof(ParkedLocal);
 }
-
-template <typename T>
-__device__ __forceinline__ T ld_sc1(const T* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// a record, field by field (every byte that is read back is written here, write-through); the stamp goes separately
-template <bool PLAIN>
-__device__ __forceinline__ void park_store(Parked* e, const Pending& q, const ScoredFree& sc)
-{
-    st_sc1(&e->q.c, q.c);
-    st_sc1(&e->q.s, q.s);
-    st_sc1(&e->q.px, q.px);
-    st_sc1(&e->q.py, q.py);
-    st_sc1(&e->q.r.p.x, q.r.p.x);
-    st_sc1(&e->q.r.p.y, q.r.p.y);
-    st_sc1(&e->q.r.p.th, q.r.p.th);
-    st_sc1(&e->q.r.v, q.r.v);
-    st_sc1(&e->q.r.w, q.r.w);
-    st_sc1(&e->q.r.steer, q.r.steer);
-    st_sc1(&e->q.r.wheel, q.r.wheel);
-    st_sc1(&e->q.old.x, q.old.x);
-    st_sc1(&e->q.old.y, q.old.y);
-    st_sc1(&e->q.old.th, q.old.th);
-    st_sc1(&e->q.min_dist, q.min_dist);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) st_sc1(&e->q.z[k], q.z[k]);
-    st_sc1(&e->q.target, q.target);
-    st_sc1(&e->q.iter, q.iter);
-    st_sc1(&e->q.err, q.err);
-    st_sc1(&e->q.drawn, q.drawn);
-    st_sc1(&e->q.collided, q.collided);
-    st_sc1(&e->q.env_lo, q.env_lo);
-    st_sc1(&e->q.env_hi, q.env_hi);
-    st_sc1(&e->q.geom, q.geom);
-    if (!PLAIN) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) st_sc1(&e->q.popped_pose[k], q.popped_pose[k]);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) st_sc1(&e->q.popped_state[k], q.popped_state[k]);
-    }
-    st_sc1(&e->sc.rew, sc.rew);
-    st_sc1(&e->sc.min_dist, sc.min_dist);
-    st_sc1(&e->sc.target, sc.target);
-}
-
-template <bool PLAIN>
-__device__ __forceinline__ void park_load(const Parked* e, Pending& q, ScoredFree& sc)
-{
-    q.c = ld_sc1(&e->q.c);
-    q.s = ld_sc1(&e->q.s);
-    q.px = ld_sc1(&e->q.px);
-    q.py = ld_sc1(&e->q.py);
-    q.r.p.x = ld_sc1(&e->q.r.p.x);
-    q.r.p.y = ld_sc1(&e->q.r.p.y);
-    q.r.p.th = ld_sc1(&e->q.r.p.th);
-    q.r.v = ld_sc1(&e->q.r.v);
-    q.r.w = ld_sc1(&e->q.r.w);
-    q.r.steer = ld_sc1(&e->q.r.steer);
-    q.r.wheel = ld_sc1(&e->q.r.wheel);
-    q.old.x = ld_sc1(&e->q.old.x);
-    q.old.y = ld_sc1(&e->q.old.y);
-    q.old.th = ld_sc1(&e->q.old.th);
-    q.min_dist = ld_sc1(&e->q.min_dist);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) q.z[k] = ld_sc1(&e->q.z[k]);
-    q.target = ld_sc1(&e->q.target);
-    q.iter = ld_sc1(&e->q.iter);
-    q.err = ld_sc1(&e->q.err);
-    q.drawn = ld_sc1(&e->q.drawn);
-    q.collided = ld_sc1(&e->q.collided);
-    q.env_lo = ld_sc1(&e->q.env_lo);
-    q.env_hi = ld_sc1(&e->q.env_hi);
-    q.geom = ld_sc1(&e->q.geom);
-    if (!PLAIN) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) q.popped_pose[k] = ld_sc1(&e->q.popped_pose[k]);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) q.popped_state[k] = ld_sc1(&e->q.popped_state[k]);
-    }
-    sc.rew = ld_sc1(&e->sc.rew);
-    sc.min_dist = ld_sc1(&e->sc.min_dist);
-    sc.target = ld_sc1(&e->sc.target);
-}
-
-// what finalize_env needs of the launch arguments (passed BY VALUE to the out-of-line parts of the single-launch step)
-struct StepOut {
-    const StepStatic* S;
-    double* reward;
-    uint8_t* done;
-    uint8_t* collided_now;
-    int32_t* err;
-    double* noise_z_out;
-    uint32_t flags;
-};
-
-template <typename A>
-__device__ __forceinline__ StepOut step_out_of(const A& a)
-{
-    StepOut o;
-    o.S = a.S;
-    o.reward = a.reward;
-    o.done = a.done;
-    o.collided_now = a.collided_now;
-    o.err = a.err;
-    o.noise_z_out = a.noise_z_out;
-    o.flags = a.flags;
-    return o;
-}
-
-// Watchdog of the waits of the single-launch step (a record's stamp, the movers' done count, a claim another wave has
-// won but not yet reported).  None of them can last: a claimed slot's owner is running, and producers never wait -- but a
-// wait that a bug or a broken device turned into an endless one would hang the GPU, so each gives up after
-// kWatchdogTicks of the 100 MHz real-time counter (or kWatchdogSpins polls, whatever the clock does), counts the event in
-// tick[4..6] (bcp_step_health; the step's results are then incomplete) and lets the launch end.
-constexpr unsigned long long kWatchdogTicks = 200000000ull;   // 2 s
-constexpr unsigned kWatchdogSpins = 1u << 20;
-
-// All waits and claims below run with WAVE-UNIFORM control flow: one lane touches memory, the value is broadcast
-// (v_readfirstlane) and every branch is a scalar one.  (A loop that only lane 0 runs, with the rest of the wave waiting
-// at its end, is legal HIP -- but the structuriser then has to thread execution masks through the enclosing loop, and
-// the masks it built for this kernel dropped lanes from the tally updates.)
-template <typename T>
-__device__ __forceinline__ int uniform_ld(const T* p)
-{
-    int v = 0;
-    if (lane_id() == 0) v = (int)ld_sc1(p);
-    return __builtin_amdgcn_readfirstlane(v);
-}
-
-__device__ __forceinline__ bool wait_ready(const Parked* e, unsigned long long stamp, uint64_t* tick)
-{
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (unsigned spins = 0;; ++spins) {
-        unsigned long long got = 0;
-        if (lane_id() == 0) got = ld_sc1(&e->ready);
-        const bool ready = __builtin_amdgcn_readfirstlane((int)(got == stamp)) != 0;
-        if (ready) return true;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > kWatchdogTicks || spins > kWatchdogSpins) {
-            if (lane_id() == 0) atomicAdd(reinterpret_cast<unsigned long long*>(tick + 4), 1ull);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(2);   // the slot's owner is running: a few hundred cycles
-    }
-}
-
-// finishing a parked env once its pose is settled (one lane)
-template <bool PLAIN>
-__device__ __forceinline__ void finish_parked(const StepOut& o, const Parked* e, bool hit)
-{
-    Pending q;
-    ScoredFree sc;
-    park_load<PLAIN>(e, q, sc);
-    const int64_t i = ((int64_t)q.env_hi << 32) | (uint32_t)q.env_lo;
-    finalize_env<PLAIN>(o, i, q, hit, nullptr, nullptr, (o.flags & kAblateNoReward) ? nullptr : &sc);
-}
-
-// Both halves of the kernel read the launch arguments where they lie -- in the kernel-argument segment, through a
-// constant-address-space reference: scalar loads on demand instead of several hundred bytes of arguments pinned in SGPRs
-// (a by-value copy of StepArgs spilled ~500 of them).
-typedef const __attribute__((address_space(4))) StepArgs& KernArgs;
 
 template <bool WIDE, bool PLAIN>
-__device__ __forceinline__ void fused_produce(const __attribute__((address_space(4))) StepArgs* ap, uint64_t step_counter,
-                                           uint64_t seed)
+__global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const StepArgs launch_args)
 {
-    KernArgs a = *ap;
+    KernArgs a = *(const __attribute__((address_space(4))) StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint64_t step_counter = a.tick[0], seed = a.tick[2];   // (StepArgs::tick: counter and seed live on the device)
     const DevParams& P = a.S->P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pair = wave >> 1;
-    const bool mover = (wave & 1) == 0;
-    StepQueue* const Q = a.queues + (int)(step_counter & 1u);
-    const unsigned long long stamp = step_counter + 1;
+    const bool mover = wave < kLocalPairs, scorer = wave >= kLocalPairs && wave < 2 * kLocalPairs;
+    const int pair = wave & (kLocalPairs - 1);
 
-    // ---- LDS: [qverts][shared path][2 x {hand_pose 3x64, hand_score 3x64}][box 8][index 128 words]; the consumer part
-    //      re-uses it from the start (the claim, then the exchange buffers of the team rasteriser)
+    // ---- LDS
     __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
     const int nq = 2 * P.n_verts;
-    const LdsF64 lds_path = a.hot.lds_path_doubles ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
-    __attribute__((address_space(3))) double* hand_pose = qv + nq + a.hot.lds_path_doubles + pair * 6 * kBlock;
+    const int npath = a.hot.lds_path_doubles;
+    const LdsF64 lds_path = npath ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
+    __attribute__((address_space(3))) double* hand_pose = qv + nq + npath + pair * 6 * kBlock;
     __attribute__((address_space(3))) double* hand_score = hand_pose + 3 * kBlock;
-    __attribute__((address_space(3))) double* lds_box = qv + nq + a.hot.lds_path_doubles + 12 * kBlock;   // [8]
+    __attribute__((address_space(3))) double* lds_box = qv + nq + npath + kLocalPairs * 6 * kBlock;   // [8]
     __attribute__((address_space(3))) uint32_t* lds_index = (__attribute__((address_space(3))) uint32_t*)(lds_box + 8);  // [128]
+    __attribute__((address_space(3))) int32_t* ctl = (__attribute__((address_space(3))) int32_t*)(lds_index + 2 * kBlock);   // [4]
+    const uint32_t rec_off = (uint32_t)((((size_t)(nq + npath + kLocalPairs * 6 * kBlock + 8) * sizeof(double) +
+                                          2 * kBlock * sizeof(uint32_t) + 4 * sizeof(int32_t)) + 15) & ~(size_t)15);
+    __attribute__((address_space(3))) ParkedLocal* rec =
+        (__attribute__((address_space(3))) ParkedLocal*)((__attribute__((address_space(3))) char*)lds_dyn + rec_off);
 
-    const int64_t n_blocks = (a.hot.n + 2 * kBlock - 1) / (2 * kBlock);
-    // staging, once per workgroup: footprint vertices, the shared path, its bounding box and bucket index
+    // staging: footprint vertices, the shared path with its bounding box and bucket index, the counters
     if (tid < nq) qv[tid] = P.qverts[tid >> 1][tid & 1];
-    for (int k = tid; k < a.hot.lds_path_doubles; k += 4 * kBlock) qv[nq + k] = a.hot.path_pts[k];
+    for (int k = tid; k < npath; k += kLocalWaves * kBlock) qv[nq + k] = a.hot.path_pts[k];
     if (a.hot.path_shared) {
-        if (tid < 8) lds_box[tid] = a.hot.path_bbox[tid];
-        if (tid >= 64 && tid < 64 + 128) lds_index[tid - 64] = reinterpret_cast<const uint32_t*>(a.hot.path_index)[tid - 64];
+        if (tid >= 512 && tid < 520) lds_box[tid - 512] = a.hot.path_bbox[tid - 512];
+        if (tid >= 576 && tid < 576 + 128) lds_index[tid - 576] = reinterpret_cast<const uint32_t*>(a.hot.path_index)[tid - 576];
     }
-    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += a.n_producers) {
-        const int64_t gi = blk * (2 * kBlock) + pair * kBlock + lane;
-        const bool active = gi < a.hot.n;
-        const int64_t i = active ? gi : a.hot.n - 1;
-        // (1) the mover's state / action / noise, the scorer's reward-state words
-        Pending q;
-        double cmd0 = 0.0, cmd1 = 0.0;
-        double box[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (mover) {
-            load_env<PLAIN>(a, seed, step_counter, i, active, q, cmd0, cmd1);
-        } else {
-            q.min_dist = a.hot.st.min_dist[i];
-            q.target = a.hot.st.target_idx[i];
-            q.geom = a.hot.geom_of_env ? a.hot.geom_of_env[i] : 0;
-            q.collided = PLAIN ? 0 : (int32_t)(a.hot.st.collided[i] != 0);
-            if (!a.hot.path_shared) {
-                const int64_t g = a.hot.geom_of_env ? (int64_t)q.geom : i;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) box[k] = a.hot.path_bbox[g * 8 + k];
-            }
-        }
-        // (2) mover: the robot model; the pose the reward provider will see goes to the scorer
-        Robot& r = q.r;
-        if (mover) {
-            q.old = r.p;
-            q.drawn = 0;
-            q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
-            const bool delayed = !PLAIN && P.pose_delay > 0 && q.iter + 1 > 1;
-            hand_pose[lane] = delayed ? q.popped_pose[0] : r.p.x;
-            hand_pose[kBlock + lane] = delayed ? q.popped_pose[1] : r.p.y;
-            hand_pose[2 * kBlock + lane] = delayed ? q.popped_pose[2] : r.p.th;
-        }
-        __syncthreads();
-        bool hit = false, park = false;
-        if (mover) {
-            // (3a) collision: distance-field classification; an undecided env is parked below
-            const int64_t g = slot_of(a.S, i, q);
-            double ox = a.S->map.ox, oy = a.S->map.oy;
-            if (a.S->map.origins) {
-                ox = a.S->map.origins[2 * g + 0];
-                oy = a.S->map.origins[2 * g + 1];
-            }
-            const int px = (int)rint((r.p.x - ox) * a.S->map.inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
-            const int py = (int)rint((r.p.y - oy) * a.S->map.inv_res);
-            const double c = cos(r.p.th), s = sin(r.p.th);
-            const int64_t map_env = a.S->map.shared ? 0 : g;
-            OuterLookups look;
-            look.off_map = true;
-            if (!(a.flags & (kAblateNoCollision | kAblateNoClassify)))
-                look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
-            const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
-            if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
-                park = true;
-                q.c = c;
-                q.s = s;
-                q.px = px;
-                q.py = py;
-                q.env_lo = (int32_t)(uint32_t)i;
-                q.env_hi = (int32_t)(i >> 32);
-            }
-        } else if (!(a.flags & kAblateNoReward)) {
-            // (3b) scorer: the reward provider for the pose as it stands if nothing collides
-            const double x = hand_pose[lane], y = hand_pose[kBlock + lane], th = hand_pose[2 * kBlock + lane];
-            const int64_t g = slot_of(a.S, i, q);
-            PathWindow win;
-            if (a.S->path.shared)
-                win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
-            else
-                win = path_window(P, box, a.S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
-            const int m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
-            double min_dist = q.min_dist;
-            int target = q.target;
-            double rew;
-            const double* gpath = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
-            if (!PLAIN && P.reward_provider == BCP_REWARD_PURE_PURSUIT) {
-                if (lds_path) rew = reward_pure_pursuit(lds_path, m, x, y, q.collided != 0, min_dist, target);
-                else rew = reward_pure_pursuit(gpath, m, x, y, q.collided != 0, min_dist, target);
-            } else if (lds_path) {
-                rew = reward_step(P, lds_path, win, m, x, y, th, min_dist, target);
-            } else {
-                rew = reward_step(P, gpath, win, m, x, y, th, min_dist, target);
-            }
-            hand_score[lane] = rew;
-            hand_score[kBlock + lane] = min_dist;
-            hand_score[2 * kBlock + lane] = (double)target;
-        }
-        __syncthreads();
-        if (mover) {
-            ScoredFree sc;
-            sc.rew = hand_score[lane];
-            sc.min_dist = hand_score[kBlock + lane];
-            sc.target = (int)hand_score[2 * kBlock + lane];
-            // (4) park the undecided envs first (somebody is waiting for them), then finish the decided ones
-            const uint64_t parking = __ballot(park);
-            if (parking) {
-                const int shard = (int)(blk % kQShards);
-                const int first = (int)__ffsll((unsigned long long)parking) - 1;
-                const int count = (int)__popcll(parking);
-                int base = 0;
-                if (lane == first) base = atomicAdd(&Q->reserve[shard].v, count);   // one atomic per wave
-                base = bcast_i(base, first);
-                if (lane < kReplicas) atomicAdd(&Q->tally[lane].reserved, count);   // (after the reservation itself)
-                if (park) {
-                    Parked* e = a.parked + (int64_t)shard * a.parked_cap + base + (int)__popcll(parking & ((1ull << lane) - 1ull));
-                    park_store<PLAIN>(e, q, sc);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has left before the stamp goes
-                    st_sc1(&e->ready, stamp);
-                }
-            }
-            if (active && !park)
-                finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &sc);
-        }
-    }
+    if (tid >= 960 && tid < 964) ctl[tid - 960] = 0;
+
+    const int64_t gi = (int64_t)blockIdx.x * kLocalEnvs + pair * kBlock + lane;
+    const bool active = gi < a.hot.n;
+    const int64_t i = active ? gi : a.hot.n - 1;   // (inactive lanes of the last workgroup shadow env n-1 and never store)
+
+    // (1) the mover's state / action / noise, the scorer's reward-state words
+    Pending q;
+    double cmd0 = 0.0, cmd1 = 0.0;
+    double box[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (mover) {
-        // every record, stamp and tally update of this wave has been acknowledged: it has nothing more to publish
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane < kReplicas) atomicAdd(&Q->tally[lane].done, 1);
+        load_env<PLAIN>(a, seed, step_counter, i, active, q, cmd0, cmd1);
+    } else if (scorer) {
+        q.min_dist = a.hot.st.min_dist[i];
+        q.target = a.hot.st.target_idx[i];
+        q.geom = a.hot.geom_of_env ? a.hot.geom_of_env[i] : 0;
+        q.collided = PLAIN ? 0 : (int32_t)(a.hot.st.collided[i] != 0);
+        if (!a.hot.path_shared) {
+            const int64_t g = a.hot.geom_of_env ? (int64_t)q.geom : i;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) box[k] = a.hot.path_bbox[g * 8 + k];
+        }
     }
-}
-
-// The consumer half, per WAVE: settle parked poses (exact test through the single-wave rasteriser, then the env's
-// finalisation) for as long as there are any, then leave.  "Any" is judged from one copy of the tallies: work exists
-// while reserved > claimed; nothing more can come once every mover wave has reported (done == n_movers) -- `done` is read
-// BEFORE `reserved` (a mover reports only after its reservations were acknowledged on every copy, so `reserved` is then
-// final) and `claimed` after it.
-template <bool WIDE, bool PLAIN>
-__device__ __forceinline__ void fused_consume(const __attribute__((address_space(4))) StepArgs* ap, uint64_t step_counter)
-{
-    KernArgs a = *ap;
-    const DevParams& P = a.S->P;
-    const int lane = lane_id();
-    const int wave_id = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    StepQueue* const Q = a.queues + (int)(step_counter & 1u);
-    const unsigned long long stamp = step_counter + 1;
-    const int n_movers = 2 * a.n_producers;
-    const TallyLine* const tally = &Q->tally[wave_id % kReplicas];
-    const int home = wave_id % kQShards;
-    const double vqx = lane < P.n_verts ? P.qverts[lane][0] : 0.0, vqy = lane < P.n_verts ? P.qverts[lane][1] : 0.0;
-    for (;;) {
-        // ---- find work (wave-uniform): a claimable slot, or the certainty that there will be none
-        int c_shard = -1, c_slot = 0;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (unsigned spins = 0; c_shard < 0; ++spins) {
-            const int done = uniform_ld(&tally->done);          // (in this order: see above)
-            const int reserved = uniform_ld(&tally->reserved);
-            const int claimed = uniform_ld(&tally->claimed);
-            if (reserved > claimed) {
-                for (int o = 0; o < kQShards && c_shard < 0; ++o) {
-                    const int sh = (home + o) % kQShards;
-                    int h = uniform_ld(&Q->head[sh].v);
-                    while (h < uniform_ld(&Q->reserve[sh].v)) {
-                        int old = 0;
-                        if (lane == 0) old = atomicCAS(&Q->head[sh].v, h, h + 1);
-                        old = __builtin_amdgcn_readfirstlane(old);
-                        if (old == h) {
-                            c_shard = sh;
-                            c_slot = h;
-                            break;
-                        }
-                        h = old;
-                    }
-                }
-                if (c_shard >= 0) break;
-                if (spins > kWatchdogSpins) {
-                    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 5), 1ull);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);    // (somebody else took it: its tally update is on the way)
-            } else if (done >= n_movers) {
-                break;                          // every slot ever reserved has been claimed
-            } else if (__builtin_amdgcn_s_memrealtime() - t0 > kWatchdogTicks || spins > kWatchdogSpins) {
-                if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 6), 1ull);
-                break;
-            } else {
-                __builtin_amdgcn_s_sleep(32);   // movers are still stepping
+    // (2) mover: the robot model (_env_step, envs/base/env.py:442-461); the pose the reward provider will see goes to the scorer
+    Robot& r = q.r;
+    if (mover) {
+        q.old = r.p;
+        q.drawn = 0;
+        q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
+        const bool delayed = !PLAIN && P.pose_delay > 0 && q.iter + 1 > 1;
+        hand_pose[lane] = delayed ? q.popped_pose[0] : r.p.x;
+        hand_pose[kBlock + lane] = delayed ? q.popped_pose[1] : r.p.y;
+        hand_pose[2 * kBlock + lane] = delayed ? q.popped_pose[2] : r.p.th;
+    }
+    __syncthreads();
+    bool hit = false, park = false;
+    if (mover) {
+        // (3a) collision: distance-field classification; an undecided env is parked below
+        const int64_t g = slot_of(a.S, i, q);
+        double ox = a.S->map.ox, oy = a.S->map.oy;
+        if (a.S->map.origins) {
+            ox = a.S->map.origins[2 * g + 0];
+            oy = a.S->map.origins[2 * g + 1];
+        }
+        const int px = (int)rint((r.p.x - ox) * a.S->map.inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
+        const int py = (int)rint((r.p.y - oy) * a.S->map.inv_res);
+        const double c = cos(r.p.th), s = sin(r.p.th);
+        const int64_t map_env = a.S->map.shared ? 0 : g;
+        OuterLookups look;
+        look.off_map = true;
+        if (!(a.flags & (kAblateNoCollision | kAblateNoClassify)))
+            look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
+        const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
+        if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
+            park = true;
+            q.c = c;
+            q.s = s;
+            q.px = px;
+            q.py = py;
+            q.env_lo = (int32_t)(uint32_t)i;
+            q.env_hi = (int32_t)(i >> 32);
+        }
+    } else if (scorer && !(a.flags & kAblateNoReward)) {
+        // (3b) scorer: the reward provider for the pose as it stands if nothing collides
+        const double x = hand_pose[lane], y = hand_pose[kBlock + lane], th = hand_pose[2 * kBlock + lane];
+        const int64_t g = slot_of(a.S, i, q);
+        PathWindow win;
+        if (a.S->path.shared)
+            win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
+        else
+            win = path_window(P, box, a.S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+        const int m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
+        double min_dist = q.min_dist;
+        int target = q.target;
+        double rew;
+        const double* gpath = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
+        if (!PLAIN && P.reward_provider == BCP_REWARD_PURE_PURSUIT) {
+            if (lds_path) rew = reward_pure_pursuit(lds_path, m, x, y, q.collided != 0, min_dist, target);
+            else rew = reward_pure_pursuit(gpath, m, x, y, q.collided != 0, min_dist, target);
+        } else if (lds_path) {
+            rew = reward_step(P, lds_path, win, m, x, y, th, min_dist, target);
+        } else {
+            rew = reward_step(P, gpath, win, m, x, y, th, min_dist, target);
+        }
+        hand_score[lane] = rew;
+        hand_score[kBlock + lane] = min_dist;
+        hand_score[2 * kBlock + lane] = (double)target;
+    }
+    __syncthreads();
+    ScoredFree sc;
+    sc.rew = 0.0;
+    sc.min_dist = 0.0;
+    sc.target = 0;
+    if (mover) {
+        sc.rew = hand_score[lane];
+        sc.min_dist = hand_score[kBlock + lane];
+        sc.target = (int)hand_score[2 * kBlock + lane];
+        // (4) park the undecided envs in LDS: one LDS atomic per wave hands out the slots
+        const uint64_t parking = __ballot(park);
+        if (parking) {
+            const int first = (int)__ffsll((unsigned long long)parking) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd((int*)&ctl[0], (int)__popcll(parking));
+            base = bcast_i(base, first);
+            if (park) {
+                __attribute__((address_space(3))) ParkedLocal* e = rec + base + (int)__popcll(parking & ((1ull << lane) - 1ull));
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass has no copy operators for address-space-qualified structs)
+                e->q = q;
+                e->sc = sc;
+#else
+                (void)e;
+#endif
             }
         }
-        if (c_shard < 0) break;
-        if (lane < kReplicas) atomicAdd(&Q->tally[lane].claimed, 1);
-        const Parked* e = a.parked + (int64_t)c_shard * a.parked_cap + c_slot;
-        wait_ready(e, stamp, a.tick);
-        const double c = ld_sc1(&e->q.c), s = ld_sc1(&e->q.s);
-        const int px = ld_sc1(&e->q.px), py = ld_sc1(&e->q.py);
-        const int64_t g = a.hot.map_shared ? 0
-                          : (a.hot.geom_of_env ? (int64_t)ld_sc1(&e->q.geom)
-                                               : (((int64_t)ld_sc1(&e->q.env_hi) << 32) | (uint32_t)ld_sc1(&e->q.env_lo)));
+    }
+    __syncthreads();
+    const int n_parked = __builtin_amdgcn_readfirstlane(ctl[0]);   // (scalar: the ticket loop below must stay wave-uniform)
+    // (5) movers finish their decided envs; every wave then settles parked poses, a ticket at a time
+    if (mover && active && !park)
+        finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &sc);
+    const double vqx = lane < P.n_verts ? qv[2 * lane] : 0.0, vqy = lane < P.n_verts ? qv[2 * lane + 1] : 0.0;
+    // (Control flow: ONE single-lane region per iteration -- lane 0 finishes the env and draws the next ticket in the same
+    //  block -- and a scalar loop condition.  With the draw at the top of the body, i.e. two `if (lane == 0)` regions per
+    //  trip, hipcc 7.2 threaded lane 0's path across the back edge and split the loop in two; lanes 1..63 then span in the
+    //  inner one on ticket 0 for ever while lane 0 waited outside it.)
+    int ticket = 0;
+    if (lane == 0) ticket = atomicAdd((int*)&ctl[1], 1);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    while (ticket < n_parked) {
+        const __attribute__((address_space(3))) ParkedLocal* e = rec + ticket;
+        const double c = e->q.c, s = e->q.s;
+        const int px = e->q.px, py = e->q.py;
+        const int64_t env = ((int64_t)e->q.env_hi << 32) | (uint32_t)e->q.env_lo;
+        const int64_t g = a.hot.map_shared ? 0 : (a.hot.geom_of_env ? (int64_t)e->q.geom : env);
         const uint32_t* words = a.hot.map_bits + g * a.hot.map_env_stride;
-        bool hit = false;
+        bool h = false;
         if (!(a.flags & kAblateNoCoop))
-            hit = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr);
-        if (lane == 0) finish_parked<PLAIN>(step_out_of(a), e, hit);
+            h = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr);
+        int next = 0;
+        if (lane == 0) {
+            Pending pq;
+            ScoredFree psc;
+#if defined(__HIP_DEVICE_COMPILE__)
+            pq = e->q;
+            psc = e->sc;
+#endif
+            finalize_env<PLAIN>(a, env, pq, h, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &psc);
+            next = atomicAdd((int*)&ctl[1], 1);
+        }
+        ticket = __builtin_amdgcn_readfirstlane(next);
     }
-}
-
-template <bool WIDE, bool PLAIN>
-__global__ void __launch_bounds__(4 * kBlock, 2) step_fused_kernel(const StepArgs a)
-{
-    const __attribute__((address_space(4))) StepArgs* ap =
-        (const __attribute__((address_space(4))) StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    // the step counter and the noise seed live on the device (StepArgs::tick)
-    const uint64_t step_counter = a.tick[0], seed = a.tick[2];
-    const int par = (int)(step_counter & 1u);
-    if (blockIdx.x == 0) {
-        // arm the counters of the NEXT step (the two copies alternate; nobody touches that copy during this step)
-        for (int k = threadIdx.x; k < (int)(sizeof(StepQueue) / sizeof(int32_t)); k += 4 * kBlock)
-            reinterpret_cast<int32_t*>(a.queues + (par ^ 1))[k] = 0;
-    }
-    fused_produce<WIDE, PLAIN>(ap, step_counter, seed);
-    fused_consume<WIDE, PLAIN>(ap, step_counter);
-    if ((a.flags & kStepAdvances) && threadIdx.x == 0) {   // the last workgroup to get here moves the step counter on
+    if ((a.flags & kStepAdvances) && tid == 0) {   // the last workgroup to get here moves the step counter on
         unsigned int* ticket = reinterpret_cast<unsigned int*>(a.tick + 3);
         if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
             *ticket = 0u;

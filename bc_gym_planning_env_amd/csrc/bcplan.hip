@@ -103,11 +103,8 @@ struct bcp_handle {
     bool ring_planned, ring_refreshed;   // plan -> refresh -> release, in that order
     int32_t edt_in_lds;       // distance transform of maps that fit: the LDS-resident kernel (BCP_TUNE_EDT_LDS)
     int32_t last_step_form;   // 0 none yet, 1 single-kernel step, 2 two-kernel step (parking counters in use)
-    int32_t fused;            // settle parked poses inside the step launch (step_fused_kernel) instead of a second launch
-    StepQueue* queues;        // owned: [2] queue counters of the single-launch step, alternating by step parity
-    Parked* parked;           // owned: [kQShards][parked_cap]
-    int32_t parked_cap;
-    int32_t fused_grid[4];    // resident workgroups of step_fused_kernel per variant (0 = not asked yet)
+    int32_t fused;            // settle parked poses inside the step launch (step_local_kernel) instead of a second launch
+    int32_t local_lds_set[4]; // step_local_kernel variant has been given its dynamic LDS size (-> that size)
 };
 
 // number of entries of a non-shared map / path / initial-state array
@@ -888,7 +885,7 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->fused = 1;
     h->static_dirty = true;
     fill_dev_params(h);
-    if (hipMalloc((void**)&h->tick, 8 * sizeof(uint64_t)) != hipSuccess || hipMemset(h->tick, 0, 8 * sizeof(uint64_t)) != hipSuccess) {
+    if (hipMalloc((void**)&h->tick, 4 * sizeof(uint64_t)) != hipSuccess || hipMemset(h->tick, 0, 4 * sizeof(uint64_t)) != hipSuccess) {
         if (h->tick) (void)hipFree(h->tick);
         delete h;
         return fail(BCP_E_HIP, "bcp_create: cannot allocate device memory");
@@ -911,8 +908,6 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->tick) (void)hipFree(h->tick);
     if (h->pending_count) (void)hipFree(h->pending_count);
     if (h->adapt) (void)hipFree(h->adapt);
-    if (h->queues) (void)hipFree(h->queues);
-    if (h->parked) (void)hipFree(h->parked);
     if (h->dev_static) (void)hipFree(h->dev_static);
     if (h->ego_bins) (void)hipFree(h->ego_bins);
     if (h->ego_order) (void)hipFree(h->ego_order);
@@ -932,8 +927,6 @@ extern "C" int bcp_seed(bcp_handle* h, uint64_t seed)
     const uint64_t tick[4] = {0, 0, seed, 0};
     HIP_TRY(hipMemcpy(h->tick, tick, sizeof(tick), hipMemcpyHostToDevice));
     if (h->pending_count) HIP_TRY(hipMemset(h->pending_count, 0, 2 * kShards * sizeof(int32_t)));
-    if (h->queues) HIP_TRY(hipMemset(h->queues, 0, 2 * sizeof(StepQueue)));
-    if (h->parked) HIP_TRY(hipMemset(h->parked, 0, (size_t)kQShards * h->parked_cap * sizeof(Parked)));   // the `ready` stamps
     if (h->adapt) {
         HIP_TRY(hipMemset(h->adapt, 0, (2 + 2 * kShards) * sizeof(int32_t)));
         const int32_t init[2] = {h->dense_threshold, h->dense_threshold};
@@ -1123,15 +1116,6 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
             const int32_t init[2] = {h->dense_threshold, h->dense_threshold};
             HIP_TRY(hipMemcpyAsync(h->adapt, init, sizeof(init), hipMemcpyHostToDevice, s));
             HIP_TRY(hipStreamSynchronize(s));   // (`init` is on the stack)
-        }
-        if (!h->parked) {
-            // single-launch step: every env of a shard's 128-env blocks may be parked at once
-            const int64_t blocks128 = (h->n + 2 * kBlock - 1) / (2 * kBlock);
-            h->parked_cap = (int32_t)(((blocks128 + kQShards - 1) / kQShards) * 2 * kBlock);
-            HIP_TRY(hipMalloc((void**)&h->parked, (size_t)kQShards * h->parked_cap * sizeof(Parked)));
-            HIP_TRY(hipMemsetAsync(h->parked, 0, (size_t)kQShards * h->parked_cap * sizeof(Parked), s));
-            HIP_TRY(hipMalloc((void**)&h->queues, 2 * sizeof(StepQueue)));
-            HIP_TRY(hipMemsetAsync(h->queues, 0, 2 * sizeof(StepQueue), s));
         }
     }
     h->have_map = true;
@@ -1323,14 +1307,13 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     }
     const StepStatic& S = h->host_static;
     // (an explicit BCP_TUNE_DENSE_THRESHOLD asks for poses to be settled inside the stepping wave: the two-launch form has that path)
-    const bool fused = S.pending && h->fused && h->parked && h->adaptive;
+    const bool fused = S.pending && h->fused && h->adaptive;
     const int32_t form = fused ? 3 : (S.pending ? 2 : 1);
     if (form != h->last_step_form) {
         if (form == 2 && h->last_step_form != 0) {
             const int rc = rearm_parking(h, s);
             if (rc != BCP_OK) return rc;
         }
-        if (form == 3 && h->last_step_form != 0) HIP_TRY(hipMemsetAsync(h->queues, 0, 2 * sizeof(StepQueue), s));
         h->last_step_form = form;
     }
     StepArgs a;
@@ -1370,39 +1353,27 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     a.tick = h->tick;
     a.pending_base = h->pending_count;
     a.adapt_base = adapt ? h->adapt : nullptr;
-    a.queues = h->queues;
-    a.parked = h->parked;
-    a.parked_cap = h->parked_cap;
-    a.n_producers = 0;
     const int blocks = (int)((h->n + kBlock - 1) / kBlock);
     if (fused) {
-        // the whole step as one launch: workgroups step 128 envs each, then -- together with the grid's extra
-        // workgroups -- settle the parked poses (step_fused_kernel)
+        // the whole step as one launch: 256 envs per workgroup of 16 waves; undecided poses are handed over in LDS and
+        // settled by all the workgroup's waves (step_local_kernel)
         const int variant = (S.wide ? 2 : 0) | (step_is_plain(h) ? 1 : 0);
-        const void* fn = variant == 3 ? (const void*)step_fused_kernel<true, true>
-                       : variant == 2 ? (const void*)step_fused_kernel<true, false>
-                       : variant == 1 ? (const void*)step_fused_kernel<false, true>
-                                      : (const void*)step_fused_kernel<false, false>;
-        const size_t lds = ((size_t)h->params.n_verts * 2 + S.lds_path_doubles + 12 * kBlock + 8) * sizeof(double) +
-                           2 * kBlock * sizeof(uint32_t);
-        if (!h->fused_grid[variant]) {
-            int per_cu = 0, cus = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 4 * kBlock, lds));
-            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-            h->fused_grid[variant] = std::max(per_cu, 1) * std::max(cus, 1);
+        const void* fn = variant == 3 ? (const void*)step_local_kernel<true, true>
+                       : variant == 2 ? (const void*)step_local_kernel<true, false>
+                       : variant == 1 ? (const void*)step_local_kernel<false, true>
+                                      : (const void*)step_local_kernel<false, false>;
+        const size_t lds = local_step_lds_bytes(h->params.n_verts, S.lds_path_doubles);
+        if (h->local_lds_set[variant] != (int32_t)lds) {
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            h->local_lds_set[variant] = (int32_t)lds;
         }
-        // every workgroup steps envs (128 per round) and then helps settling parked poses: nobody waits for a workgroup
-        // that has not started, so the grid may exceed what is resident -- it is capped there only to keep the
-        // consumers' totals (n_producers) small
-        const int64_t blocks128 = (h->n + 2 * kBlock - 1) / (2 * kBlock);
-        a.n_producers = (int32_t)std::min<int64_t>(blocks128, h->fused_grid[variant]);
         a.flags |= kStepAdvances;
-        const dim3 grid((unsigned)a.n_producers), block(4 * kBlock);
+        const dim3 grid((unsigned)((h->n + kLocalEnvs - 1) / kLocalEnvs)), block(kLocalWaves * kBlock);
         switch (variant) {
-            case 3: hipLaunchKernelGGL((step_fused_kernel<true, true>), grid, block, lds, s, a); break;
-            case 2: hipLaunchKernelGGL((step_fused_kernel<true, false>), grid, block, lds, s, a); break;
-            case 1: hipLaunchKernelGGL((step_fused_kernel<false, true>), grid, block, lds, s, a); break;
-            default: hipLaunchKernelGGL((step_fused_kernel<false, false>), grid, block, lds, s, a); break;
+            case 3: hipLaunchKernelGGL((step_local_kernel<true, true>), grid, block, lds, s, a); break;
+            case 2: hipLaunchKernelGGL((step_local_kernel<true, false>), grid, block, lds, s, a); break;
+            case 1: hipLaunchKernelGGL((step_local_kernel<false, true>), grid, block, lds, s, a); break;
+            default: hipLaunchKernelGGL((step_local_kernel<false, false>), grid, block, lds, s, a); break;
         }
     } else if (S.pending) {
         // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest
@@ -1473,47 +1444,13 @@ extern "C" int bcp_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, vo
     return BCP_OK;
 }
 
-extern "C" int bcp_step_health(bcp_handle* h, uint64_t* watchdog_events)
-{
-    if (!h || !watchdog_events) return fail(BCP_E_INVALID, "bcp_step_health: null argument");
-    HIP_TRY(hipSetDevice(h->device));
-    uint64_t ev[3] = {0, 0, 0};   // a record's stamp / a claim that never came / the movers' done count
-    HIP_TRY(hipMemcpy(ev, h->tick + 4, sizeof(ev), hipMemcpyDeviceToHost));
-    *watchdog_events = ev[0] + ev[1] + ev[2];
-    if (*watchdog_events) fail(BCP_OK, "watchdog: %llu stamp waits, %llu claim waits, %llu done waits",
-                               (unsigned long long)ev[0], (unsigned long long)ev[1], (unsigned long long)ev[2]);
-    return BCP_OK;
-}
-
-extern "C" int bcp_step_queues(bcp_handle* h, int32_t* out)
-{
-    if (!h || !out) return fail(BCP_E_INVALID, "bcp_step_queues: null argument");
-    if (!h->queues) return fail(BCP_E_STATE, "bcp_step_queues: the single-launch step has not been set up");
-    HIP_TRY(hipSetDevice(h->device));
-    StepQueue q[2];
-    HIP_TRY(hipMemcpy(q, h->queues, sizeof(q), hipMemcpyDeviceToHost));
-    for (int p = 0; p < 2; ++p) {
-        int32_t* o = out + p * (2 * kQShards + 3 * kReplicas);
-        for (int k = 0; k < kQShards; ++k) {
-            o[k] = q[p].reserve[k].v;
-            o[kQShards + k] = q[p].head[k].v;
-        }
-        for (int k = 0; k < kReplicas; ++k) {
-            o[2 * kQShards + 3 * k + 0] = q[p].tally[k].reserved;
-            o[2 * kQShards + 3 * k + 1] = q[p].tally[k].claimed;
-            o[2 * kQShards + 3 * k + 2] = q[p].tally[k].done;
-        }
-    }
-    return BCP_OK;
-}
-
 extern "C" int bcp_step_form(bcp_handle* h)
 {
     if (!h) return fail(BCP_E_INVALID, "bcp_step_form: null handle");
     if (!h->have_map || !h->have_path || !h->have_state) return fail(BCP_E_STATE, "bcp_step_form: costmaps, paths and state must be set first");
     if (!step_uses_deferral(h)) return 0;
     if (h->dense_threshold < 0) return 1;
-    return (h->fused && h->parked && h->adaptive) ? 3 : 2;
+    return (h->fused && h->adaptive) ? 3 : 2;
 }
 
 extern "C" int bcp_time_steps(bcp_handle* h, const bcp_step_io* io, uint32_t flags, int32_t steps, void* stream,

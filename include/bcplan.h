@@ -156,7 +156,7 @@ int bcp_seed(bcp_handle *h, uint64_t seed);
  *   BCP_TUNE_EDT_LDS          0 = build distance fields with the two-pass global-memory kernels even where a map fits
  *                             into LDS (takes effect at the next bcp_set_costmaps)
  *   BCP_TUNE_FUSED            0 = settle the parked poses in a second launch (step_fast_pair_kernel + step_pending_kernel)
- *                             instead of inside the step launch itself (step_fused_kernel, the default) */
+ *                             instead of inside the step launch itself (step_local_kernel, the default) */
 enum { BCP_TUNE_EXACT_MODE = 0, BCP_TUNE_DENSE_THRESHOLD = 1, BCP_TUNE_CULL = 2, BCP_TUNE_DEFER = 3, BCP_TUNE_EDT_LDS = 4,
        BCP_TUNE_FUSED = 5 };
 int bcp_set_tuning(bcp_handle *h, int32_t key, int32_t value);
@@ -352,18 +352,9 @@ int bcp_device_normals(bcp_handle *h, int64_t first_env, int64_t n_envs, uint64_
                        void *stream);
 
 /* ---- measurement -------------------------------------------------------------------------------------- */
-/* Health of the single-launch step (synchronises): the number of times one of its in-kernel waits -- for a parked record's
- * stamp, for the producers' done count -- hit its 2 s watchdog since bcp_create.  0 on a healthy device; anything else
- * means steps ended with parked envs left unfinished. */
-int bcp_step_health(bcp_handle *h, uint64_t *watchdog_events /*host*/);
-/* Introspection of the single-launch step's queues (synchronises; tests and debugging): out, host int32 [2][8 + 8 + 32 * 3],
- * receives for both step parities the slots reserved and the slots claimed per shard (8 + 8) and the 32 copies of the
- * totals {reserved, claimed, mover waves done}.  After a step all copies of a parity agree, reserved == claimed == the
- * number of poses the step parked, and done == twice the number of stepping workgroups. */
-int bcp_step_queues(bcp_handle *h, int32_t *out /*host*/);
 /* Which kernels a bcp_step() of this handle launches, as configured now: 0 = step_kernel alone (no distance field, or a
  * forced mode), 1 = step_fast_pair_kernel alone (every undecided pose settled in place), 2 = step_fast_pair_kernel +
- * step_pending_kernel, 3 = step_fused_kernel (one launch).  Negative: BCP_E_*. */
+ * step_pending_kernel, 3 = step_local_kernel (one launch).  Negative: BCP_E_*. */
 int bcp_step_form(bcp_handle *h);
 /* Runs `steps` bcp_step() launches back to back on `stream` bracketed by HIP events recorded on that stream and
  * returns the average kernel-launch duration in milliseconds (synchronises).  Used by bench.py for
