@@ -396,4 +396,138 @@ __device__ __forceinline__ bool coop_collides_quad(const DevParams& P, double qx
     return coop_raster<NW, 2>(P, qx, qy, c, s, sink, wave >> 1, 2, wave & 1, xch, wave);
 }
 
+// ---- the exact test, cell by cell ------------------------------------------------------------------------------------
+// coop_raster builds the coverage of EVERY row of the footprint image (lane = row, a loop over the edges with ~90
+// vector operations per edge and 64-row chunk) and then looks whether a lethal cell lies under it.  On the maps this
+// path meets -- walls one cell thick -- the image holds ~1500 cells and the map only a few dozen lethal ones beneath its
+// bounding box, so this form turns the question round: the lethal cells under the bounding box are listed (lane = row:
+// the row's lethal bits, a wave-wide prefix sum, the set bits written to a list in LDS), a lane takes a cell, and the
+// loop over the edges asks of that ONE pixel what cv2.fillPoly's raster holds there:
+//     outline: the pixel lies on the run of edge e on its row          (same run arithmetic as coop_raster)
+//     span   : an odd number of active edges cross its row to its left (x > floor(x_e): the parity form, see above)
+// ~25 vector operations per edge, one pass for up to 64 cells whatever the image height.  Same verdict as coop_raster,
+// pixel for pixel; `list` is kSparseCap words of LDS owned by the calling wave.  A chunk of rows holding more than
+// kSparseCap lethal cells (filled obstacles) makes the function return kSparseTooMany: the caller then rasterises.
+constexpr int kSparseCap = 256;
+enum { kSparseFree = 0, kSparseHit = 1, kSparseTooMany = 2 };
+
+template <bool WIDE, typename WordPtr>
+__device__ __forceinline__ int coop_collides_sparse(const DevParams& P, double qx, double qy, double c, double s, int px,
+                                                    int py, WordPtr words, int rows, int cols, int wpr, LdsU32 list)
+{
+    constexpr int NW = WIDE ? 8 : 3;
+    const int K = P.n_verts;
+    const int lane = lane_id();
+    // ---- lane k < K owns vertex k and edge k (as in coop_raster)
+    int u = 0, v = 0;
+    if (lane < K) {
+        u = (int)rint(fma(qy, -s, qx * c));   // path_tools.py:142-150
+        v = (int)rint(fma(qy, c, qx * s));
+    }
+    const int prev = lane == 0 ? K - 1 : lane - 1;
+    const int up = __shfl(u, prev), vp = __shfl(v, prev);
+    const bool owner = lane < K;
+    int vmin = 0x7fffffff, vmax = -0x7fffffff, umin = 0x7fffffff, umax = -0x7fffffff;
+    for (int k = 0; k < K; ++k) {
+        const int uk = bcast_i(u, k), vk = bcast_i(v, k);
+        vmin = min(vmin, vk);
+        vmax = max(vmax, vk);
+        umin = min(umin, uk);
+        umax = max(umax, uk);
+    }
+    EdgeRegs E;
+    {
+        const int ddy = v - vp;
+        E.y0 = min(v, vp);
+        E.y1 = owner ? max(v, vp) : E.y0;
+        E.x0fp = (vp < v ? up : u) << 16;
+        E.dxfp = ddy != 0 ? ((u - up) * 65536) / ddy : 0;
+        int sx = up, sy = vp, dx = u - up, dy = v - vp;
+        if (dx < 0) {
+            dx = -dx;
+            dy = -dy;
+            sx = u;
+            sy = v;
+        }
+        E.ystep = 1;
+        if (dy < 0) {
+            dy = -dy;
+            E.ystep = -1;
+        }
+        E.sx = sx;
+        E.sy = sy;
+        E.dx = dx;
+        E.dy = owner ? dy : -1;
+        const uint32_t D = 2u * (uint32_t)(dy > 0 ? dy : 1);
+        E.inv = (uint32_t)(4294967296.0 / (double)D) + 1u;
+    }
+    CoopCollisionSink<NW, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
+    sink.extent(umin, umax);
+    const int n_chunks = (vmax - vmin) / 64 + 1;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        // ---- the lethal cells of this chunk's rows under the image's columns (lane = row)
+        const int y_row = vmin + 64 * chunk + lane;
+        if (!sink.chunk_matters(y_row, y_row <= vmax)) continue;   // (loads the lane's row; wave-uniform result)
+        int count = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) count += (int)__popc(sink.leth[w]);
+        int incl = count;   // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        const int total = bcast_i(incl, 63);
+        if (total > kSparseCap) return kSparseTooMany;
+        int at = incl - count;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            uint32_t bits = sink.leth[w];
+            while (bits) {
+                const int b = (int)__builtin_ctz(bits);
+                bits &= bits - 1;
+                list[at++] = ((uint32_t)(64 * chunk + lane) << 16) | (uint32_t)(32 * w + b);   // (row - vmin, column - umin)
+            }
+        }
+        wave_lds_sync();
+        // ---- a lane per cell, a loop over the edges
+        for (int base = 0; base < total; base += 64) {
+            const bool valid = base + lane < total;
+            const uint32_t cell = valid ? list[base + lane] : 0u;
+            const int y = vmin + (int)(cell >> 16), x = umin + (int)(cell & 0xFFFFu);
+            bool on_outline = false;
+            int crossings = 0;
+            for (int e = 0; e < K; ++e) {
+                const int ey0 = bcast_i(E.y0, e), ey1 = bcast_i(E.y1, e);
+                if (y >= ey0 && y < ey1) {   // span edge active on this row: does it cross left of the pixel?
+                    const int xe = bcast_i(E.x0fp, e) + (y - ey0) * bcast_i(E.dxfp, e);
+                    crossings += (int)(x > (xe >> 16));
+                }
+                const int sy = bcast_i(E.sy, e), sx = bcast_i(E.sx, e);
+                const int dx = bcast_i(E.dx, e), dy = bcast_i(E.dy, e), ystep = bcast_i(E.ystep, e);
+                const int i = (y - sy) * ystep;
+                if (i >= 0 && i <= dy) {     // the run of this edge on the pixel's row
+                    int lo, hi;
+                    if (dy > dx) {
+                        lo = hi = sx + (int)__umulhi((uint32_t)(2 * dx * i + dy - 1), (uint32_t)bcast_i((int)E.inv, e));
+                    } else if (dy == 0) {
+                        lo = sx;
+                        hi = sx + dx;
+                    } else {
+                        const uint32_t inv = (uint32_t)bcast_i((int)E.inv, e);
+                        const int qhi = (int)__umulhi((uint32_t)(2 * dx * i + dx), inv);
+                        const int qlo = i == 0 ? -1 : (int)__umulhi((uint32_t)(2 * dx * (i - 1) + dx), inv);
+                        lo = sx + qlo + 1;
+                        hi = sx + (qhi > dx ? dx : qhi);
+                    }
+                    on_outline |= x >= lo && x <= hi;
+                }
+            }
+            if (__any(valid && (on_outline || (crossings & 1)))) return kSparseHit;
+        }
+        wave_lds_sync();   // the list is rewritten for the next chunk
+    }
+    return kSparseFree;
+}
+
 }  // namespace bcp

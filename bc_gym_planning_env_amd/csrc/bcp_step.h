@@ -490,6 +490,7 @@ struct CollisionLds {
     LdsWords bits;
     LdsF64 qverts;
     VertLds scratch;
+    LdsU32 cells;     // kSparseCap words: the cell list of coop_collides_sparse (exact mode 3)
 };
 
 __device__ __forceinline__ CollisionLds collision_lds_setup(const DevParams& P, const MapDesc& map, int tid)
@@ -506,6 +507,7 @@ __device__ __forceinline__ CollisionLds collision_lds_setup(const DevParams& P, 
     L.qverts = q;
     L.scratch.base = lds + q_off + 4 * P.n_verts + tid;
     L.scratch.stride = kBlock;
+    L.cells = lds + q_off + 4 * P.n_verts + 2 * P.n_verts * kBlock;
     __syncthreads();
     return L;
 }
@@ -516,6 +518,7 @@ static size_t collision_lds_bytes(int n_verts, int in_lds, int rows, int wpr)
     words = (words + 1) & ~(size_t)1;
     words += 4 * (size_t)n_verts;            // qverts (doubles)
     words += 2 * (size_t)n_verts * kBlock;   // per-thread vertex scratch
+    words += kSparseCap;                     // cell list of the cell-by-cell exact test
     return words * sizeof(uint32_t);
 }
 
@@ -537,7 +540,7 @@ __device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc&
     bool hit = cls == kHit;
     uint64_t amb = __ballot(cls == kAmbiguous);
     if (amb == 0) return hit;
-    const bool dense = exact_mode == 2 || (exact_mode == 0 && (int)__popcll(amb) > dense_threshold);
+    const bool dense = exact_mode == 2 || (exact_mode == 0 && (int)__popcll(amb) > dense_threshold);   // (modes 1 and 3: cooperative)
     if (dense) {
         // many undecided lanes: one per-thread rasteriser pass settles them all at once
         if (cls == kAmbiguous) {
@@ -561,11 +564,22 @@ __device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc&
         const double c_ = bcast_d(c, src), s_ = bcast_d(s, src);
         const int px_ = bcast_i(px, src), py_ = bcast_i(py, src);
         bool h;
-        if (L.staged) {
+        const int64_t env_ = ((int64_t)bcast_i((int)(env >> 32), src) << 32) | (uint32_t)bcast_i((int)env, src);
+        const uint32_t* words = map.bits + (map.shared ? 0 : env_ * map.env_stride);
+        int verdict = kSparseTooMany;
+        if (exact_mode == 3) {   // the cell-by-cell form of the exact test (what step_local_kernel uses)
+            if (L.staged)
+                verdict = wide ? coop_collides_sparse<true>(P, vqx, vqy, c_, s_, px_, py_, L.bits, map.rows, map.cols, map.wpr, L.cells)
+                               : coop_collides_sparse<false>(P, vqx, vqy, c_, s_, px_, py_, L.bits, map.rows, map.cols, map.wpr, L.cells);
+            else
+                verdict = wide ? coop_collides_sparse<true>(P, vqx, vqy, c_, s_, px_, py_, words, map.rows, map.cols, map.wpr, L.cells)
+                               : coop_collides_sparse<false>(P, vqx, vqy, c_, s_, px_, py_, words, map.rows, map.cols, map.wpr, L.cells);
+        }
+        if (verdict != kSparseTooMany) {
+            h = verdict == kSparseHit;
+        } else if (L.staged) {
             h = coop_collides(P, vqx, vqy, c_, s_, px_, py_, L.bits, map.rows, map.cols, map.wpr, wide);
         } else {
-            const int64_t env_ = ((int64_t)bcast_i((int)(env >> 32), src) << 32) | (uint32_t)bcast_i((int)env, src);
-            const uint32_t* words = map.bits + (map.shared ? 0 : env_ * map.env_stride);
             h = coop_collides(P, vqx, vqy, c_, s_, px_, py_, words, map.rows, map.cols, map.wpr, wide);
         }
         if (lane_id() == src) hit = h;
@@ -1122,7 +1136,8 @@ static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles)
     bytes += 2 * kBlock * sizeof(uint32_t);          // bucket index of the shared path
     bytes += 4 * sizeof(int32_t);                    // parked count, ticket counter
     bytes = (bytes + 15) & ~(size_t)15;
-    return bytes + (size_t)kLocalEnvs * sizeof(ParkedLocal);
+    bytes += (size_t)kLocalEnvs * sizeof(ParkedLocal);
+    return bytes + (size_t)kLocalWaves * kSparseCap * sizeof(uint32_t);   // a cell list per wave (coop_collides_sparse)
 }
 
 template <bool WIDE, bool PLAIN>
@@ -1149,6 +1164,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
                                           2 * kBlock * sizeof(uint32_t) + 4 * sizeof(int32_t)) + 15) & ~(size_t)15);
     __attribute__((address_space(3))) ParkedLocal* rec =
         (__attribute__((address_space(3))) ParkedLocal*)((__attribute__((address_space(3))) char*)lds_dyn + rec_off);
+    const LdsU32 cell_list = (LdsU32)(rec + kLocalEnvs) + wave * kSparseCap;
 
     // staging: footprint vertices, the shared path with its bounding box and bucket index, the counters
     if (tid < nq) qv[tid] = P.qverts[tid >> 1][tid & 1];
@@ -1293,8 +1309,14 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         const int64_t g = a.hot.map_shared ? 0 : (a.hot.geom_of_env ? (int64_t)e->q.geom : env);
         const uint32_t* words = a.hot.map_bits + g * a.hot.map_env_stride;
         bool h = false;
-        if (!(a.flags & kAblateNoCoop))
-            h = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr);
+        if (!(a.flags & kAblateNoCoop)) {
+            // the lethal cells under the image tested one by one; a map too dense for that is rasterised row by row
+            const int verdict = coop_collides_sparse<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols,
+                                                           a.hot.map_wpr, cell_list);
+            h = verdict == kSparseHit;
+            if (verdict == kSparseTooMany)
+                h = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr);
+        }
         int next = 0;
         if (lane == 0) {
             Pending pq;

@@ -80,7 +80,7 @@ struct bcp_handle {
     int32_t* pending_count;   // owned: two alternating sets of kShards counters
     int32_t pending_cap;      // parking slots per shard
     int32_t defer;            // settle undecided envs in a second kernel (shared map with distance field)
-    int32_t exact_mode;       // 0 auto, 1 cooperative only, 2 per-thread only
+    int32_t exact_mode;       // 0 auto, 1 cooperative only, 2 per-thread only, 3 cooperative cell by cell
     int32_t dense_threshold;  // auto: more ambiguous lanes than this in a wave -> per-thread rasteriser
     int32_t adaptive;         // the threshold above is only the fallback: kernel 2 re-decides every step
     int32_t* adapt;           // owned: [2] thresholds + [2] in-place counters, alternating by step parity
@@ -957,7 +957,7 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
     h->static_dirty = true;
     switch (key) {
         case BCP_TUNE_EXACT_MODE:
-            if (value < 0 || value > 2) return fail(BCP_E_INVALID, "bcp_set_tuning: exact mode must be 0, 1 or 2");
+            if (value < 0 || value > 3) return fail(BCP_E_INVALID, "bcp_set_tuning: exact mode must be 0, 1, 2 or 3");
             h->exact_mode = value;
             return BCP_OK;
         case BCP_TUNE_DENSE_THRESHOLD:

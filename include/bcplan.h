@@ -147,7 +147,8 @@ int bcp_destroy(bcp_handle *h);
 int bcp_seed(bcp_handle *h, uint64_t seed);
 
 /* Execution knobs; none of them changes any result (tests run every combination against the oracle).
- *   BCP_TUNE_EXACT_MODE       0 = auto, 1 = always the wave-cooperative exact rasteriser, 2 = always the per-thread one
+ *   BCP_TUNE_EXACT_MODE       0 = auto, 1 = always the wave-cooperative exact rasteriser, 2 = always the per-thread one,
+ *                             3 = wave-cooperative, cell by cell (the lethal cells under the image tested one by one)
  *   BCP_TUNE_DENSE_THRESHOLD  auto mode: more undecided poses than this in one wavefront -> settle them inside the
  *                             step kernel (cooperatively with a distance field, per thread without one)
  *   BCP_TUNE_CULL             0 = skip the distance-field pre-classification (every in-map pose is rasterised)

@@ -19,7 +19,7 @@ def global_actions(n_total, steps, seed=77):
     return a
 
 
-def make_shard(n_local, first, device, timeout=60):
+def make_shard(n_local, first, device, timeout=30):
     from util import GOLDEN
     from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
     g = np.load(os.path.join(GOLDEN, "g8_traj_mini_03.npz"))

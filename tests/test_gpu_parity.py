@@ -112,7 +112,8 @@ def test_pose_collides_vs_reference(torch_cuda, tag):
 
 
 MODES = [dict(cull=1, exact_mode=0), dict(cull=1, exact_mode=1), dict(cull=1, exact_mode=2),
-         dict(cull=0, exact_mode=1), dict(cull=0, exact_mode=2), dict(cull=1, exact_mode=0, dense_threshold=0)]
+         dict(cull=0, exact_mode=1), dict(cull=0, exact_mode=2), dict(cull=1, exact_mode=0, dense_threshold=0),
+         dict(cull=0, exact_mode=3), dict(cull=1, exact_mode=3)]
 
 
 @pytest.mark.parametrize("mode", MODES, ids=lambda m: "-".join("%s%d" % (k[:4], v) for k, v in sorted(m.items())))
@@ -274,7 +275,7 @@ def _random_batch(oracle, rng, n, g, name):
     return st, md, tgt, it
 
 
-STEP_MODES = [dict(), dict(fused=0), dict(defer=0), dict(exact_mode=1), dict(exact_mode=2), dict(cull=0, exact_mode=1),
+STEP_MODES = [dict(), dict(fused=0), dict(defer=0), dict(exact_mode=1), dict(exact_mode=2), dict(exact_mode=3), dict(cull=0, exact_mode=1),
               dict(cull=0, exact_mode=2), dict(defer=0, dense_threshold=0), dict(dense_threshold=0),
               dict(dense_threshold=64)]
 

@@ -1,7 +1,11 @@
-"""The C3 step with stages switched off (ablation flags of bcplan.hip: results are wrong by construction, only the
-timing is of interest).  HIP-event timing of 20 back-to-back steps, 5 repetitions each."""
-import sys, numpy as np, torch
+"""The C3 step with stages switched off (ablation flags of bcp_step.h: results are wrong by construction, only the
+timing is of interest).  HIP-event timing of 20 back-to-back steps, 5 repetitions each.  Needs the diagnostic build:
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -DBCP_DIAG bc_gym_planning_env_amd/csrc/bcplan.hip
+      -o tools/libbcplan_diag.so      (BCP_FUSED=0 in the environment: the two-launch step)"""
+import os, sys, numpy as np, torch
 sys.path.insert(0, '.')
+from bc_gym_planning_env_amd import _lib
+_lib.LIB_PATH = os.path.join('tools', 'libbcplan_diag.so')   # -DBCP_DIAG build: the shipping library rejects these flags
 import bench
 env, g = bench.make_env(65536, 0, 0, 1)
 rng = np.random.RandomState(0)
@@ -10,9 +14,12 @@ env.state.current_iter.copy_(torch.from_numpy(rng.randint(0, 1200, 65536).astype
 for k in range(1200):
     env.step(pool[k % 16])
 torch.cuda.synchronize()
+if os.environ.get("BCP_FUSED") is not None:
+    env.set_tuning(fused=int(os.environ["BCP_FUSED"]))
+print(env.step_kernels(), flush=True)
 st = env.get_state()
 for name, fl in [('full', 0), ('no_park', 1 << 21), ('no_classify', 1 << 22), ('no_collision', 1 << 16),
-                 ('no_reward', 1 << 17), ('neither', 3 << 16), ('k2_no_coop', 1 << 19)]:
+                 ('no_reward', 1 << 17), ('neither', 3 << 16), ('no_exact_test', 1 << 19)]:
     env.set_state(st)
     env._debug_flags = fl
     ms = [env.time_steps(pool[i % 16], 20) for i in range(5)]
