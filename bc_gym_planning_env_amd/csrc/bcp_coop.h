@@ -406,9 +406,10 @@ __device__ __forceinline__ bool coop_collides_quad(const DevParams& P, double qx
 //     outline: the pixel lies on the run of edge e on its row          (same run arithmetic as coop_raster)
 //     span   : an odd number of active edges cross its row to its left (x > floor(x_e): the parity form, see above)
 // ~25 vector operations per edge, one pass for up to 64 cells whatever the image height.  Same verdict as coop_raster,
-// pixel for pixel; `list` is kSparseCap words of LDS owned by the calling wave.  A chunk of rows holding more than
-// kSparseCap lethal cells (filled obstacles) makes the function return kSparseTooMany: the caller then rasterises.
+// pixel for pixel; `list` is kSparseLdsWords words of LDS owned by the calling wave.  More than kSparseCap lethal cells
+// under the image (filled obstacles) make the function return kSparseTooMany: the caller then rasterises.
 constexpr int kSparseCap = 256;
+constexpr int kSparseLdsWords = kSparseCap + 1;   // the list + its fill counter
 enum { kSparseFree = 0, kSparseHit = 1, kSparseTooMany = 2 };
 
 template <bool WIDE, typename WordPtr>
@@ -435,13 +436,15 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, double q
         umin = min(umin, uk);
         umax = max(umax, uk);
     }
-    EdgeRegs E;
+    // the edge of this lane, packed for broadcasting (|u|, |v| <= BCP_MAX_KERNEL_HALF + 1: 16 bits each are plenty)
+    int e_y, e_s, e_d, e_x0fp, e_dxfp;
+    uint32_t e_inv;
     {
         const int ddy = v - vp;
-        E.y0 = min(v, vp);
-        E.y1 = owner ? max(v, vp) : E.y0;
-        E.x0fp = (vp < v ? up : u) << 16;
-        E.dxfp = ddy != 0 ? ((u - up) * 65536) / ddy : 0;
+        const int y0 = min(v, vp), y1 = owner ? max(v, vp) : y0;   // span activity y0 <= y < y1
+        e_y = (y1 << 16) | (y0 & 0xFFFF);
+        e_x0fp = (vp < v ? up : u) << 16;
+        e_dxfp = ddy != 0 ? ((u - up) * 65536) / ddy : 0;
         int sx = up, sy = vp, dx = u - up, dy = v - vp;
         if (dx < 0) {
             dx = -dx;
@@ -449,83 +452,83 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, double q
             sx = u;
             sy = v;
         }
-        E.ystep = 1;
+        int down = 0;   // ystep = -1
         if (dy < 0) {
             dy = -dy;
-            E.ystep = -1;
+            down = 1;
         }
-        E.sx = sx;
-        E.sy = sy;
-        E.dx = dx;
-        E.dy = owner ? dy : -1;
+        if (!owner) dy = -1;   // inert
+        e_s = (sy << 16) | (sx & 0xFFFF);
+        e_d = (dy << 16) | (down << 15) | dx;
         const uint32_t D = 2u * (uint32_t)(dy > 0 ? dy : 1);
-        E.inv = (uint32_t)(4294967296.0 / (double)D) + 1u;
+        e_inv = (uint32_t)(4294967296.0 / (double)D) + 1u;
     }
     CoopCollisionSink<NW, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
     sink.extent(umin, umax);
+    // ---- the lethal cells under the image's columns, all row chunks into one list (lane = row of the chunk; the order
+    //      of the cells does not matter, so a lane just reserves room for its row's cells with one LDS atomic)
+    if (lane == 0) list[kSparseCap] = 0;
+    wave_lds_sync();
     const int n_chunks = (vmax - vmin) / 64 + 1;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        // ---- the lethal cells of this chunk's rows under the image's columns (lane = row)
         const int y_row = vmin + 64 * chunk + lane;
         if (!sink.chunk_matters(y_row, y_row <= vmax)) continue;   // (loads the lane's row; wave-uniform result)
         int count = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) count += (int)__popc(sink.leth[w]);
-        int incl = count;   // inclusive prefix sum over the lanes
+        if (count) {
+            int at = (int)atomicAdd((unsigned int*)&list[kSparseCap], (unsigned int)count);
+            if (at + count <= kSparseCap) {
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
-        const int total = bcast_i(incl, 63);
-        if (total > kSparseCap) return kSparseTooMany;
-        int at = incl - count;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            uint32_t bits = sink.leth[w];
-            while (bits) {
-                const int b = (int)__builtin_ctz(bits);
-                bits &= bits - 1;
-                list[at++] = ((uint32_t)(64 * chunk + lane) << 16) | (uint32_t)(32 * w + b);   // (row - vmin, column - umin)
-            }
-        }
-        wave_lds_sync();
-        // ---- a lane per cell, a loop over the edges
-        for (int base = 0; base < total; base += 64) {
-            const bool valid = base + lane < total;
-            const uint32_t cell = valid ? list[base + lane] : 0u;
-            const int y = vmin + (int)(cell >> 16), x = umin + (int)(cell & 0xFFFFu);
-            bool on_outline = false;
-            int crossings = 0;
-            for (int e = 0; e < K; ++e) {
-                const int ey0 = bcast_i(E.y0, e), ey1 = bcast_i(E.y1, e);
-                if (y >= ey0 && y < ey1) {   // span edge active on this row: does it cross left of the pixel?
-                    const int xe = bcast_i(E.x0fp, e) + (y - ey0) * bcast_i(E.dxfp, e);
-                    crossings += (int)(x > (xe >> 16));
-                }
-                const int sy = bcast_i(E.sy, e), sx = bcast_i(E.sx, e);
-                const int dx = bcast_i(E.dx, e), dy = bcast_i(E.dy, e), ystep = bcast_i(E.ystep, e);
-                const int i = (y - sy) * ystep;
-                if (i >= 0 && i <= dy) {     // the run of this edge on the pixel's row
-                    int lo, hi;
-                    if (dy > dx) {
-                        lo = hi = sx + (int)__umulhi((uint32_t)(2 * dx * i + dy - 1), (uint32_t)bcast_i((int)E.inv, e));
-                    } else if (dy == 0) {
-                        lo = sx;
-                        hi = sx + dx;
-                    } else {
-                        const uint32_t inv = (uint32_t)bcast_i((int)E.inv, e);
-                        const int qhi = (int)__umulhi((uint32_t)(2 * dx * i + dx), inv);
-                        const int qlo = i == 0 ? -1 : (int)__umulhi((uint32_t)(2 * dx * (i - 1) + dx), inv);
-                        lo = sx + qlo + 1;
-                        hi = sx + (qhi > dx ? dx : qhi);
+                for (int w = 0; w < NW; ++w) {
+                    uint32_t bits = sink.leth[w];
+                    while (bits) {
+                        const int b = (int)__builtin_ctz(bits);
+                        bits &= bits - 1;
+                        list[at++] = ((uint32_t)(64 * chunk + lane) << 16) | (uint32_t)(32 * w + b);   // (row - vmin, column - umin)
                     }
-                    on_outline |= x >= lo && x <= hi;
                 }
             }
-            if (__any(valid && (on_outline || (crossings & 1)))) return kSparseHit;
         }
-        wave_lds_sync();   // the list is rewritten for the next chunk
+    }
+    wave_lds_sync();
+    const int total = bcast_i((int)list[kSparseCap], 0);
+    if (total > kSparseCap) return kSparseTooMany;
+    // ---- a lane per cell, a loop over the edges
+    for (int base = 0; base < total; base += 64) {
+        const bool valid = base + lane < total;
+        const uint32_t cell = valid ? list[base + lane] : 0u;
+        const int y = vmin + (int)(cell >> 16), x = umin + (int)(cell & 0xFFFFu);
+        bool on_outline = false;
+        int crossings = 0;
+        for (int e = 0; e < K; ++e) {
+            const int by = bcast_i(e_y, e), bs = bcast_i(e_s, e), bd = bcast_i(e_d, e);
+            const int ey0 = (int)(short)(by & 0xFFFF), ey1 = by >> 16;
+            if (y >= ey0 && y < ey1) {   // span edge active on this row: does it cross left of the pixel?
+                const int xe = bcast_i(e_x0fp, e) + (y - ey0) * bcast_i(e_dxfp, e);
+                crossings += (int)(x > (xe >> 16));
+            }
+            const int sx = (int)(short)(bs & 0xFFFF), sy = bs >> 16;
+            const int dx = bd & 0x7FFF, dy = bd >> 16;
+            const int i = (bd & 0x8000) ? sy - y : y - sy;
+            if (i >= 0 && i <= dy) {     // the run of this edge on the pixel's row
+                int lo, hi;
+                if (dy > dx) {
+                    lo = hi = sx + (int)__umulhi((uint32_t)(2 * dx * i + dy - 1), (uint32_t)bcast_i((int)e_inv, e));
+                } else if (dy == 0) {
+                    lo = sx;
+                    hi = sx + dx;
+                } else {
+                    const uint32_t inv = (uint32_t)bcast_i((int)e_inv, e);
+                    const int qhi = (int)__umulhi((uint32_t)(2 * dx * i + dx), inv);
+                    const int qlo = i == 0 ? -1 : (int)__umulhi((uint32_t)(2 * dx * (i - 1) + dx), inv);
+                    lo = sx + qlo + 1;
+                    hi = sx + (qhi > dx ? dx : qhi);
+                }
+                on_outline |= x >= lo && x <= hi;
+            }
+        }
+        if (__any(valid && (on_outline || (crossings & 1)))) return kSparseHit;
     }
     return kSparseFree;
 }

@@ -389,6 +389,33 @@ __device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path, 
     return 0.0;
 }
 
+// reward_step with the scan already done (`last` = last_reached_from's result for this pose and target): the rest of
+// ContinuousRewardProvider.reward (envs/base/reward.py:234-259)
+template <typename PathPtr>
+__device__ __forceinline__ double reward_from_last(const DevParams& P, PathPtr path, int m, int last, double x, double y,
+                                                   double& min_dist, int& target)
+{
+    if (target > m - 1) return 0.0;
+    if (last >= 0) {
+        target = last + 1;
+        if (!(target > m - 1)) {
+            const PathPtr g = path + 5 * target;
+            min_dist = hypot(g[0] - x, g[1] - y);
+        } else {
+            min_dist = 0.0;
+        }
+        return 1.0;
+    }
+    const PathPtr g = path + 5 * target;
+    const double d = hypot(g[0] - x, g[1] - y);
+    if (d < min_dist) {
+        const double r = min_dist - d;
+        min_dist = d;
+        return r * P.progress_mult;
+    }
+    return 0.0;
+}
+
 // ContinuousRewardPurePursuitProvider.reward (envs/base/reward.py:330-353) with update_goal (:125-139): the target is
 // the first way point from target_idx on that is more than 2 m away (np.linalg.norm = sqrt of an fma-contracted
 // 2-term dot product, like every 2-element np.dot in this code base), the goal is always the LAST way point.
@@ -507,7 +534,7 @@ __device__ __forceinline__ CollisionLds collision_lds_setup(const DevParams& P, 
     L.qverts = q;
     L.scratch.base = lds + q_off + 4 * P.n_verts + tid;
     L.scratch.stride = kBlock;
-    L.cells = lds + q_off + 4 * P.n_verts + 2 * P.n_verts * kBlock;
+    L.cells = lds + q_off + 4 * P.n_verts + 2 * P.n_verts * kBlock;   // kSparseLdsWords
     __syncthreads();
     return L;
 }
@@ -518,7 +545,7 @@ static size_t collision_lds_bytes(int n_verts, int in_lds, int rows, int wpr)
     words = (words + 1) & ~(size_t)1;
     words += 4 * (size_t)n_verts;            // qverts (doubles)
     words += 2 * (size_t)n_verts * kBlock;   // per-thread vertex scratch
-    words += kSparseCap;                     // cell list of the cell-by-cell exact test
+    words += kSparseLdsWords;                // cell list of the cell-by-cell exact test
     return words * sizeof(uint32_t);
 }
 
@@ -1130,14 +1157,17 @@ constexpr int kLocalEnvs = kLocalPairs * kBlock;
 typedef const __attribute__((address_space(4))) StepArgs& KernArgs;   // the launch arguments where they lie: scalar loads on
                                                                       // demand instead of ~500 bytes pinned in SGPRs
 
-static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles)
+constexpr int kLocalMapWords = 4096;   // a shared lethal bitmap of up to 16 KB is staged in LDS for the exact tests
+
+static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles, int staged_map_words)
 {
     size_t bytes = ((size_t)2 * n_verts + lds_path_doubles + (size_t)kLocalPairs * 6 * kBlock + 8) * sizeof(double);
     bytes += 2 * kBlock * sizeof(uint32_t);          // bucket index of the shared path
     bytes += 4 * sizeof(int32_t);                    // parked count, ticket counter
     bytes = (bytes + 15) & ~(size_t)15;
     bytes += (size_t)kLocalEnvs * sizeof(ParkedLocal);
-    return bytes + (size_t)kLocalWaves * kSparseCap * sizeof(uint32_t);   // a cell list per wave (coop_collides_sparse)
+    bytes += (size_t)kLocalWaves * kSparseLdsWords * sizeof(uint32_t);   // a cell list per wave (coop_collides_sparse)
+    return bytes + (size_t)staged_map_words * sizeof(uint32_t);
 }
 
 template <bool WIDE, bool PLAIN>
@@ -1149,6 +1179,11 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool mover = wave < kLocalPairs, scorer = wave >= kLocalPairs && wave < 2 * kLocalPairs;
     const int pair = wave & (kLocalPairs - 1);
+    // PLAIN (continuous reward, no delays): the backward scan for the last reached way point -- the longest stretch of
+    // the reward provider -- is split three ways between the pair's scorer and its two helper waves (member 0 takes the
+    // top third of the candidate window, ...); the mover takes the maximum and does the rest of the provider itself.
+    const bool scanner = PLAIN ? !mover : scorer;
+    const int member = (wave >> 2) - 1;   // 0 = scorer, 1 / 2 = helpers (PLAIN only)
 
     // ---- LDS
     __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
@@ -1164,7 +1199,9 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
                                           2 * kBlock * sizeof(uint32_t) + 4 * sizeof(int32_t)) + 15) & ~(size_t)15);
     __attribute__((address_space(3))) ParkedLocal* rec =
         (__attribute__((address_space(3))) ParkedLocal*)((__attribute__((address_space(3))) char*)lds_dyn + rec_off);
-    const LdsU32 cell_list = (LdsU32)(rec + kLocalEnvs) + wave * kSparseCap;
+    const LdsU32 cell_list = (LdsU32)(rec + kLocalEnvs) + wave * kSparseLdsWords;
+    const LdsU32 lds_map = (LdsU32)(rec + kLocalEnvs) + kLocalWaves * kSparseLdsWords;
+    const int map_words = a.hot.map_shared && a.hot.map_rows * a.hot.map_wpr <= kLocalMapWords ? a.hot.map_rows * a.hot.map_wpr : 0;
 
     // staging: footprint vertices, the shared path with its bounding box and bucket index, the counters
     if (tid < nq) qv[tid] = P.qverts[tid >> 1][tid & 1];
@@ -1174,6 +1211,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         if (tid >= 576 && tid < 576 + 128) lds_index[tid - 576] = reinterpret_cast<const uint32_t*>(a.hot.path_index)[tid - 576];
     }
     if (tid >= 960 && tid < 964) ctl[tid - 960] = 0;
+    for (int k = tid; k < map_words; k += kLocalWaves * kBlock) lds_map[k] = a.hot.map_bits[k];   // (read after the barriers)
 
     const int64_t gi = (int64_t)blockIdx.x * kLocalEnvs + pair * kBlock + lane;
     const bool active = gi < a.hot.n;
@@ -1185,7 +1223,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     double box[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (mover) {
         load_env<PLAIN>(a, seed, step_counter, i, active, q, cmd0, cmd1);
-    } else if (scorer) {
+    } else if (scanner) {
         q.min_dist = a.hot.st.min_dist[i];
         q.target = a.hot.st.target_idx[i];
         q.geom = a.hot.geom_of_env ? a.hot.geom_of_env[i] : 0;
@@ -1235,8 +1273,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             q.env_lo = (int32_t)(uint32_t)i;
             q.env_hi = (int32_t)(i >> 32);
         }
-    } else if (scorer && !(a.flags & kAblateNoReward)) {
-        // (3b) scorer: the reward provider for the pose as it stands if nothing collides
+    } else if (scanner && !(a.flags & kAblateNoReward)) {
+        // (3b) the reward provider for the pose as it stands if nothing collides
         const double x = hand_pose[lane], y = hand_pose[kBlock + lane], th = hand_pose[2 * kBlock + lane];
         const int64_t g = slot_of(a.S, i, q);
         PathWindow win;
@@ -1245,21 +1283,34 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         else
             win = path_window(P, box, a.S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
         const int m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
-        double min_dist = q.min_dist;
-        int target = q.target;
-        double rew;
         const double* gpath = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
-        if (!PLAIN && P.reward_provider == BCP_REWARD_PURE_PURSUIT) {
-            if (lds_path) rew = reward_pure_pursuit(lds_path, m, x, y, q.collided != 0, min_dist, target);
-            else rew = reward_pure_pursuit(gpath, m, x, y, q.collided != 0, min_dist, target);
-        } else if (lds_path) {
-            rew = reward_step(P, lds_path, win, m, x, y, th, min_dist, target);
+        if (PLAIN) {
+            // this member's slice of the candidate window [max(lo, target), min(hi, m - 1)], counted from the top
+            const int lo = max(win.lo, q.target), hi = min(win.hi, m - 1);
+            const int third = (max(hi - lo + 1, 0) + 2) / 3;
+            PathWindow part;
+            part.hi = hi - member * third;
+            part.lo = max(lo, part.hi - third + 1);
+            int last;
+            if (lds_path) last = last_reached_from(P, lds_path, part, m, q.target, x, y, th);
+            else last = last_reached_from(P, gpath, part, m, q.target, x, y, th);
+            ((__attribute__((address_space(3))) int32_t*)hand_score)[member * kBlock + lane] = last;
         } else {
-            rew = reward_step(P, gpath, win, m, x, y, th, min_dist, target);
+            double min_dist = q.min_dist;
+            int target = q.target;
+            double rew;
+            if (P.reward_provider == BCP_REWARD_PURE_PURSUIT) {
+                if (lds_path) rew = reward_pure_pursuit(lds_path, m, x, y, q.collided != 0, min_dist, target);
+                else rew = reward_pure_pursuit(gpath, m, x, y, q.collided != 0, min_dist, target);
+            } else if (lds_path) {
+                rew = reward_step(P, lds_path, win, m, x, y, th, min_dist, target);
+            } else {
+                rew = reward_step(P, gpath, win, m, x, y, th, min_dist, target);
+            }
+            hand_score[lane] = rew;
+            hand_score[kBlock + lane] = min_dist;
+            hand_score[2 * kBlock + lane] = (double)target;
         }
-        hand_score[lane] = rew;
-        hand_score[kBlock + lane] = min_dist;
-        hand_score[2 * kBlock + lane] = (double)target;
     }
     __syncthreads();
     ScoredFree sc;
@@ -1267,9 +1318,23 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     sc.min_dist = 0.0;
     sc.target = 0;
     if (mover) {
-        sc.rew = hand_score[lane];
-        sc.min_dist = hand_score[kBlock + lane];
-        sc.target = (int)hand_score[2 * kBlock + lane];
+        if (PLAIN) {
+            const __attribute__((address_space(3))) int32_t* found = (__attribute__((address_space(3))) int32_t*)hand_score;
+            const int last = max(max(found[lane], found[kBlock + lane]), found[2 * kBlock + lane]);
+            const int64_t g = slot_of(a.S, i, q);
+            const int m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
+            sc.min_dist = q.min_dist;
+            sc.target = q.target;
+            if (lds_path)
+                sc.rew = reward_from_last(P, lds_path, m, last, r.p.x, r.p.y, sc.min_dist, sc.target);
+            else
+                sc.rew = reward_from_last(P, a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5), m,
+                                          last, r.p.x, r.p.y, sc.min_dist, sc.target);
+        } else {
+            sc.rew = hand_score[lane];
+            sc.min_dist = hand_score[kBlock + lane];
+            sc.target = (int)hand_score[2 * kBlock + lane];
+        }
         // (4) park the undecided envs in LDS: one LDS atomic per wave hands out the slots
         const uint64_t parking = __ballot(park);
         if (parking) {
@@ -1311,8 +1376,11 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         bool h = false;
         if (!(a.flags & kAblateNoCoop)) {
             // the lethal cells under the image tested one by one; a map too dense for that is rasterised row by row
-            const int verdict = coop_collides_sparse<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols,
-                                                           a.hot.map_wpr, cell_list);
+            const int verdict = map_words
+                ? coop_collides_sparse<WIDE>(P, vqx, vqy, c, s, px, py, (LdsWords)lds_map, a.hot.map_rows, a.hot.map_cols,
+                                             a.hot.map_wpr, cell_list)
+                : coop_collides_sparse<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr,
+                                             cell_list);
             h = verdict == kSparseHit;
             if (verdict == kSparseTooMany)
                 h = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr);

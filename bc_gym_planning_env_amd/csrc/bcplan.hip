@@ -1362,7 +1362,9 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
                        : variant == 2 ? (const void*)step_local_kernel<true, false>
                        : variant == 1 ? (const void*)step_local_kernel<false, true>
                                       : (const void*)step_local_kernel<false, false>;
-        const size_t lds = local_step_lds_bytes(h->params.n_verts, S.lds_path_doubles);
+        const int64_t bitmap_words = (int64_t)S.map.rows * S.map.wpr;
+        const size_t lds = local_step_lds_bytes(h->params.n_verts, S.lds_path_doubles,
+                                                (S.map.shared && bitmap_words <= kLocalMapWords) ? (int)bitmap_words : 0);
         if (h->local_lds_set[variant] != (int32_t)lds) {
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             h->local_lds_set[variant] = (int32_t)lds;

@@ -184,19 +184,21 @@ def cpu_baseline(g, envs=ENVS_PER_GPU, budget_s=12.0):
                                 "it cannot travel to the GPU box)"}
 
 
-def newest_profile(pattern):
-    """Newest committed profiles/rNN_<pattern> (by round number): (path, parsed json) or (None, None)."""
+def newest_profile(name):
+    """Newest committed profiles/rNN_<name> (by round number, exact name): (path, parsed json) or (None, None)."""
     best = None
-    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_" + pattern)):
-        m = re.match(r"r(\d+)_", os.path.basename(path))
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_" + name)):
+        m = re.match(r"^r(\d+)_" + re.escape(name) + "$", os.path.basename(path))
         if m and (best is None or int(m.group(1)) > best[0]):
             best = (int(m.group(1)), path)
     if best is None:
         return None, None
     try:
         with open(best[1]) as f:
-            return os.path.relpath(best[1], ROOT), json.load(f)
-    except (OSError, ValueError):
+            data = json.load(f)
+        data["corrected_bytes_per_step"]["total"]   # (the field the bench line quotes)
+        return os.path.relpath(best[1], ROOT), data
+    except (OSError, ValueError, KeyError, TypeError):
         return None, None
 
 
