@@ -399,74 +399,93 @@ __device__ __forceinline__ bool coop_collides_quad(const DevParams& P, double qx
 // ---- the exact test, cell by cell ------------------------------------------------------------------------------------
 // coop_raster builds the coverage of EVERY row of the footprint image (lane = row, a loop over the edges with ~90
 // vector operations per edge and 64-row chunk) and then looks whether a lethal cell lies under it.  On the maps this
-// path meets -- walls one cell thick -- the image holds ~1500 cells and the map only a few dozen lethal ones beneath its
-// bounding box, so this form turns the question round: the lethal cells under the bounding box are listed (lane = row:
-// the row's lethal bits, a wave-wide prefix sum, the set bits written to a list in LDS), a lane takes a cell, and the
-// loop over the edges asks of that ONE pixel what cv2.fillPoly's raster holds there:
-//     outline: the pixel lies on the run of edge e on its row          (same run arithmetic as coop_raster)
-//     span   : an odd number of active edges cross its row to its left (x > floor(x_e): the parity form, see above)
-// ~25 vector operations per edge, one pass for up to 64 cells whatever the image height.  Same verdict as coop_raster,
-// pixel for pixel; `list` is kSparseLdsWords words of LDS owned by the calling wave.  More than kSparseCap lethal cells
-// under the image (filled obstacles) make the function return kSparseTooMany: the caller then rasterises.
+// path meets -- walls one cell thick -- the image holds ~1500 cells and the map a handful of lethal ones beneath its
+// bounding box (metric workload: median 3, 90th percentile 14), so this form turns the question round:
+//   1. the lethal cells under the bounding box are listed (lane = row: the row's lethal bits, room in the list
+//      reserved with one LDS atomic, the set bits written out);
+//   2. a lane takes a (cell, edge) PAIR -- a group of G = 16 (or 32) lanes per cell, lane e of the group holding edge
+//      e's parameters, which it computed itself -- and asks of that one pixel what cv2.fillPoly's raster holds there:
+//          outline: the pixel lies on the run of edge e on its row          (same run arithmetic as coop_raster)
+//          span   : edge e is active on its row and crosses it to its left  (x > floor(x_e): the parity form, see above)
+//      two ballots later every group knows its cell: covered <=> any outline bit, or an odd number of crossings.
+// No loop over the edges, no v_readlane: ~60 vector operations per 4 cells.  Same verdict as coop_raster, pixel for
+// pixel; `qverts` = the footprint vertices / resolution in LDS (2 doubles each), `list` = kSparseLdsWords words of LDS
+// owned by the calling wave.  More than kSparseCap lethal cells under the image (filled obstacles) make the function
+// return kSparseTooMany: the caller then rasterises.
 constexpr int kSparseCap = 256;
 constexpr int kSparseLdsWords = kSparseCap + 1;   // the list + its fill counter
 enum { kSparseFree = 0, kSparseHit = 1, kSparseTooMany = 2 };
 
+// minimum / maximum over the 16 lanes of a DPP row (every lane gets the result): four rotate-and-combine steps
+template <int CTRL>
+__device__ __forceinline__ int dpp_ror(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);   // row_ror:n = 0x120 + n
+}
+
+__device__ __forceinline__ int row_min(int v)
+{
+    v = min(v, dpp_ror<0x128>(v));
+    v = min(v, dpp_ror<0x124>(v));
+    v = min(v, dpp_ror<0x122>(v));
+    return min(v, dpp_ror<0x121>(v));
+}
+
+__device__ __forceinline__ int row_max(int v)
+{
+    v = max(v, dpp_ror<0x128>(v));
+    v = max(v, dpp_ror<0x124>(v));
+    v = max(v, dpp_ror<0x122>(v));
+    return max(v, dpp_ror<0x121>(v));
+}
+
 template <bool WIDE, typename WordPtr>
-__device__ __forceinline__ int coop_collides_sparse(const DevParams& P, double qx, double qy, double c, double s, int px,
-                                                    int py, WordPtr words, int rows, int cols, int wpr, LdsU32 list)
+__device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 qverts, double c, double s, int px, int py,
+                                                    WordPtr words, int rows, int cols, int wpr, LdsU32 list)
 {
     constexpr int NW = WIDE ? 8 : 3;
     const int K = P.n_verts;
     const int lane = lane_id();
-    // ---- lane k < K owns vertex k and edge k (as in coop_raster)
-    int u = 0, v = 0;
-    if (lane < K) {
-        u = (int)rint(fma(qy, -s, qx * c));   // path_tools.py:142-150
-        v = (int)rint(fma(qy, c, qx * s));
+    const int G = K <= 16 ? 16 : 32;            // lanes per cell; lane e of a group owns edge e = (V[e-1] -> V[e])
+    const int e = lane & (G - 1), group = lane / G;
+    const bool owner = e < K;
+    // ---- this lane's edge, from its two vertices (inert lanes take vertex 0 twice: no effect on the extents)
+    const int ve = owner ? e : 0, vp_i = owner ? (e == 0 ? K - 1 : e - 1) : 0;
+    const double qx = qverts[2 * ve], qy = qverts[2 * ve + 1], pqx = qverts[2 * vp_i], pqy = qverts[2 * vp_i + 1];
+    const int u = (int)rint(fma(qy, -s, qx * c)), v = (int)rint(fma(qy, c, qx * s));       // path_tools.py:142-150
+    const int up = (int)rint(fma(pqy, -s, pqx * c)), vp = (int)rint(fma(pqy, c, pqx * s));
+    int vmin = row_min(v), vmax = row_max(v), umin = row_min(u), umax = row_max(u);
+    if (G == 32) {   // the group spans two DPP rows
+        vmin = min(vmin, __shfl_xor(vmin, 16));
+        vmax = max(vmax, __shfl_xor(vmax, 16));
+        umin = min(umin, __shfl_xor(umin, 16));
+        umax = max(umax, __shfl_xor(umax, 16));
     }
-    const int prev = lane == 0 ? K - 1 : lane - 1;
-    const int up = __shfl(u, prev), vp = __shfl(v, prev);
-    const bool owner = lane < K;
-    int vmin = 0x7fffffff, vmax = -0x7fffffff, umin = 0x7fffffff, umax = -0x7fffffff;
-    for (int k = 0; k < K; ++k) {
-        const int uk = bcast_i(u, k), vk = bcast_i(v, k);
-        vmin = min(vmin, vk);
-        vmax = max(vmax, vk);
-        umin = min(umin, uk);
-        umax = max(umax, uk);
+    vmin = bcast_i(vmin, 0);   // (the same in every group; scalar from here on)
+    vmax = bcast_i(vmax, 0);
+    umin = bcast_i(umin, 0);
+    umax = bcast_i(umax, 0);
+    // span edge (CollectPolyEdges): active for y0 <= y < y1, x in 16.16 from the end with the smaller y
+    const int ddy = v - vp;
+    const int y0 = min(v, vp), y1 = owner ? max(v, vp) : y0;
+    const int x0fp = (vp < v ? up : u) << 16;
+    const int dxfp = ddy != 0 ? ((u - up) * 65536) / ddy : 0;
+    // Bresenham (LineIterator, leftToRight): from the end with the smaller x
+    int sx = up, sy = vp, dx = u - up, dy = v - vp;
+    if (dx < 0) {
+        dx = -dx;
+        dy = -dy;
+        sx = u;
+        sy = v;
     }
-    // the edge of this lane, packed for broadcasting (|u|, |v| <= BCP_MAX_KERNEL_HALF + 1: 16 bits each are plenty)
-    int e_y, e_s, e_d, e_x0fp, e_dxfp;
-    uint32_t e_inv;
-    {
-        const int ddy = v - vp;
-        const int y0 = min(v, vp), y1 = owner ? max(v, vp) : y0;   // span activity y0 <= y < y1
-        e_y = (y1 << 16) | (y0 & 0xFFFF);
-        e_x0fp = (vp < v ? up : u) << 16;
-        e_dxfp = ddy != 0 ? ((u - up) * 65536) / ddy : 0;
-        int sx = up, sy = vp, dx = u - up, dy = v - vp;
-        if (dx < 0) {
-            dx = -dx;
-            dy = -dy;
-            sx = u;
-            sy = v;
-        }
-        int down = 0;   // ystep = -1
-        if (dy < 0) {
-            dy = -dy;
-            down = 1;
-        }
-        if (!owner) dy = -1;   // inert
-        e_s = (sy << 16) | (sx & 0xFFFF);
-        e_d = (dy << 16) | (down << 15) | dx;
-        const uint32_t D = 2u * (uint32_t)(dy > 0 ? dy : 1);
-        e_inv = (uint32_t)(4294967296.0 / (double)D) + 1u;
-    }
-    CoopCollisionSink<NW, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
-    sink.extent(umin, umax);
+    const bool down = dy < 0;   // ystep = -1
+    if (down) dy = -dy;
+    const uint32_t inv = (uint32_t)(4294967296.0 / (double)(2u * (uint32_t)(dy > 0 ? dy : 1))) + 1u;   // see coop_raster
+    if (!owner) dy = -1;        // inert: no run on any row
     // ---- the lethal cells under the image's columns, all row chunks into one list (lane = row of the chunk; the order
     //      of the cells does not matter, so a lane just reserves room for its row's cells with one LDS atomic)
+    CoopCollisionSink<NW, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
+    sink.extent(umin, umax);
     if (lane == 0) list[kSparseCap] = 0;
     wave_lds_sync();
     const int n_chunks = (vmax - vmin) / 64 + 1;
@@ -494,41 +513,34 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, double q
     wave_lds_sync();
     const int total = bcast_i((int)list[kSparseCap], 0);
     if (total > kSparseCap) return kSparseTooMany;
-    // ---- a lane per cell, a loop over the edges
-    for (int base = 0; base < total; base += 64) {
-        const bool valid = base + lane < total;
-        const uint32_t cell = valid ? list[base + lane] : 0u;
+    // ---- a group of lanes per cell, a lane per edge
+    const int per_pass = 64 / G;
+    const uint64_t group_mask = (G == 16 ? 0xFFFFull : 0xFFFFFFFFull) << (G * group);
+    for (int base = 0; base < total; base += per_pass) {
+        const bool valid = base + group < total;
+        const uint32_t cell = valid ? list[base + group] : 0u;
         const int y = vmin + (int)(cell >> 16), x = umin + (int)(cell & 0xFFFFu);
+        const bool crossing = y >= y0 && y < y1 && x > ((x0fp + (y - y0) * dxfp) >> 16);
         bool on_outline = false;
-        int crossings = 0;
-        for (int e = 0; e < K; ++e) {
-            const int by = bcast_i(e_y, e), bs = bcast_i(e_s, e), bd = bcast_i(e_d, e);
-            const int ey0 = (int)(short)(by & 0xFFFF), ey1 = by >> 16;
-            if (y >= ey0 && y < ey1) {   // span edge active on this row: does it cross left of the pixel?
-                const int xe = bcast_i(e_x0fp, e) + (y - ey0) * bcast_i(e_dxfp, e);
-                crossings += (int)(x > (xe >> 16));
+        const int i = down ? sy - y : y - sy;
+        if (i >= 0 && i <= dy) {     // the run of this edge on the pixel's row
+            int lo, hi;
+            if (dy > dx) {           // y-major: x = sx + floor((2*dx*i + dy - 1) / (2*dy))
+                lo = hi = sx + (int)__umulhi((uint32_t)(2 * dx * i + dy - 1), inv);
+            } else if (dy == 0) {    // horizontal edge / single point
+                lo = sx;
+                hi = sx + dx;
+            } else {                 // x-major: steps floor((2*dx*(i-1)+dx)/(2*dy)) + 1 .. min(dx, floor((2*dx*i+dx)/(2*dy)))
+                const int qhi = (int)__umulhi((uint32_t)(2 * dx * i + dx), inv);
+                const int qlo = i == 0 ? -1 : (int)__umulhi((uint32_t)(2 * dx * (i - 1) + dx), inv);
+                lo = sx + qlo + 1;
+                hi = sx + (qhi > dx ? dx : qhi);
             }
-            const int sx = (int)(short)(bs & 0xFFFF), sy = bs >> 16;
-            const int dx = bd & 0x7FFF, dy = bd >> 16;
-            const int i = (bd & 0x8000) ? sy - y : y - sy;
-            if (i >= 0 && i <= dy) {     // the run of this edge on the pixel's row
-                int lo, hi;
-                if (dy > dx) {
-                    lo = hi = sx + (int)__umulhi((uint32_t)(2 * dx * i + dy - 1), (uint32_t)bcast_i((int)e_inv, e));
-                } else if (dy == 0) {
-                    lo = sx;
-                    hi = sx + dx;
-                } else {
-                    const uint32_t inv = (uint32_t)bcast_i((int)e_inv, e);
-                    const int qhi = (int)__umulhi((uint32_t)(2 * dx * i + dx), inv);
-                    const int qlo = i == 0 ? -1 : (int)__umulhi((uint32_t)(2 * dx * (i - 1) + dx), inv);
-                    lo = sx + qlo + 1;
-                    hi = sx + (qhi > dx ? dx : qhi);
-                }
-                on_outline |= x >= lo && x <= hi;
-            }
+            on_outline = x >= lo && x <= hi;
         }
-        if (__any(valid && (on_outline || (crossings & 1)))) return kSparseHit;
+        const uint64_t outlines = __ballot(valid && on_outline), crossings = __ballot(valid && crossing);
+        const bool covered = (outlines & group_mask) != 0 || (__popcll(crossings & group_mask) & 1);
+        if (__any(covered)) return kSparseHit;
     }
     return kSparseFree;
 }

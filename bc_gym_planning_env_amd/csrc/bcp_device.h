@@ -25,6 +25,7 @@ struct DevParams {
     double sp2_lo, sp2_hi;   // sp^2 (1 -+ 1e-13): dx^2+dy^2 outside this band decides hypot(dx,dy) < sp on its own
     double sp_prune;         // sp nudged up two ulps: |dx| > sp_prune  =>  hypot(dx,dy) >= sp for any faithful hypot
     double qverts[BCP_MAX_VERTS][2];  // footprint / resolution (path_tools.py:145), divided on the host in fp64
+    float qbox[4];                    // bounding box of qverts in the robot frame: xmin, xmax, ymin, ymax (pixels)
     int32_t reward_provider;          // BCP_REWARD_*
     int32_t control_delay, pose_delay, state_delay;   // EnvParams delays (envs/base/params.py:28-30)
 };

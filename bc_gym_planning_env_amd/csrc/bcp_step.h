@@ -495,15 +495,19 @@ __device__ __forceinline__ void fifo_push(double* __restrict__ q, int delay, int
 
 constexpr int kWavePerPoseFrom = 1;   // step_pending_kernel: more than this many rounds of parked poses per team -> a pose per wave
 #ifdef BCP_DIAG
-constexpr int kDiagBlocks = 4096;   // stamps of the first kDiagBlocks workgroups of step_pending_kernel
-__device__ unsigned long long g_diag[kDiagBlocks * 8];
-#define DIAG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+constexpr int kDiagBlocks = 4096;   // stamps of the first kDiagBlocks workgroups of a step kernel, 16 slots each
+__device__ unsigned long long g_diag[kDiagBlocks * 16];
+#define DIAG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// lane 0 of wave `w` of the workgroup
+#define DIAG_STAMP_W(w, k) do { if (threadIdx.x == (w) * 64 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int bcp_diag_read(unsigned long long* out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(g_diag));
 }
+
 #else
 #define DIAG_STAMP(k) do { } while (0)
+#define DIAG_STAMP_W(w, k) do { } while (0)
 #endif
 
 
@@ -596,11 +600,11 @@ __device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc&
         int verdict = kSparseTooMany;
         if (exact_mode == 3) {   // the cell-by-cell form of the exact test (what step_local_kernel uses)
             if (L.staged)
-                verdict = wide ? coop_collides_sparse<true>(P, vqx, vqy, c_, s_, px_, py_, L.bits, map.rows, map.cols, map.wpr, L.cells)
-                               : coop_collides_sparse<false>(P, vqx, vqy, c_, s_, px_, py_, L.bits, map.rows, map.cols, map.wpr, L.cells);
+                verdict = wide ? coop_collides_sparse<true>(P, L.qverts, c_, s_, px_, py_, L.bits, map.rows, map.cols, map.wpr, L.cells)
+                               : coop_collides_sparse<false>(P, L.qverts, c_, s_, px_, py_, L.bits, map.rows, map.cols, map.wpr, L.cells);
             else
-                verdict = wide ? coop_collides_sparse<true>(P, vqx, vqy, c_, s_, px_, py_, words, map.rows, map.cols, map.wpr, L.cells)
-                               : coop_collides_sparse<false>(P, vqx, vqy, c_, s_, px_, py_, words, map.rows, map.cols, map.wpr, L.cells);
+                verdict = wide ? coop_collides_sparse<true>(P, L.qverts, c_, s_, px_, py_, words, map.rows, map.cols, map.wpr, L.cells)
+                               : coop_collides_sparse<false>(P, L.qverts, c_, s_, px_, py_, words, map.rows, map.cols, map.wpr, L.cells);
         }
         if (verdict != kSparseTooMany) {
             h = verdict == kSparseHit;
@@ -1203,6 +1207,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     const LdsU32 lds_map = (LdsU32)(rec + kLocalEnvs) + kLocalWaves * kSparseLdsWords;
     const int map_words = a.hot.map_shared && a.hot.map_rows * a.hot.map_wpr <= kLocalMapWords ? a.hot.map_rows * a.hot.map_wpr : 0;
 
+    DIAG_STAMP(0);
     // staging: footprint vertices, the shared path with its bounding box and bucket index, the counters
     if (tid < nq) qv[tid] = P.qverts[tid >> 1][tid & 1];
     for (int k = tid; k < npath; k += kLocalWaves * kBlock) qv[nq + k] = a.hot.path_pts[k];
@@ -1239,13 +1244,16 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     if (mover) {
         q.old = r.p;
         q.drawn = 0;
+        DIAG_STAMP(1);   // (the compiler may move loads across this: indicative only)
         q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
         const bool delayed = !PLAIN && P.pose_delay > 0 && q.iter + 1 > 1;
         hand_pose[lane] = delayed ? q.popped_pose[0] : r.p.x;
         hand_pose[kBlock + lane] = delayed ? q.popped_pose[1] : r.p.y;
         hand_pose[2 * kBlock + lane] = delayed ? q.popped_pose[2] : r.p.th;
+        DIAG_STAMP(2);
     }
     __syncthreads();
+    DIAG_STAMP(3);
     bool hit = false, park = false;
     if (mover) {
         // (3a) collision: distance-field classification; an undecided env is parked below
@@ -1312,7 +1320,10 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             hand_score[2 * kBlock + lane] = (double)target;
         }
     }
+    DIAG_STAMP(4);        // mover: classified
+    DIAG_STAMP_W(4, 8);   // scorer of pair 0: scanned
     __syncthreads();
+    DIAG_STAMP(5);
     ScoredFree sc;
     sc.rew = 0.0;
     sc.min_dist = 0.0;
@@ -1353,20 +1364,24 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             }
         }
     }
+    DIAG_STAMP(6);        // mover: parked
     __syncthreads();
+    DIAG_STAMP_W(8, 9);   // helper: past the third barrier
     const int n_parked = __builtin_amdgcn_readfirstlane(ctl[0]);   // (scalar: the ticket loop below must stay wave-uniform)
     // (5) movers finish their decided envs; every wave then settles parked poses, a ticket at a time
     if (mover && active && !park)
         finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &sc);
-    const double vqx = lane < P.n_verts ? qv[2 * lane] : 0.0, vqy = lane < P.n_verts ? qv[2 * lane + 1] : 0.0;
+    const double vqx = lane < P.n_verts ? qv[2 * lane] : 0.0, vqy = lane < P.n_verts ? qv[2 * lane + 1] : 0.0;   // (row-by-row fallback)
     // (Control flow: ONE single-lane region per iteration -- lane 0 finishes the env and draws the next ticket in the same
     //  block -- and a scalar loop condition.  With the draw at the top of the body, i.e. two `if (lane == 0)` regions per
     //  trip, hipcc 7.2 threaded lane 0's path across the back edge and split the loop in two; lanes 1..63 then span in the
     //  inner one on ticket 0 for ever while lane 0 waited outside it.)
+    DIAG_STAMP(7);        // mover: decided envs finished
     int ticket = 0;
     if (lane == 0) ticket = atomicAdd((int*)&ctl[1], 1);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     while (ticket < n_parked) {
+        DIAG_STAMP_W(8, 10);   // helper: has a ticket
         const __attribute__((address_space(3))) ParkedLocal* e = rec + ticket;
         const double c = e->q.c, s = e->q.s;
         const int px = e->q.px, py = e->q.py;
@@ -1377,14 +1392,15 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         if (!(a.flags & kAblateNoCoop)) {
             // the lethal cells under the image tested one by one; a map too dense for that is rasterised row by row
             const int verdict = map_words
-                ? coop_collides_sparse<WIDE>(P, vqx, vqy, c, s, px, py, (LdsWords)lds_map, a.hot.map_rows, a.hot.map_cols,
+                ? coop_collides_sparse<WIDE>(P, (LdsF64)qv, c, s, px, py, (LdsWords)lds_map, a.hot.map_rows, a.hot.map_cols,
                                              a.hot.map_wpr, cell_list)
-                : coop_collides_sparse<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr,
+                : coop_collides_sparse<WIDE>(P, (LdsF64)qv, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr,
                                              cell_list);
             h = verdict == kSparseHit;
             if (verdict == kSparseTooMany)
                 h = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr);
         }
+        DIAG_STAMP_W(8, 11);   // helper: verdict
         int next = 0;
         if (lane == 0) {
             Pending pq;
@@ -1397,7 +1413,13 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             next = atomicAdd((int*)&ctl[1], 1);
         }
         ticket = __builtin_amdgcn_readfirstlane(next);
+        DIAG_STAMP_W(8, 12);   // helper: env finished
     }
+    DIAG_STAMP(13);            // mover: out of tickets
+    DIAG_STAMP_W(8, 14);       // helper: out of tickets
+#ifdef BCP_DIAG
+    if (tid == 0 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 16 + 15] = (unsigned long long)n_parked;
+#endif
     if ((a.flags & kStepAdvances) && tid == 0) {   // the last workgroup to get here moves the step counter on
         unsigned int* ticket = reinterpret_cast<unsigned int*>(a.tick + 3);
         if (atomicAdd(ticket, 1u) == gridDim.x - 1) {

@@ -798,6 +798,21 @@ static int footprint_is_wide(const bcp_params& p, double res)
     return std::sqrt(d2) / res + 3.0 > 96.0;  // row masks of the cooperative path: 3 words unless wider
 }
 
+// robot_footprint / map_resolution (path_tools.py:145), divided on the host in fp64, and its bounding box
+static void scale_footprint(DevParams& d, const bcp_params& p, double res)
+{
+    d.qbox[0] = d.qbox[2] = 1e30f;
+    d.qbox[1] = d.qbox[3] = -1e30f;
+    for (int k = 0; k < p.n_verts; ++k) {
+        d.qverts[k][0] = p.verts[k][0] / res;
+        d.qverts[k][1] = p.verts[k][1] / res;
+        d.qbox[0] = std::min(d.qbox[0], (float)d.qverts[k][0]);
+        d.qbox[1] = std::max(d.qbox[1], (float)d.qverts[k][0]);
+        d.qbox[2] = std::min(d.qbox[2], (float)d.qverts[k][1]);
+        d.qbox[3] = std::max(d.qbox[3], (float)d.qverts[k][1]);
+    }
+}
+
 static void fill_dev_params(bcp_handle* h)
 {
     const bcp_params& p = h->params;
@@ -829,10 +844,7 @@ static void fill_dev_params(bcp_handle* h)
     d.pose_delay = p.pose_delay;
     d.state_delay = p.state_delay;
     const double res = h->resolution > 0 ? h->resolution : 1.0;
-    for (int k = 0; k < p.n_verts; ++k) {
-        d.qverts[k][0] = p.verts[k][0] / res;  // robot_footprint / map_resolution (path_tools.py:145)
-        d.qverts[k][1] = p.verts[k][1] / res;
-    }
+    scale_footprint(d, p, res);
 }
 
 static int check_kernel_size(const bcp_params& p, double res)
@@ -1568,10 +1580,7 @@ extern "C" int bcp_pixel_footprint(bcp_handle* h, const double* angles, int64_t 
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     DevParams P = h->dev;
-    for (int k = 0; k < h->params.n_verts; ++k) {
-        P.qverts[k][0] = h->params.verts[k][0] / resolution;
-        P.qverts[k][1] = h->params.verts[k][1] / resolution;
-    }
+    scale_footprint(P, h->params, resolution);
     HIP_TRY(hipMemsetAsync(masks, 0, (size_t)n * side * side, s));
     if (h->exact_mode == 2) {  // per-thread rasteriser
         const int blocks = (int)((n + kBlock - 1) / kBlock);
@@ -1893,10 +1902,7 @@ static int sample_mini_worlds(bcp_handle* h, const bcp_mini_world_params* p, uin
     if (rows <= 0 || cols <= 0 || lds > 60 * 1024) return fail(BCP_E_INVALID, "bcp_sample_mini_worlds: unsupported map shape");
     HIP_TRY(hipSetDevice(h->device));
     DevParams P = h->dev;
-    for (int k = 0; k < h->params.n_verts; ++k) {   // robot_footprint / map_resolution (path_tools.py:145)
-        P.qverts[k][0] = h->params.verts[k][0] / p->resolution;
-        P.qverts[k][1] = h->params.verts[k][1] / p->resolution;
-    }
+    scale_footprint(P, h->params, p->resolution);
     MiniWorldParams mp;
     mp.inner_h = p->inner_h;
     mp.inner_w = p->inner_w;
