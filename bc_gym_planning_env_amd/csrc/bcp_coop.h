@@ -89,7 +89,7 @@ __device__ __forceinline__ OuterLookups outer_lookups_issue(const CullDesc& C, i
     OuterLookups L;
     L.off_map = px + C.reach < 0 || px - C.reach >= cols || py + C.reach < 0 || py - C.reach >= rows;
     const double ay_c = C.axis_y * c, ay_s = C.axis_y * s;
-    const uint8_t* field = C.edt + env * C.env_stride;
+    const GlobalPtr<const uint8_t> field = as_global(C.edt) + env * C.env_stride;
     // a sample outside the stored (padded) rectangle is more than `pad` px away from every cell of the map
     const int not_stored = min(C.pad + 1, 255);
 #pragma unroll

@@ -12,6 +12,19 @@
 
 namespace bcp {
 
+// Pointers that reach a kernel through memory (the device-resident parameter block, the kernel-argument segment read
+// through a constant-address-space reference) are generic to the compiler, which then emits FLAT loads and stores: they
+// count against both the vector-memory and the LDS counters, so an LDS operation behind a few flat stores waits for
+// memory.  Everything these kernels reach through such pointers is global memory: say so.
+template <typename T>
+using GlobalPtr = T __attribute__((address_space(1)))*;
+
+template <typename T>
+__device__ __forceinline__ GlobalPtr<T> as_global(T* p)
+{
+    return (GlobalPtr<T>)p;
+}
+
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kTwoPi = 2.0 * kPi;
 

@@ -644,7 +644,9 @@ struct ScoredFree {
 // One env's parked record of the single-launch step (LDS): the state after the robot model + the scorer wave's result
 struct ParkedLocal {
     Pending q;
-    ScoredFree sc;
+    ScoredFree sc;       // written by the mover once the scan results are in (after the record itself) ...
+    int32_t sc_ready;    // ... and then announced here
+    int32_t pad_;
 };
 
 // entry of the non-shared map / path arrays that env i uses
@@ -660,8 +662,9 @@ __device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const
 // (A: StepArgs by value, or by reference into the kernel-argument segment -- only a.S, the output pointers and a.flags are used)
 template <bool PLAIN, typename A>
 __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
-                                             const PathWindow* free_window = nullptr, const ScoredFree* scored = nullptr)
-{
+                                             const PathWindow* free_window = nullptr, bool have_score = false,
+                                             ScoredFree score = ScoredFree())
+{   // (the score travels by value: a pointer to a local made the compiler keep it in scratch memory)
     const DevParams& P = a.S->P;
     const int pose_delay = PLAIN ? 0 : P.pose_delay, state_delay = PLAIN ? 0 : P.state_delay;
     const bool pure_pursuit = !PLAIN && P.reward_provider == BCP_REWARD_PURE_PURSUIT;
@@ -691,10 +694,10 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
     const double* pts = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
     m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
     if (pure_pursuit) {
-        if (scored && !hit) {   // the scorer wave has already done it (no collision: the flag it assumed stands)
-            rew = scored->rew;
-            min_dist = scored->min_dist;
-            target = scored->target;
+        if (have_score && !hit) {   // the scorer wave has already done it (no collision: the flag it assumed stands)
+            rew = score.rew;
+            min_dist = score.min_dist;
+            target = score.target;
         } else if (!(a.flags & kAblateNoReward)) {
             rew = reward_pure_pursuit(pts, m, seen[0], seen[1], collided, min_dist, target);
         }
@@ -702,10 +705,10 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
     } else {
         // the scorer wave has already done it (step_fast_pair_kernel) for the pose State exposes if nothing collides --
         // which, with a pose delay, is an earlier pose whatever this step's verdict (from the second step of an episode on)
-        if (scored && (!hit || (pose_delay && iter > 1))) {
-            rew = scored->rew;
-            min_dist = scored->min_dist;
-            target = scored->target;
+        if (have_score && (!hit || (pose_delay && iter > 1))) {
+            rew = score.rew;
+            min_dist = score.min_dist;
+            target = score.target;
         } else if (!(a.flags & kAblateNoReward)) {
             // way-point window of the pose: the caller may have looked it up already for the un-rolled-back pose
             const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : g * 8);
@@ -721,15 +724,15 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
     }
     const bool done = goal || (iter >= P.iteration_timeout) || collided;
 
-    a.reward[i] = rew;
-    a.done[i] = (uint8_t)done;
-    if (a.collided_now) a.collided_now[i] = (uint8_t)hit;
-    if (a.err) a.err[i] = q.err;
+    as_global(a.reward)[i] = rew;
+    as_global(a.done)[i] = (uint8_t)done;
+    if (a.collided_now) as_global(a.collided_now)[i] = (uint8_t)hit;
+    if (a.err) as_global(a.err)[i] = q.err;
     if (a.noise_z_out) {
         const double nan = __builtin_nan("");
-        a.noise_z_out[3 * i + 0] = (q.drawn & 1) ? q.z[0] : nan;
-        a.noise_z_out[3 * i + 1] = (q.drawn & 2) ? q.z[1] : nan;
-        a.noise_z_out[3 * i + 2] = (q.drawn & 4) ? q.z[2] : nan;
+        as_global(a.noise_z_out)[3 * i + 0] = (q.drawn & 1) ? q.z[0] : nan;
+        as_global(a.noise_z_out)[3 * i + 1] = (q.drawn & 2) ? q.z[1] : nan;
+        as_global(a.noise_z_out)[3 * i + 2] = (q.drawn & 4) ? q.z[2] : nan;
     }
 
     if (done && (a.flags & BCP_STEP_AUTO_RESET)) {  // PlanEnv.reset(): set_state(initial_state) (env.py:293-303)
@@ -737,22 +740,22 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
         if (a.S->geom_of_env) {  // RandomMiniEnv.reset(): the env moves on to its next geometry (mini_env.py:469-481).
             // Computed from the entry the step started with, so kernel 2 redoing an env that kernel 1 already reset
             // lands on the same geometry (a hit always ends the episode, so both reset or neither does).
-            k = a.S->next_geom ? a.S->next_geom[g] : g;
-            a.S->geom_of_env[i] = (int32_t)k;
+            k = a.S->next_geom ? as_global(a.S->next_geom)[g] : g;
+            as_global(a.S->geom_of_env)[i] = (int32_t)k;
         }
-        r.p.x = a.S->init.x[k];
-        r.p.y = a.S->init.y[k];
-        r.p.th = a.S->init.angle[k];
-        r.v = a.S->init.v[k];
-        r.w = a.S->init.w[k];
+        r.p.x = as_global(a.S->init.x)[k];
+        r.p.y = as_global(a.S->init.y)[k];
+        r.p.th = as_global(a.S->init.angle)[k];
+        r.v = as_global(a.S->init.v)[k];
+        r.w = as_global(a.S->init.w)[k];
         if (tri) {
-            r.steer = a.S->init.steer[k];
-            r.wheel = a.S->init.wheel[k];
+            r.steer = as_global(a.S->init.steer)[k];
+            r.wheel = as_global(a.S->init.wheel)[k];
         }
-        min_dist = a.S->init.min_dist[k];
-        target = a.S->init.target_idx[k];
-        iter = a.S->init.cur_iter[k];
-        collided = a.S->init.collided[k] != 0;
+        min_dist = as_global(a.S->init.min_dist)[k];
+        target = as_global(a.S->init.target_idx)[k];
+        iter = as_global(a.S->init.cur_iter)[k];
+        collided = as_global(a.S->init.collided)[k] != 0;
         // the restored State exposes the initial pose / robot state; its queues are empty (pushes restart at k = 1)
         seen[0] = r.p.x;
         seen[1] = r.p.y;
@@ -765,19 +768,20 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
         seen_rs[5] = r.steer;
         seen_rs[6] = r.wheel;
     }
-    a.S->st.x[i] = r.p.x;
-    a.S->st.y[i] = r.p.y;
-    a.S->st.angle[i] = r.p.th;
-    a.S->st.v[i] = r.v;
-    a.S->st.w[i] = r.w;
+    // (the state pointers come with the kernel arguments -- StepHot -- not through *S: one dependent load less per array)
+    as_global(a.hot.st.x)[i] = r.p.x;
+    as_global(a.hot.st.y)[i] = r.p.y;
+    as_global(a.hot.st.angle)[i] = r.p.th;
+    as_global(a.hot.st.v)[i] = r.v;
+    as_global(a.hot.st.w)[i] = r.w;
     if (tri) {
-        a.S->st.steer[i] = r.steer;
-        a.S->st.wheel[i] = r.wheel;
+        as_global(a.hot.st.steer)[i] = r.steer;
+        as_global(a.hot.st.wheel)[i] = r.wheel;
     }
-    a.S->st.min_dist[i] = min_dist;
-    a.S->st.target_idx[i] = target;
-    a.S->st.cur_iter[i] = iter;
-    a.S->st.collided[i] = (uint8_t)collided;
+    as_global(a.hot.st.min_dist)[i] = min_dist;
+    as_global(a.hot.st.target_idx)[i] = target;
+    as_global(a.hot.st.cur_iter)[i] = iter;
+    as_global(a.hot.st.collided)[i] = (uint8_t)collided;
     if (pose_delay) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) a.S->st.pose_seen[c * n + i] = seen[c];
@@ -795,27 +799,27 @@ __device__ __forceinline__ void load_env(const A& a, uint64_t seed, uint64_t ste
 {
     const DevParams& P = a.S->P;
     Robot& r = q.r;
-    r.p.x = a.hot.st.x[i];
-    r.p.y = a.hot.st.y[i];
-    r.p.th = a.hot.st.angle[i];
-    r.v = a.hot.st.v[i];
-    r.w = a.hot.st.w[i];
+    r.p.x = as_global(a.hot.st.x)[i];
+    r.p.y = as_global(a.hot.st.y)[i];
+    r.p.th = as_global(a.hot.st.angle)[i];
+    r.v = as_global(a.hot.st.v)[i];
+    r.w = as_global(a.hot.st.w)[i];
     const bool tri = a.hot.model == BCP_MODEL_TRICYCLE;
-    r.steer = tri ? a.hot.st.steer[i] : 0.0;
-    r.wheel = tri ? a.hot.st.wheel[i] : 0.0;
-    q.min_dist = a.hot.st.min_dist[i];
-    q.target = a.hot.st.target_idx[i];
-    q.iter = a.hot.st.cur_iter[i];
-    q.collided = a.hot.st.collided[i] != 0;
-    q.geom = a.hot.geom_of_env ? a.hot.geom_of_env[i] : 0;
+    r.steer = tri ? as_global(a.hot.st.steer)[i] : 0.0;
+    r.wheel = tri ? as_global(a.hot.st.wheel)[i] : 0.0;
+    q.min_dist = as_global(a.hot.st.min_dist)[i];
+    q.target = as_global(a.hot.st.target_idx)[i];
+    q.iter = as_global(a.hot.st.cur_iter)[i];
+    q.collided = as_global(a.hot.st.collided)[i] != 0;
+    q.geom = a.hot.geom_of_env ? as_global(a.hot.geom_of_env)[i] : 0;
     if (a.flags & BCP_STEP_ACTIONS_F32) {
-        const float2 c = reinterpret_cast<const float2*>(a.actions)[i];
-        cmd0 = (double)c.x;
-        cmd1 = (double)c.y;
+        const GlobalPtr<const float> c = as_global(reinterpret_cast<const float*>(a.actions)) + 2 * i;   // (one 8-byte load)
+        cmd0 = (double)c[0];
+        cmd1 = (double)c[1];
     } else {
-        const double2 c = reinterpret_cast<const double2*>(a.actions)[i];
-        cmd0 = c.x;
-        cmd1 = c.y;
+        const GlobalPtr<const double> c = as_global(reinterpret_cast<const double*>(a.actions)) + 2 * i;   // (one 16-byte load)
+        cmd0 = c[0];
+        cmd1 = c[1];
     }
     if (!PLAIN && P.control_delay && active) {   // the robot executes the command given control_delay steps ago (env.py:371-373)
         double cmd[2] = {cmd0, cmd1};
@@ -830,9 +834,9 @@ __device__ __forceinline__ void load_env(const A& a, uint64_t seed, uint64_t ste
     q.z[0] = q.z[1] = q.z[2] = 0.0;
     if (P.noise_on) {
         if (a.noise_z) {
-            q.z[0] = a.noise_z[3 * i + 0];
-            q.z[1] = a.noise_z[3 * i + 1];
-            q.z[2] = a.noise_z[3 * i + 2];
+            q.z[0] = as_global(a.noise_z)[3 * i + 0];
+            q.z[1] = as_global(a.noise_z)[3 * i + 1];
+            q.z[2] = as_global(a.noise_z)[3 * i + 2];
         } else {
             device_normals(seed, (uint64_t)(a.S->env_id_base + i), step_counter, q.z);
         }
@@ -1051,7 +1055,7 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
         sc.rew = hand_score[lane];
         sc.min_dist = hand_score[kBlock + lane];
         sc.target = (int)hand_score[2 * kBlock + lane];
-        finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &sc);
+        finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, !(a.flags & kAblateNoReward), sc);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) a.tick[1] = a.step_counter;   // for kernel 2 (see StepArgs::tick)
     advance_step_by_ticket(a);   // (only when no kernel 2 follows)
@@ -1210,13 +1214,13 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     DIAG_STAMP(0);
     // staging: footprint vertices, the shared path with its bounding box and bucket index, the counters
     if (tid < nq) qv[tid] = P.qverts[tid >> 1][tid & 1];
-    for (int k = tid; k < npath; k += kLocalWaves * kBlock) qv[nq + k] = a.hot.path_pts[k];
+    for (int k = tid; k < npath; k += kLocalWaves * kBlock) qv[nq + k] = as_global(a.hot.path_pts)[k];
     if (a.hot.path_shared) {
         if (tid >= 512 && tid < 520) lds_box[tid - 512] = a.hot.path_bbox[tid - 512];
         if (tid >= 576 && tid < 576 + 128) lds_index[tid - 576] = reinterpret_cast<const uint32_t*>(a.hot.path_index)[tid - 576];
     }
     if (tid >= 960 && tid < 964) ctl[tid - 960] = 0;
-    for (int k = tid; k < map_words; k += kLocalWaves * kBlock) lds_map[k] = a.hot.map_bits[k];   // (read after the barriers)
+    for (int k = tid; k < map_words; k += kLocalWaves * kBlock) lds_map[k] = as_global(a.hot.map_bits)[k];   // (read after the barriers)
 
     const int64_t gi = (int64_t)blockIdx.x * kLocalEnvs + pair * kBlock + lane;
     const bool active = gi < a.hot.n;
@@ -1229,10 +1233,10 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     if (mover) {
         load_env<PLAIN>(a, seed, step_counter, i, active, q, cmd0, cmd1);
     } else if (scanner) {
-        q.min_dist = a.hot.st.min_dist[i];
-        q.target = a.hot.st.target_idx[i];
-        q.geom = a.hot.geom_of_env ? a.hot.geom_of_env[i] : 0;
-        q.collided = PLAIN ? 0 : (int32_t)(a.hot.st.collided[i] != 0);
+        q.min_dist = as_global(a.hot.st.min_dist)[i];
+        q.target = as_global(a.hot.st.target_idx)[i];
+        q.geom = a.hot.geom_of_env ? as_global(a.hot.geom_of_env)[i] : 0;
+        q.collided = PLAIN ? 0 : (int32_t)(as_global(a.hot.st.collided)[i] != 0);
         if (!a.hot.path_shared) {
             const int64_t g = a.hot.geom_of_env ? (int64_t)q.geom : i;
 #pragma unroll
@@ -1320,10 +1324,32 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             hand_score[2 * kBlock + lane] = (double)target;
         }
     }
-    DIAG_STAMP(4);        // mover: classified
+    // (4) movers park the undecided envs in LDS right away (one LDS atomic per wave hands out the slots); the reward
+    //     provider's result follows after the barrier
+    __attribute__((address_space(3))) ParkedLocal* my_rec = rec;
+    if (mover) {
+        const uint64_t parking = __ballot(park);
+        if (parking) {
+            const int first = (int)__ffsll((unsigned long long)parking) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd((int*)&ctl[0], (int)__popcll(parking));
+            base = bcast_i(base, first);
+            if (park) {
+                my_rec = rec + base + (int)__popcll(parking & ((1ull << lane) - 1ull));
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass has no copy operators for address-space-qualified structs)
+                my_rec->q = q;
+#endif
+                my_rec->sc_ready = 0;
+            }
+        }
+    }
+    DIAG_STAMP(4);        // mover: classified and parked
     DIAG_STAMP_W(4, 8);   // scorer of pair 0: scanned
     __syncthreads();
     DIAG_STAMP(5);
+    const int n_parked = __builtin_amdgcn_readfirstlane(ctl[0]);   // (scalar: the ticket loop below must stay wave-uniform)
+    // (5) movers: the rest of the reward provider, handed to the parked records, then the decided envs are finished;
+    //     everybody else goes straight to the parked poses
     ScoredFree sc;
     sc.rew = 0.0;
     sc.min_dist = 0.0;
@@ -1346,31 +1372,18 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             sc.min_dist = hand_score[kBlock + lane];
             sc.target = (int)hand_score[2 * kBlock + lane];
         }
-        // (4) park the undecided envs in LDS: one LDS atomic per wave hands out the slots
-        const uint64_t parking = __ballot(park);
-        if (parking) {
-            const int first = (int)__ffsll((unsigned long long)parking) - 1;
-            int base = 0;
-            if (lane == first) base = atomicAdd((int*)&ctl[0], (int)__popcll(parking));
-            base = bcast_i(base, first);
-            if (park) {
-                __attribute__((address_space(3))) ParkedLocal* e = rec + base + (int)__popcll(parking & ((1ull << lane) - 1ull));
-#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass has no copy operators for address-space-qualified structs)
-                e->q = q;
-                e->sc = sc;
-#else
-                (void)e;
-#endif
-            }
+        if (park) {
+            my_rec->sc.rew = sc.rew;
+            my_rec->sc.min_dist = sc.min_dist;
+            my_rec->sc.target = sc.target;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (LDS operations of a wave complete in order)
+            __hip_atomic_store(&my_rec->sc_ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        DIAG_STAMP(6);    // mover: scores handed over
+        if (active && !park)
+            finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, !(a.flags & kAblateNoReward), sc);
     }
-    DIAG_STAMP(6);        // mover: parked
-    __syncthreads();
-    DIAG_STAMP_W(8, 9);   // helper: past the third barrier
-    const int n_parked = __builtin_amdgcn_readfirstlane(ctl[0]);   // (scalar: the ticket loop below must stay wave-uniform)
-    // (5) movers finish their decided envs; every wave then settles parked poses, a ticket at a time
-    if (mover && active && !park)
-        finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &sc);
+    DIAG_STAMP_W(8, 9);   // helper: past the second barrier
     const double vqx = lane < P.n_verts ? qv[2 * lane] : 0.0, vqy = lane < P.n_verts ? qv[2 * lane + 1] : 0.0;   // (row-by-row fallback)
     // (Control flow: ONE single-lane region per iteration -- lane 0 finishes the env and draws the next ticket in the same
     //  block -- and a scalar loop condition.  With the draw at the top of the body, i.e. two `if (lane == 0)` regions per
@@ -1394,8 +1407,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             const int verdict = map_words
                 ? coop_collides_sparse<WIDE>(P, (LdsF64)qv, c, s, px, py, (LdsWords)lds_map, a.hot.map_rows, a.hot.map_cols,
                                              a.hot.map_wpr, cell_list)
-                : coop_collides_sparse<WIDE>(P, (LdsF64)qv, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr,
-                                             cell_list);
+                : coop_collides_sparse<WIDE>(P, (LdsF64)qv, c, s, px, py, as_global(words), a.hot.map_rows, a.hot.map_cols,
+                                             a.hot.map_wpr, cell_list);
             h = verdict == kSparseHit;
             if (verdict == kSparseTooMany)
                 h = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr);
@@ -1403,13 +1416,16 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         DIAG_STAMP_W(8, 11);   // helper: verdict
         int next = 0;
         if (lane == 0) {
+            // (the mover wrote the reward provider's result into the record a few hundred cycles after the barrier)
+            while (__hip_atomic_load(&e->sc_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             Pending pq;
             ScoredFree psc;
 #if defined(__HIP_DEVICE_COMPILE__)
             pq = e->q;
             psc = e->sc;
 #endif
-            finalize_env<PLAIN>(a, env, pq, h, lds_path, nullptr, (a.flags & kAblateNoReward) ? nullptr : &psc);
+            finalize_env<PLAIN>(a, env, pq, h, lds_path, nullptr, !(a.flags & kAblateNoReward), psc);
             next = atomicAdd((int*)&ctl[1], 1);
         }
         ticket = __builtin_amdgcn_readfirstlane(next);
