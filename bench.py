@@ -212,6 +212,20 @@ def steady_state(env, pool, rng):
     torch.cuda.synchronize()
 
 
+def make_c4_env(n, device, seed=11):
+    """BASELINE.json configs[3]: n AisleTurnEnv replicas (10 m / 256 px, the four flip variants) with PRIVATE costmaps stored
+    uint8 [n, 256, 256] (valid 256 x 141) and private 130-point paths, tricycle + PlanEnv noise, reset on done."""
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    G = os.path.join(ROOT, "tests", "golden")
+    names = ["g8_traj_aisle_c4_00.npz", "g8_traj_aisle_c4_10.npz", "g8_traj_aisle_c4_01.npz", "g8_traj_aisle_c4_11.npz"]
+    gs = [np.load(os.path.join(G, nm)) for nm in names]
+    res = float(gs[0]["resolution"])
+    params = EnvParams(resolution=res, refine_path=False)
+    cms = [CostMap2D(x["costmap"], res, x["origin"]) for x in gs]
+    return BatchedPlanEnv(cms, [x["path"] for x in gs], params, n_envs=n, auto_reset=True, template_of_env=np.arange(n) % 4,
+                          map_storage=(256, 256), device=device, seed=seed)
+
+
 def aux_other_configs(device):
     """BASELINE.json configs[1] (C2) and configs[3] (C4), informational lines with their own roofline objects."""
     import torch
@@ -241,16 +255,9 @@ def aux_other_configs(device):
     env.close()
     del env, pool
     # ---- C4: 65 536 AisleTurn envs, PRIVATE costmaps stored [N, 256, 256] (valid 256 x 141) and private 130-point paths
-    names = ["g8_traj_aisle_c4_00.npz", "g8_traj_aisle_c4_10.npz", "g8_traj_aisle_c4_01.npz", "g8_traj_aisle_c4_11.npz"]
-    gs = [np.load(os.path.join(G, nm)) for nm in names]
-    res = float(gs[0]["resolution"])
     n = ENVS_PER_GPU
-    idx = np.arange(n) % 4
-    params = EnvParams(resolution=res, refine_path=False)
-    cms = [CostMap2D(x["costmap"], res, x["origin"]) for x in gs]
     t0 = time.perf_counter()
-    env = BatchedPlanEnv(cms, [x["path"] for x in gs], params, n_envs=n, auto_reset=True, template_of_env=idx,
-                         map_storage=(256, 256), device=device, seed=11)
+    env = make_c4_env(n, device)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t0
     pool = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(8)])).to(env.device)

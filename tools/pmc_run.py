@@ -7,10 +7,7 @@ n = 65536
 env, g = bench.make_env(n, 0, 0, 2024)
 rng = np.random.RandomState(1234)
 pool = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(16)])).cuda()
-env.state.current_iter.copy_(torch.from_numpy(rng.randint(0, 1200, n).astype(np.int32)).cuda())
-for k in range(1200):
-    env.step(pool[k % 16])
-torch.cuda.synchronize()
+bench.steady_state(env, pool, rng)
 for k in range(40):
     env.step(pool[k % 16])
 torch.cuda.synchronize()
