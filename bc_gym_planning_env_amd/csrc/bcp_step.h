@@ -1233,7 +1233,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     if (mover) {
         load_env<PLAIN>(a, seed, step_counter, i, active, q, cmd0, cmd1);
     } else if (scanner) {
-        q.min_dist = as_global(a.hot.st.min_dist)[i];
+        if (!PLAIN) q.min_dist = as_global(a.hot.st.min_dist)[i];   // (PLAIN: the scan only needs the target index)
         q.target = as_global(a.hot.st.target_idx)[i];
         q.geom = a.hot.geom_of_env ? as_global(a.hot.geom_of_env)[i] : 0;
         q.collided = PLAIN ? 0 : (int32_t)(as_global(a.hot.st.collided)[i] != 0);

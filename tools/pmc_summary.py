@@ -43,7 +43,7 @@ wf = (factors.get("calib_step", {}).get("write_factor") or 1.0)
 raw = passes(work, ("step_", "copyBuffer", "robot_step_kernel"))
 per, total = {}, 0.0
 for name, v in raw.items():
-    if name.startswith("step_") or "step_f" in name or "step_p" in name or "step_k" in name:
+    if name.startswith("step_"):   # the step kernels proper (robot_step_kernel / copyBuffer are calibration launches)
         rd = v.get("FETCH_SIZE", (0, 0.0))[1] * 1024.0 * rf
         wr = v.get("WRITE_SIZE", (0, 0.0))[1] * 1024.0 * wf
         per[name] = {"launches": v.get("FETCH_SIZE", (0, 0))[0], "read": rd, "write": wr, "total": rd + wr}
