@@ -641,12 +641,14 @@ struct ScoredFree {
     int target;
 };
 
-// One env's parked record of the single-launch step (LDS): the state after the robot model + the scorer wave's result
-struct ParkedLocal {
-    Pending q;
-    ScoredFree sc;       // written by the mover once the scan results are in (after the record itself) ...
-    int32_t sc_ready;    // ... and then announced here
-    int32_t pad_;
+// A parked pose of the single-launch step (LDS): what the exact test needs, and its verdict.  The env's state stays in
+// the registers of the mover lane that parked it; that lane finishes the env once the verdict is in.
+struct ParkedPose {
+    double c, s;             // cos / sin of the new heading
+    int32_t px, py;          // world_to_pixel of the new position
+    int32_t env_lo, env_hi;  // env index (private maps: the map entry)
+    int32_t geom;            // geometry-pool entry
+    int32_t verdict;         // 0 = pending, 1 = free, 2 = collides
 };
 
 // entry of the non-shared map / path arrays that env i uses
@@ -1151,11 +1153,14 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
 // So nothing leaves the CU here:
 //   * a workgroup = 256 envs = 4 (mover, scorer) wave pairs as in step_fast_pair_kernel + 8 helper waves: 16 waves, one
 //     workgroup per CU, four waves per SIMD;
-//   * movers park the records of their undecided envs (state after the robot model + the scorer's result) in LDS;
-//   * after the third barrier ALL 16 waves draw tickets (an LDS counter) and settle one parked pose each -- exact test
-//     through the single-wave rasteriser, then the env's finalisation (rollback on a hit, reward, done, reset, stores) by
-//     lane 0 -- while the movers first finish their decided envs.  With ~4 parked poses per 256 envs and 16 waves the
-//     exact tests of a workgroup run side by side, right after the classification, on a warm CU.
+//   * movers park the POSES of their undecided envs in LDS (40 bytes each; the env's state stays in the mover lane's
+//     registers) before the second barrier;
+//   * after it ALL 16 waves draw tickets (an LDS counter) and settle one parked pose each -- the exact test, cell by cell
+//     (coop_collides_sparse) -- and post the verdict in the record, while the movers first finish their decided envs;
+//   * a mover lane that parked an env waits for its verdict (a few hundred cycles, LDS) and finishes the env itself:
+//     rollback on a hit, reward, done, in-kernel reset, stores -- in SIMD with the wave's other parked lanes.
+//     With ~4 parked poses per 256 envs and 16 waves the exact tests of a workgroup run side by side, right after the
+//     classification, on a warm CU.
 // No queue, no atomic in global memory, no poll, no second launch; load balance comes from the workgroup being large
 // (the sum of 256 envs' luck) and from the helper waves.
 constexpr int kLocalPairs = 4;
@@ -1173,7 +1178,7 @@ static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles, int staged
     bytes += 2 * kBlock * sizeof(uint32_t);          // bucket index of the shared path
     bytes += 4 * sizeof(int32_t);                    // parked count, ticket counter
     bytes = (bytes + 15) & ~(size_t)15;
-    bytes += (size_t)kLocalEnvs * sizeof(ParkedLocal);
+    bytes += (size_t)kLocalEnvs * sizeof(ParkedPose);
     bytes += (size_t)kLocalWaves * kSparseLdsWords * sizeof(uint32_t);   // a cell list per wave (coop_collides_sparse)
     return bytes + (size_t)staged_map_words * sizeof(uint32_t);
 }
@@ -1205,8 +1210,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     __attribute__((address_space(3))) int32_t* ctl = (__attribute__((address_space(3))) int32_t*)(lds_index + 2 * kBlock);   // [4]
     const uint32_t rec_off = (uint32_t)((((size_t)(nq + npath + kLocalPairs * 6 * kBlock + 8) * sizeof(double) +
                                           2 * kBlock * sizeof(uint32_t) + 4 * sizeof(int32_t)) + 15) & ~(size_t)15);
-    __attribute__((address_space(3))) ParkedLocal* rec =
-        (__attribute__((address_space(3))) ParkedLocal*)((__attribute__((address_space(3))) char*)lds_dyn + rec_off);
+    __attribute__((address_space(3))) ParkedPose* rec =
+        (__attribute__((address_space(3))) ParkedPose*)((__attribute__((address_space(3))) char*)lds_dyn + rec_off);
     const LdsU32 cell_list = (LdsU32)(rec + kLocalEnvs) + wave * kSparseLdsWords;
     const LdsU32 lds_map = (LdsU32)(rec + kLocalEnvs) + kLocalWaves * kSparseLdsWords;
     const int map_words = a.hot.map_shared && a.hot.map_rows * a.hot.map_wpr <= kLocalMapWords ? a.hot.map_rows * a.hot.map_wpr : 0;
@@ -1324,9 +1329,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             hand_score[2 * kBlock + lane] = (double)target;
         }
     }
-    // (4) movers park the undecided envs in LDS right away (one LDS atomic per wave hands out the slots); the reward
-    //     provider's result follows after the barrier
-    __attribute__((address_space(3))) ParkedLocal* my_rec = rec;
+    // (4) movers park the undecided poses in LDS right away (one LDS atomic per wave hands out the slots)
+    __attribute__((address_space(3))) ParkedPose* my_rec = rec;
     if (mover) {
         const uint64_t parking = __ballot(park);
         if (parking) {
@@ -1336,10 +1340,14 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             base = bcast_i(base, first);
             if (park) {
                 my_rec = rec + base + (int)__popcll(parking & ((1ull << lane) - 1ull));
-#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass has no copy operators for address-space-qualified structs)
-                my_rec->q = q;
-#endif
-                my_rec->sc_ready = 0;
+                my_rec->c = q.c;
+                my_rec->s = q.s;
+                my_rec->px = q.px;
+                my_rec->py = q.py;
+                my_rec->env_lo = q.env_lo;
+                my_rec->env_hi = q.env_hi;
+                my_rec->geom = q.geom;
+                my_rec->verdict = 0;
             }
         }
     }
@@ -1372,20 +1380,14 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             sc.min_dist = hand_score[kBlock + lane];
             sc.target = (int)hand_score[2 * kBlock + lane];
         }
-        if (park) {
-            my_rec->sc.rew = sc.rew;
-            my_rec->sc.min_dist = sc.min_dist;
-            my_rec->sc.target = sc.target;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (LDS operations of a wave complete in order)
-            __hip_atomic_store(&my_rec->sc_ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        DIAG_STAMP(6);    // mover: scores handed over
+        DIAG_STAMP(6);    // mover: reward provider done
         if (active && !park)
             finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, !(a.flags & kAblateNoReward), sc);
     }
     DIAG_STAMP_W(8, 9);   // helper: past the second barrier
     const double vqx = lane < P.n_verts ? qv[2 * lane] : 0.0, vqy = lane < P.n_verts ? qv[2 * lane + 1] : 0.0;   // (row-by-row fallback)
-    // (Control flow: ONE single-lane region per iteration -- lane 0 finishes the env and draws the next ticket in the same
+    // (6) every wave settles parked poses, a ticket at a time: exact test, verdict into the record.
+    // (Control flow: ONE single-lane region per iteration -- lane 0 posts the verdict and draws the next ticket in the same
     //  block -- and a scalar loop condition.  With the draw at the top of the body, i.e. two `if (lane == 0)` regions per
     //  trip, hipcc 7.2 threaded lane 0's path across the back edge and split the loop in two; lanes 1..63 then span in the
     //  inner one on ticket 0 for ever while lane 0 waited outside it.)
@@ -1395,11 +1397,11 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     while (ticket < n_parked) {
         DIAG_STAMP_W(8, 10);   // helper: has a ticket
-        const __attribute__((address_space(3))) ParkedLocal* e = rec + ticket;
-        const double c = e->q.c, s = e->q.s;
-        const int px = e->q.px, py = e->q.py;
-        const int64_t env = ((int64_t)e->q.env_hi << 32) | (uint32_t)e->q.env_lo;
-        const int64_t g = a.hot.map_shared ? 0 : (a.hot.geom_of_env ? (int64_t)e->q.geom : env);
+        __attribute__((address_space(3))) ParkedPose* e = rec + ticket;
+        const double c = e->c, s = e->s;
+        const int px = e->px, py = e->py;
+        const int64_t env = ((int64_t)e->env_hi << 32) | (uint32_t)e->env_lo;
+        const int64_t g = a.hot.map_shared ? 0 : (a.hot.geom_of_env ? (int64_t)e->geom : env);
         const uint32_t* words = a.hot.map_bits + g * a.hot.map_env_stride;
         bool h = false;
         if (!(a.flags & kAblateNoCoop)) {
@@ -1416,20 +1418,21 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         DIAG_STAMP_W(8, 11);   // helper: verdict
         int next = 0;
         if (lane == 0) {
-            // (the mover wrote the reward provider's result into the record a few hundred cycles after the barrier)
-            while (__hip_atomic_load(&e->sc_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            Pending pq;
-            ScoredFree psc;
-#if defined(__HIP_DEVICE_COMPILE__)
-            pq = e->q;
-            psc = e->sc;
-#endif
-            finalize_env<PLAIN>(a, env, pq, h, lds_path, nullptr, !(a.flags & kAblateNoReward), psc);
+            __hip_atomic_store(&e->verdict, h ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             next = atomicAdd((int*)&ctl[1], 1);
         }
         ticket = __builtin_amdgcn_readfirstlane(next);
-        DIAG_STAMP_W(8, 12);   // helper: env finished
+        DIAG_STAMP_W(8, 12);   // helper: verdict posted
+    }
+    // (7) movers: the envs they parked are finished by the lane that holds their state, as soon as the verdicts are in
+    //     (every parked pose has been claimed by now -- by this wave or by one that is working on it)
+    if (mover && __ballot(park)) {
+        int verdict = park ? 0 : 1;
+        while (__ballot(verdict == 0)) {
+            if (verdict == 0) verdict = __hip_atomic_load(&my_rec->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (park) finalize_env<PLAIN>(a, i, q, verdict == 2, lds_path, nullptr, !(a.flags & kAblateNoReward), sc);
     }
     DIAG_STAMP(13);            // mover: out of tickets
     DIAG_STAMP_W(8, 14);       // helper: out of tickets

@@ -20,7 +20,7 @@ L.bcp_diag_read(buf)
 a = np.array(buf[:]).reshape(4096, 16).astype(np.int64)[:n // 256]
 t0 = a[:, 0].min()
 names = {1: "mover: loads issued .. robot model starts", 2: "mover: robot model done", 3: "mover: past barrier 1",
-         4: "mover: classified and parked", 5: "mover: past barrier 2", 6: "mover: scores handed over", 7: "mover: decided envs finished",
+         4: "mover: classified and parked", 5: "mover: past barrier 2", 6: "mover: reward provider done", 7: "mover: decided envs finished",
          13: "mover: out of tickets", 8: "scorer: scanned", 9: "helper: past barrier 2", 14: "helper: out of tickets"}
 print("workgroups %d; start skew (stamp 0 - earliest): median %d max %d cycles" % (len(a), np.median(a[:, 0] - t0), (a[:, 0] - t0).max()))
 for k in (1, 2, 3, 8, 4, 5, 6, 9, 7, 13, 14):
@@ -29,7 +29,7 @@ for k in (1, 2, 3, 8, 4, 5, 6, 9, 7, 13, 14):
 had = a[:, 10] > a[:, 0]
 print("helper wave 8 had a ticket in %d of %d workgroups; parked poses per workgroup: mean %.2f max %d" % (had.sum(), len(a), a[:, 15].mean(), a[:, 15].max()))
 h = a[had] if had.any() else a[:1]
-print("  helper: ticket -> verdict  median %d  p90 %d ;  verdict -> env finished  median %d  p90 %d" % (
+print("  helper: ticket -> verdict  median %d  p90 %d ;  verdict -> verdict posted  median %d  p90 %d" % (
     np.median(h[:, 11] - h[:, 10]), np.percentile(h[:, 11] - h[:, 10], 90), np.median(h[:, 12] - h[:, 11]), np.percentile(h[:, 12] - h[:, 11], 90)))
 end = np.maximum(a[:, 13], a[:, 14]) - t0
 print("workgroup end since the earliest start: median %d  p90 %d  max %d cycles" % (np.median(end), np.percentile(end, 90), end.max()))
