@@ -100,6 +100,7 @@ SYMBOLS = {
     "bcp_sample_mini_worlds": (C.c_int, [_H, C.POINTER(BcpMiniWorldParams), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcp_get_distance_field": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "bcp_get_near_field": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "bcp_plan_mini_worlds": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcp_refresh_mini_worlds": (C.c_int, [_H, C.POINTER(BcpMiniWorldParams)] + [C.c_void_p] * 6 + [C.c_double] +
                                 [C.c_void_p] * 3),

@@ -582,6 +582,20 @@ class BatchedPlanEnv(object):
         _lib.check(self._lib.bcp_get_distance_field(self._h, int(first), int(count), out.data_ptr(), shape, self._stream()))
         return out, int(shape[2]), int(shape[3])
 
+    def near_field(self, first=0, count=1):
+        """The 1-bit form of the distance fields the step's outer test reads (bcp_get_near_field), unpacked:
+        (bool device tensor [count, rows + 2 pad, cols + 2 pad] -- True where the field is < t_out --, t_out)."""
+        shape = (C.c_int32 * 3)()
+        _lib.check(self._lib.bcp_get_near_field(self._h, 0, 0, None, shape, None))
+        ty, tx, t_out = int(shape[0]), int(shape[1]), int(shape[2])
+        words = torch.empty((int(count), ty, tx, 32), dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.bcp_get_near_field(self._h, int(first), int(count), words.data_ptr(), shape, self._stream()))
+        dshape = (C.c_int32 * 4)()
+        _lib.check(self._lib.bcp_get_distance_field(self._h, 0, 0, None, dshape, None))
+        bits = (words.unsqueeze(-1) >> torch.arange(32, device=self.device, dtype=torch.int32)) & 1   # [count, ty, tx, 32 rows, 32 bits]
+        cells = bits.permute(0, 1, 3, 2, 4).reshape(int(count), ty * 32, tx * 32)
+        return cells[:, :dshape[0], :dshape[1]].bool(), t_out
+
     # ------------------------------------------------------------------ per-env lookups
     def path_of(self, i):
         if self.geom_of_env is not None:

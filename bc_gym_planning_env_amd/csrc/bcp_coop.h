@@ -36,6 +36,12 @@ struct CullDesc {
     int32_t t_in[kMaxSamples];   // hit <=  edt <= t_in[j] at inner sample j
     double out_x[kMaxSamples], in_x[kMaxSamples];  // sample abscissae on the robot axis, in pixels
     double axis_y;        // ordinate of the sample axis in the robot frame, in pixels
+    // The outer test only asks "is a lethal cell closer than t_out": the field as ONE BIT per cell, in tiles of
+    // 32 x 32 cells (32 row words = one 128-byte line each; the samples of a pose lie on a line of <= 2 reach px, so
+    // they meet three to five lines instead of one each).  word = near[((y >> 5) * near_tx + (x >> 5)) * 32 + (y & 31)]
+    const uint32_t* near;
+    int64_t near_stride;  // words per env (0: shared)
+    int32_t near_tx, near_words;   // tiles per tile row; words of one entry
 };
 
 enum { kFree = 0, kHit = 1, kAmbiguous = 2 };
@@ -99,6 +105,31 @@ __device__ __forceinline__ OuterLookups outer_lookups_issue(const CullDesc& C, i
         const bool stored = !L.off_map && i < C.n_out && (unsigned)x < (unsigned)C.width && (unsigned)y < (unsigned)C.height;
         L.val[i] = stored ? (int)field[y * C.width + x] : (i < C.n_out ? not_stored : 255);
     }
+    return L;
+}
+
+// the same lookups from the 1-bit tiles (CullDesc::near) of this pose's map entry, in global memory or staged in LDS
+template <typename WordPtr>
+__device__ __forceinline__ OuterLookups outer_lookups_near(const CullDesc& C, WordPtr tiles, int rows, int cols, int px, int py,
+                                                           double c, double s)
+{
+    OuterLookups L;
+    L.off_map = px + C.reach < 0 || px - C.reach >= cols || py + C.reach < 0 || py - C.reach >= rows;
+    const double ay_c = C.axis_y * c, ay_s = C.axis_y * s;
+    const int not_stored = min(C.pad + 1, 255);
+    uint32_t word[kMaxSamples];
+    int bit[kMaxSamples];
+#pragma unroll
+    for (int i = 0; i < kMaxSamples; ++i) {
+        const int du = (int)rint(C.out_x[i] * c - ay_s), dv = (int)rint(C.out_x[i] * s + ay_c);
+        const int x = px + C.pad + du, y = py + C.pad + dv;
+        const bool stored = !L.off_map && i < C.n_out && (unsigned)x < (unsigned)C.width && (unsigned)y < (unsigned)C.height;
+        bit[i] = stored ? (x & 31) : -1;
+        word[i] = stored ? tiles[((y >> 5) * C.near_tx + (x >> 5)) * 32 + (y & 31)] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxSamples; ++i)   // as the byte field reads: 0 = closer than t_out, 255 = not
+        L.val[i] = bit[i] >= 0 ? (((word[i] >> bit[i]) & 1u) ? 0 : 255) : (i < C.n_out ? not_stored : 255);
     return L;
 }
 

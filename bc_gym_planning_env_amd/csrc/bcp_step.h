@@ -74,6 +74,7 @@ struct StepHot {
     const int16_t* path_index;
     struct Pending* pending;
     const uint32_t* map_bits;
+    const uint32_t* near;
     int64_t map_env_stride;
     int32_t model, lds_path_doubles, path_shared, pending_cap;
     int32_t map_rows, map_cols, map_wpr, map_shared;
@@ -1278,8 +1279,14 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         const int64_t map_env = a.S->map.shared ? 0 : g;
         OuterLookups look;
         look.off_map = true;
-        if (!(a.flags & (kAblateNoCollision | kAblateNoClassify)))
-            look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
+        if (!(a.flags & (kAblateNoCollision | kAblateNoClassify))) {
+            // (a shared field is 18 KB for the 183 x 183 map and stays in the CU's L1: a copy in LDS measured no faster)
+            if (a.hot.near)
+                look = outer_lookups_near(a.S->cull, as_global(a.hot.near) + map_env * a.S->cull.near_stride, a.S->map.rows,
+                                          a.S->map.cols, px, py, c, s);
+            else
+                look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
+        }
         const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
         if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
             park = true;

@@ -69,6 +69,8 @@ struct bcp_handle {
     size_t edt_bytes;
     uint8_t* edt_col;      // owned scratch of the transform
     size_t edt_col_bytes;
+    uint32_t* near;        // owned: the field as 1-bit tiles (CullDesc::near)
+    size_t near_bytes;
     MapDesc map;
     CullDesc cull;
     PathDesc path;
@@ -414,6 +416,36 @@ __global__ void edt_rows_kernel(const uint8_t* __restrict__ g, EntrySelect sel, 
     const int64_t per = (int64_t)W * H, total = sel.size() * per;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x)
         edt_cell(g, sel.entry(it / per) * per + it % per, W, clamp, out);
+}
+
+// The distance field as one bit per cell, "a lethal cell is closer than t_out", in 32 x 32-cell tiles (CullDesc::near):
+// all the outer test of the step asks.  One thread per output word = 32 consecutive cells of one row.
+typedef uint32_t __attribute__((aligned(1))) EdtUnalignedWord;
+__global__ void near_tiles_kernel(const uint8_t* __restrict__ edt, EntrySelect sel, int W, int H, int tiles_x, int tiles_y,
+                                  int t_out, uint32_t* __restrict__ tiles)
+{
+    const int64_t per = (int64_t)tiles_x * tiles_y * 32, total = sel.size() * per;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int tx = (int)(it % tiles_x);
+        const int64_t t = it / tiles_x;
+        const int y = (int)(t % (tiles_y * 32));
+        const int64_t e = sel.entry(t / (tiles_y * 32));
+        uint32_t word = 0;
+        if (y < H) {
+            const uint8_t* row = edt + (e * H + y) * (int64_t)W + tx * 32;
+            if (tx * 32 + 32 <= W) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t four = *reinterpret_cast<const EdtUnalignedWord*>(row + 4 * k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) word |= (uint32_t)((int)((four >> (8 * j)) & 255u) < t_out) << (4 * k + j);
+                }
+            } else {
+                for (int j = 0; tx * 32 + j < W; ++j) word |= (uint32_t)((int)row[j] < t_out) << j;
+            }
+        }
+        tiles[e * per + ((int64_t)(y >> 5) * tiles_x + tx) * 32 + (y & 31)] = word;
+    }
 }
 
 // The same transform for maps that fit into LDS (every private / pool map), one workgroup per map, `clamp` <= 60:
@@ -916,6 +948,7 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->path_index) (void)hipFree(h->path_index);
     if (h->edt) (void)hipFree(h->edt);
     if (h->edt_col) (void)hipFree(h->edt_col);
+    if (h->near) (void)hipFree(h->near);
     if (h->pending) (void)hipFree(h->pending);
     if (h->tick) (void)hipFree(h->tick);
     if (h->pending_count) (void)hipFree(h->pending_count);
@@ -1003,6 +1036,15 @@ static void launch_pack_bitmap(bcp_handle* h, EntrySelect sel, int64_t max_entri
                        h->bitmap, sel, m.rows, m.cols, m.wpr, h->map_valid_rows, h->map_valid_cols);
 }
 
+static void launch_near_tiles(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
+{
+    const CullDesc& C = h->cull;
+    if (!C.near) return;
+    const int tiles_y = C.near_words / (32 * C.near_tx);
+    hipLaunchKernelGGL(near_tiles_kernel, dim3(stride_grid(max_entries * C.near_words, 256, sel.list != nullptr)), dim3(256), 0, s,
+                       h->edt, sel, C.width, C.height, C.near_tx, tiles_y, C.t_out, h->near);
+}
+
 static void launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
 {
     const MapDesc& m = h->map;
@@ -1016,12 +1058,14 @@ static void launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_en
         const int64_t blocks = std::min<int64_t>(max_entries, sel.list ? 2048 : 16384);
         hipLaunchKernelGGL(edt_lds_kernel, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), lds, s, h->bitmap, sel,
                            m.rows, m.cols, m.wpr, C.pad, C.clamp, h->edt);
+        launch_near_tiles(h, sel, max_entries, s);
         return;
     }
     hipLaunchKernelGGL(edt_columns_kernel, dim3(stride_grid(max_entries * C.width, 64, sel.list != nullptr)), dim3(64), 0, s, h->bitmap, sel, m.rows,
                        m.cols, m.wpr, C.pad, C.clamp, h->edt_col);
     hipLaunchKernelGGL(edt_rows_kernel, dim3(stride_grid(max_entries * C.width * C.height, 256, sel.list != nullptr)), dim3(256), 0, s, h->edt_col,
                        sel, C.width, C.height, C.clamp, h->edt);
+    launch_near_tiles(h, sel, max_entries, s);
 }
 
 static void launch_path_data(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
@@ -1108,6 +1152,20 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
             HIP_TRY(hipMalloc((void**)&h->edt_col, cells));
             h->edt_col_bytes = cells;
         }
+        // the 1-bit form for the outer test (near_tiles_kernel)
+        const int tiles_x = (W + 31) / 32, tiles_y = (H + 31) / 32;
+        const size_t near_bytes = (size_t)n_maps * tiles_x * tiles_y * 32 * sizeof(uint32_t);
+        if (near_bytes > h->near_bytes) {
+            if (h->near) HIP_TRY(hipFree(h->near));
+            h->near = nullptr;
+            h->near_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&h->near, near_bytes));
+            h->near_bytes = near_bytes;
+        }
+        C.near = h->near;
+        C.near_tx = tiles_x;
+        C.near_words = tiles_x * tiles_y * 32;
+        C.near_stride = shared ? 0 : (int64_t)C.near_words;
         C.edt = h->edt;
         C.width = W;
         C.height = H;
@@ -1152,6 +1210,26 @@ extern "C" int bcp_get_distance_field(bcp_handle* h, int64_t first_entry, int64_
     HIP_TRY(hipSetDevice(h->device));
     const size_t per = (size_t)C.width * C.height;
     HIP_TRY(hipMemcpyAsync(out, h->edt + first_entry * per, n_entries * per, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return BCP_OK;
+}
+
+extern "C" int bcp_get_near_field(bcp_handle* h, int64_t first_entry, int64_t n_entries, uint32_t* out, int32_t* shape,
+                                  void* stream)
+{
+    if (!h || !shape) return fail(BCP_E_INVALID, "bcp_get_near_field: null argument");
+    if (!h->have_map || !h->cull.near) return fail(BCP_E_STATE, "bcp_get_near_field: no distance field (no costmap, or culling off)");
+    const CullDesc& C = h->cull;
+    shape[0] = C.near_words / (32 * C.near_tx);
+    shape[1] = C.near_tx;
+    shape[2] = C.t_out;
+    if (!out) return BCP_OK;
+    const int64_t n_maps = h->map.shared ? 1 : n_slots(h);
+    if (first_entry < 0 || n_entries <= 0 || first_entry + n_entries > n_maps)
+        return fail(BCP_E_INVALID, "bcp_get_near_field: entries out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t per = (size_t)C.near_words;
+    HIP_TRY(hipMemcpyAsync(out, h->near + first_entry * per, n_entries * per * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
     return BCP_OK;
 }
 
@@ -1348,6 +1426,7 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     hot.map_cols = S.map.cols;
     hot.map_wpr = S.map.wpr;
     hot.map_shared = S.map.shared;
+    hot.near = S.cull.on ? S.cull.near : nullptr;
     a.actions = io->actions;
     a.noise_z = io->noise_z;
     a.noise_z_out = io->noise_z_out;

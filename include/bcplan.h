@@ -194,6 +194,12 @@ int bcp_set_costmaps(bcp_handle *h, const uint8_t *data, int32_t rows, int32_t c
  * shared map). */
 int bcp_get_distance_field(bcp_handle *h, int64_t first_entry, int64_t n_entries, uint8_t *out, int32_t *shape /*host*/,
                            void *stream);
+/* The same field as the step's outer test reads it: one bit per cell, set where the field value is < t_out (a lethal
+ * cell may touch a footprint whose sample disc is centred there), in tiles of 32 x 32 cells -- bit (x & 31) of word
+ * ((y >> 5) * tiles_x + (x >> 5)) * 32 + (y & 31) is cell (y, x) of the padded field.  shape (host int32 [3]) receives
+ * {tiles_y, tiles_x, t_out}; out (device uint32 [n_entries][tiles_y * tiles_x * 32], or NULL for the shape only). */
+int bcp_get_near_field(bcp_handle *h, int64_t first_entry, int64_t n_entries, uint32_t *out, int32_t *shape /*host*/,
+                       void *stream);
 /* Static path of the reward provider (ContinuousRewardProviderState.path, reward.py:17-18), already refined.
  * xytheta: double [max_len,3] when shared, else [N,max_len,3]; lens: NULL when shared (then len = max_len) else
  * int32 [N].  Precomputes cos/sin of the waypoint headings (path_tools.py:405) on the device. */

@@ -305,6 +305,10 @@ def _check_ring_entries(env, deep, world_of_env, generated):
             assert pl[g] == dl[d] and (pp[g, :pl[g]] == dpth[d, :dl[d]]).all() and (pi[g] == di[d]).all(), (c, j)
             assert (ix[:, g] == dpth[d, 0]).all() and imd[g] == di[d, 0] and iti[g] == int(di[d, 1]), (c, j)
             assert nxt[g] == (g if j == generated[c] - 1 else c * E + (j + 1) % E), (c, j)
+    # the 1-bit tiles of the step's outer test follow the distance fields through every re-sampling
+    import torch
+    near, t_out = env.near_field(0, env.n_envs * E)
+    assert torch.equal(near, env.distance_field(0, env.n_envs * E)[0] < t_out)
 
 
 @pytest.mark.parametrize("overlap,E", [(False, 3), (True, 5)], ids=["in-order", "side-stream"])
@@ -378,6 +382,17 @@ def test_endless_pool_guard_holds_envs_back(torch_cuda):
         mini_env.BatchedRandomMiniEnv(4, params, n_chains=4, episodes=2).refresh()
 
 
+def test_near_field_of_a_shared_map(torch_cuda):
+    """shared 183 x 183 map: the padded field is 379 cells wide -- not a multiple of the 32-cell tiles"""
+    torch = torch_cuda
+    import bench
+    env, _ = bench.make_env(256, 0, 0, 5)
+    field, pad, clamp = env.distance_field(0, 1)
+    near, t_out = env.near_field(0, 1)
+    assert field.shape[2] % 32 != 0 and 0 < t_out <= clamp
+    assert torch.equal(near, field < t_out) and bool(near.any()) and not bool(near.all())
+
+
 def test_distance_fields_lds_kernel_vs_two_pass_vs_scipy(torch_cuda):
     """the distance fields behind the pose pre-classification: the LDS-resident transform (pool / private maps), the
     two-pass global-memory kernels and scipy's exact EDT agree cell for cell"""
@@ -392,6 +407,8 @@ def test_distance_fields_lds_kernel_vs_two_pass_vs_scipy(torch_cuda):
     env.set_costmap_tensors(env._keep["map"], env._keep["origins"], env.resolution)
     slow, pad2, clamp2 = env.distance_field(0, g_n)
     assert (pad, clamp) == (pad2, clamp2) and torch.equal(fast, slow)
+    near, t_out = env.near_field(0, g_n)          # the 1-bit tiles the step's outer test reads
+    assert 0 < t_out <= clamp and torch.equal(near, slow < t_out)
     maps = pool.maps.cpu().numpy()
     for k in (0, 5, g_n - 1):
         free = np.pad(maps[k] != 254, pad, constant_values=True)
@@ -408,6 +425,8 @@ def test_distance_fields_lds_kernel_vs_two_pass_vs_scipy(torch_cuda):
     env.set_tuning(edt_lds=0)
     env.set_costmap_tensors(dmap, env._keep["origins"], env.resolution)
     assert (env.distance_field(0, g_n)[0].cpu().numpy() == fast).all()
+    near, t_out = env.near_field(0, g_n)
+    assert (near.cpu().numpy() == (fast < t_out)).all()
     for k in (1, g_n - 2):
         free = np.pad(dense[k] != 254, pad, constant_values=True)
         want = np.minimum(np.floor(ndimage.distance_transform_edt(free) + 1e-9), clamp).astype(np.uint8)
