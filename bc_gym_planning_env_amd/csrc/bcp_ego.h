@@ -13,7 +13,7 @@
 
 namespace bcp {
 
-extern __shared__ uint32_t ego_lds[];
+extern __shared__ __attribute__((aligned(16))) uint32_t ego_lds[];
 
 // extract_egocentric_costmap (utilities/costmap_utils.py:25-75) = cv2.getRotationMatrix2D + cv2.warpAffine with
 // INTER_NEAREST for every env at once.  OpenCV's nearest-neighbour warp works in 22.10 fixed point:
@@ -47,14 +47,6 @@ __device__ __forceinline__ int sat_int(double v)   // cv::saturate_cast<int>(dou
 {
     const double r = rint(v);
     return r >= 2147483647.0 ? 2147483647 : (r <= -2147483648.0 ? (-2147483647 - 1) : (int)r);
-}
-
-// clamp(v, lo, hi) as ONE instruction (the compiler emits v_max + v_min for min(max()))
-__device__ __forceinline__ int clamp_med3(int v, int lo, int hi)
-{
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
-    return r;
 }
 
 // byte at a raw LDS address (no symbol base is added: the caller folds the base into the address)
@@ -97,6 +89,7 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef __attribute__((address_space(3))) int* LdsI32;
 typedef __attribute__((address_space(3))) uint8_t* LdsU8;
 constexpr int kRowOff = -2147483647 - 1;   // row-table X0 of a row that lies off the map (real X0 are >= INT_MIN + 512)
+constexpr int kRowOutShift = 1024;              // an off-map row is parked this many cells left of the ring (> any dcols)
 
 struct EgoXform {
     double M[6];   // dst -> src, as cv::warpAffine uses it
@@ -193,7 +186,7 @@ __device__ __forceinline__ EgoImage ego_broadcast(const EgoXform& T, int k)
 // from HBM) then costs two or three memory round trips, the first of them hidden behind the border fill -- and is
 // scattered into the ringed layout byte by byte.
 __device__ __forceinline__ void ego_stage_map(const EgoArgs& a, const uint8_t* __restrict__ src, int vr, int vc, LdsU8 lmap,
-                                              int pitch, int map_bytes)
+                                              int pitch, int map_bytes, int threads = 256)
 {
     constexpr int kInFlight = 16;
     const int total = a.rows * a.cols;
@@ -203,23 +196,23 @@ __device__ __forceinline__ void ego_stage_map(const EgoArgs& a, const uint8_t* _
     uint32_t v[kInFlight];
 #pragma unroll
     for (int u = 0; u < kInFlight; ++u) {   // first batch: issued before the fill
-        const int w = threadIdx.x + u * 256;
+        const int w = threadIdx.x + u * threads;
         v[u] = w < n_words ? w32[w] : 0u;
     }
     __attribute__((address_space(3))) uint32_t* l32 = (__attribute__((address_space(3))) uint32_t*)lmap;
-    for (int k = threadIdx.x; k < map_bytes / 4; k += 256) l32[k] = (uint32_t)a.border * 0x01010101u;
+    for (int k = threadIdx.x; k < map_bytes / 4; k += threads) l32[k] = (uint32_t)a.border * 0x01010101u;
     __syncthreads();
-    for (int w0 = threadIdx.x; w0 < n_words; w0 += kInFlight * 256) {
+    for (int w0 = threadIdx.x; w0 < n_words; w0 += kInFlight * threads) {
         if (w0 != (int)threadIdx.x) {
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) {
-                const int w = w0 + u * 256;
+                const int w = w0 + u * threads;
                 v[u] = w < n_words ? w32[w] : 0u;
             }
         }
 #pragma unroll
         for (int u = 0; u < kInFlight; ++u) {
-            const int w = w0 + u * 256;
+            const int w = w0 + u * threads;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int idx = 4 * w + j - off;                       // linear index into the map entry
@@ -235,57 +228,241 @@ __device__ __forceinline__ void ego_stage_map(const EgoArgs& a, const uint8_t* _
 
 // How source coordinates map onto the LDS copy of (a part of) the costmap: the copy holds map columns c0 .. c0 + w - 1
 // and rows r0 .. r0 + h - 1 inside a one-cell ring of the border value, `pitch` = w + 2 bytes per row.
-//   X' = X + x_add, clamped to [x_lo, x_hi]  (x_add = 1 + LDS base address - c0: the sum is a raw LDS byte address)
-//   Y' = Y + y_add, clamped to [0, y_hi]     (y_add = 1 - r0)
+//   X' = X + x_add, clamped to [0, x_hi]   (x_add = 1 - c0)
+//   Y' = Y + y_add, clamped to [0, y_hi]   (y_add = 1 - r0)          byte address = base + Y' * pitch + X'
 struct EgoStage {
-    int x_add, y_add, x_lo, x_hi, y_hi, pitch;
+    int x_add, y_add, x_hi, y_hi, pitch, base;
 };
 
 __device__ __forceinline__ EgoStage ego_stage_of(int lds_base, int c0, int r0, int w, int h)
 {
     EgoStage G;
-    G.x_add = 1 + lds_base - c0;
+    G.x_add = 1 - c0;
     G.y_add = 1 - r0;
-    G.x_lo = lds_base;
-    G.x_hi = lds_base + w + 1;
+    G.x_hi = w + 1;
     G.y_hi = h + 1;
     G.pitch = w + 2;
+    G.base = lds_base;
     return G;
 }
 
-// per-row terms of one image (rounding term included; staged sampling: ring offset and LDS base folded in) and the
-// off-map flag of each row, for rows t0, t0 + tstep, ...
+// per-row terms of one image (rounding term included) for rows t0, t0 + tstep, ..., as a table [drows][2]; kRowOff
+// marks a row that lies off the map in the plain (22.10) table of the global-memory path.  Staged sampling works in
+// 16.16: its table holds (term + ring offset) << 6, so that the integer part of a source coordinate -- (row term +
+// column term) >> 10 in cv::warpAffine's 22.10 -- is the upper half of the sum.  A row that lies off the map gets terms
+// that put every pixel of it on the ring's left column (it is only sampled when it shares a bundle of rows with a live
+// one).  A row that is not off the map stays within (window width) cells of it, so the shifted terms fit as long as the
+// map is narrower than 2^15 - 2 dcols cells (LDS-resident maps are).
+constexpr int kEgoBoundInts = 16;   // behind the tables: {first live row, first inside row, inside end, live end} per wave
+
+// ints of one table: row terms, row bounds
+__device__ __forceinline__ int ego_table_ints(const EgoArgs& a) { return 2 * a.drows + kEgoBoundInts; }
+
 template <bool STAGED>
 __device__ __forceinline__ void ego_row_terms(const EgoArgs& a, const EgoImage& I, const EgoStage& G, LdsI32 row_tab,
                                               int t0, int tstep)
 {
     const int last_cx = sat_int(I.m0 * (a.dcols - 1) * 1024), last_cy = sat_int(I.m3 * (a.dcols - 1) * 1024);
-    for (int y = t0; y < a.drows; y += tstep) {
+    // Rows that are not off the map form an interval of the image, and so do the rows entirely inside it (the source
+    // coordinates of both row ends are monotone in y): [live_lo, live_hi) and [in_lo, in_hi), found with ballots.
+    const int lane = t0 & 63;
+    int live_lo = a.drows, live_hi = 0, in_lo = a.drows, in_hi = 0;
+    for (int y0 = t0 - lane; y0 < a.drows; y0 += tstep) {   // (wave-uniform: this pass covers rows y0 .. y0 + 63)
+        const int y = y0 + lane;
+        const bool real = y < a.drows;
         const int rx = sat_int((I.m1 * y + I.m2) * 1024) + 512, ry = sat_int((I.m4 * y + I.m5) * 1024) + 512;
         const int xa = rx >> 10, xb = (rx + last_cx) >> 10, ya = ry >> 10, yb = (ry + last_cy) >> 10;
         const bool off = (xa < 0 && xb < 0) || (xa >= I.vc && xb >= I.vc) || (ya < 0 && yb < 0) || (ya >= I.vr && yb >= I.vr);
-        row_tab[2 * y] = off ? kRowOff : (STAGED ? rx + G.x_add * 1024 : rx);
-        row_tab[2 * y + 1] = STAGED ? ry + G.y_add * 1024 : ry;
+        if (STAGED) {
+            // (monotone along a row too: both ends inside => every pixel inside)
+            const bool inside = (unsigned)xa < (unsigned)I.vc && (unsigned)xb < (unsigned)I.vc &&
+                                (unsigned)ya < (unsigned)I.vr && (unsigned)yb < (unsigned)I.vr;
+            const uint64_t live = __ballot(real && !off), in = __ballot(real && inside);
+            if (live) {
+                live_lo = min(live_lo, y0 + (int)__builtin_ctzll(live));
+                live_hi = max(live_hi, y0 + 64 - (int)__builtin_clzll(live));
+            }
+            if (in) {
+                in_lo = min(in_lo, y0 + (int)__builtin_ctzll(in));
+                in_hi = max(in_hi, y0 + 64 - (int)__builtin_clzll(in));
+            }
+            if (real) {
+                row_tab[2 * y] = off ? (int)((uint32_t)(-kRowOutShift * 1024) << 6) : (int)((uint32_t)(rx + G.x_add * 1024) << 6);
+                row_tab[2 * y + 1] = off ? 0 : (int)((uint32_t)(ry + G.y_add * 1024) << 6);
+            }
+        } else if (real) {
+            row_tab[2 * y] = off ? kRowOff : rx;
+            row_tab[2 * y + 1] = ry;
+        }
+    }
+    if (STAGED && lane == 0) {
+        const LdsI32 bounds = row_tab + 2 * a.drows + 4 * ((t0 >> 6) & 3);
+        bounds[0] = live_lo;
+        bounds[1] = in_lo;
+        bounds[2] = in_hi;
+        bounds[3] = live_hi;
     }
 }
 
-// the pixels of rows r0, r0 + rstep, ... for this lane's column groups.  Pixel groups are PX columns wide; the last
-// group of a row is shifted left so that it ends at the last column (it recomputes a few pixels of its neighbour
-// instead of needing a narrower store).
-template <bool STAGED, int PX>
-__device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, const EgoStage& G,
-                                           const uint8_t* __restrict__ src, LdsI32 row_tab, uint8_t* __restrict__ image,
-                                           int cg, int r0, int rstep)
+typedef short EgoI16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short EgoU16x2 __attribute__((ext_vector_type(2)));
+typedef int EgoI32x2 __attribute__((ext_vector_type(2)));
+
+// LDS reads whose latency the pixel loop hides itself: issued here, consumed only after lds_wait_*() -- the compiler does
+// not know they are in flight (its own waits would count them and drain the queue early), so every LDS access between
+// the first issue and the wait goes through these.
+__device__ __forceinline__ uint32_t lds_issue_u8(uint32_t addr)
+{
+    uint32_t v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("ds_read_u8 %0, %1" : "=v"(v) : "v"(addr));
+#else
+    (void)addr;
+#endif
+    return v;
+}
+
+__device__ __forceinline__ EgoI32x2 lds_issue_b64(uint32_t addr)
+{
+    EgoI32x2 v = {0, 0};
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+#else
+    (void)addr;
+#endif
+    return v;
+}
+
+template <int PX>
+__device__ __forceinline__ void lds_wait_pixels(uint32_t (&val)[PX], EgoI32x2& row)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (PX == 8)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]),
+                       "+v"(val[7]), "+v"(row)
+                     :
+                     : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(row) : : "memory");
+#endif
+}
+
+// the pixels of rows r_first + rl, + rstep, ... for this lane's column groups (rl = the lane's row within the wave's
+// bundle of kRows rows).  Pixel groups are PX columns wide; the last group of a row is shifted left so that it ends
+// at the last column (it recomputes a few pixels of its neighbour instead of needing a narrower store); a lane whose
+// row would lie below the image repeats the last row (same bytes to the same addresses) -- no execution masks.
+// Staged sampling (the map copy in LDS), per pixel: two adds (row term + column term, 16.16), one v_perm_b32 that puts
+// the two integer parts side by side as {Y, X} 16-bit halves, one v_dot2_u32_u16 with {pitch, 1} that turns them into
+// the LDS byte address, the byte read -- and, only for bundles with a row that can leave the map, v_pk_max_i16 /
+// v_pk_min_i16 in between, which clamp both coordinates onto the border ring of the LDS copy at once.  Which bundles
+// those are follows from the row bounds of ego_row_terms: scalar trip counts, no per-trip test.  Bundles off the map
+// are filled with the border value without sampling.  The loop is software-pipelined by hand: the byte reads of
+// bundle k are in flight while the addresses of bundle k + 1 are computed; the row terms are fetched two bundles ahead.
+template <int PX>
+__device__ __forceinline__ void ego_pixels_lds(const EgoArgs& a, const EgoImage& I, const EgoStage& G, LdsI32 row_tab,
+                                               uint8_t* __restrict__ image, int cg, int rl, int r_first, int rstep, int parts)
+{
+    constexpr int kRows = 64 / (128 / PX);
+    const uint64_t border8 = (uint64_t)(uint32_t)a.border * 0x0101010101010101ull;
+    const EgoI16x2 ring_lo = {0, 0}, ring_hi = {(short)G.x_hi, (short)G.y_hi};
+    const EgoU16x2 weights = {1, (unsigned short)G.pitch};
+    const uint32_t rows_at = (uint32_t)(uintptr_t)row_tab;
+    // row bounds -> bundle bounds [0, it_a) off | [it_a, it_b) clamped | [it_b, it_c) inside | [it_c, it_d) clamped | off
+    int live_lo = a.drows, in_lo = a.drows, in_hi = 0, live_hi = 0;
+    {
+        const LdsI32 bounds = row_tab + 2 * a.drows;
+        for (int p = 0; p < parts; ++p) {
+            live_lo = min(live_lo, __builtin_amdgcn_readfirstlane(bounds[4 * p + 0]));
+            in_lo = min(in_lo, __builtin_amdgcn_readfirstlane(bounds[4 * p + 1]));
+            in_hi = max(in_hi, __builtin_amdgcn_readfirstlane(bounds[4 * p + 2]));
+            live_hi = max(live_hi, __builtin_amdgcn_readfirstlane(bounds[4 * p + 3]));
+        }
+    }
+    const auto trips_below = [rstep](int rows) { return rows <= 0 ? 0 : (rows + rstep - 1) / rstep; };   // #k: k * rstep < rows
+    const int n_it = trips_below(a.drows - r_first);
+    const int it_a = min(trips_below(live_lo - (kRows - 1) - r_first), n_it);
+    const int it_d = max(it_a, min(trips_below(live_hi - r_first), n_it));
+    const int it_b = max(it_a, min(trips_below(in_lo - r_first), it_d));
+    const int it_c = max(it_b, min(in_hi - kRows - r_first < 0 ? 0 : (in_hi - kRows - r_first) / rstep + 1, it_d));
+    const int last_row = a.drows - 1;
+    for (int xg = PX * cg; xg < a.dcols; xg += 128) {
+        const int x0 = min(xg, a.dcols - PX);
+        const auto store = [&](int k, uint64_t packed) {
+            uint8_t* const p = image + (uint32_t)(__mul24(min(r_first + k * rstep + rl, last_row), a.dcols) + x0);
+            if (PX == 8)
+                *reinterpret_cast<u64_unaligned*>(p) = packed;
+            else
+                *reinterpret_cast<u32_unaligned*>(p) = (uint32_t)packed;
+        };
+        for (int k = 0; k < it_a; ++k) store(k, border8);
+        for (int k = it_d; k < n_it; ++k) store(k, border8);
+        if (it_a == it_d) continue;
+        EgoI32x2 cc[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {   // this lane's column terms (cv::hal::warpAffine's adelta / bdelta), 16.16
+            // (|M0 x 1024| < 2^31 by a wide margin -- the transform is a rotation -- so saturate_cast<int> is plain rounding)
+            cc[j].x = (int)((uint32_t)(int)rint(I.m0 * (x0 + j) * 1024) << 6);
+            cc[j].y = (int)((uint32_t)(int)rint(I.m3 * (x0 + j) * 1024) << 6);
+        }
+        const auto row_at = [&](int k) { return rows_at + 8u * (uint32_t)min(r_first + k * rstep + rl, last_row); };
+        const auto addresses = [&](const EgoI32x2 row, bool clamp, uint32_t (&addr)[PX]) {
+            uint32_t yx[PX];
+#pragma unroll
+            for (int j = 0; j < PX; ++j)
+                yx[j] = __builtin_amdgcn_perm((uint32_t)(row.y + cc[j].y), (uint32_t)(row.x + cc[j].x), 0x07060302u);
+            if (clamp) {
+#pragma unroll
+                for (int j = 0; j < PX; ++j)
+                    yx[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(
+                        __builtin_elementwise_max(__builtin_bit_cast(EgoI16x2, yx[j]), ring_lo), ring_hi));
+            }
+            // (saturate_cast<short> never bites: |X|, |Y| < 2^15 on live rows, and off-map rows are parked)
+#pragma unroll
+            for (int j = 0; j < PX; ++j)
+                addr[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(EgoU16x2, yx[j]), weights, (uint32_t)G.base, false);
+        };
+        // prologue: row terms of bundles it_a and it_a + 1, addresses of bundle it_a
+        EgoI32x2 row = lds_issue_b64(row_at(it_a)), row_next = lds_issue_b64(row_at(min(it_a + 1, it_d - 1)));
+        uint32_t addr[PX], val[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) val[j] = 0;
+        lds_wait_pixels<PX>(val, row);
+        lds_wait_pixels<PX>(val, row_next);
+        addresses(row, it_a < it_b || it_a >= it_c, addr);
+        for (int k = it_a; k < it_d; ++k) {
+            EgoI32x2 row_after = lds_issue_b64(row_at(min(k + 2, it_d - 1)));
+            // Packing four pixels takes two operations instead of four: the third byte arrives already shifted
+            // (ds_read_u8_d16_hi puts it into bits 16..23; on this ECC target the low half comes back zero), one
+            // v_perm_b32 places bytes one and three, one v_or3_b32 joins the three registers.
+#pragma unroll
+            for (int j = 0; j < PX; ++j) val[j] = (j & 3) == 2 ? lds_byte_shifted_16(addr[j]) : lds_issue_u8(addr[j]);
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(row_next));   // (the next bundle's arithmetic stays behind the issue of these reads)
+#endif
+            uint32_t addr_next[PX];
+            addresses(row_next, k + 1 < it_b || k + 1 >= it_c, addr_next);
+            lds_wait_pixels<PX>(val, row_after);
+            uint32_t half[2] = {0, 0};
+#pragma unroll
+            for (int q = 0; q < PX / 4; ++q)   // (b3 << 24) | (b1 << 8), then | b0 | (b2 << 16)
+                half[q] = __builtin_amdgcn_perm(val[4 * q + 3], val[4 * q + 1], 0x040c000cu) | val[4 * q] | val[4 * q + 2];
+            store(k, ((uint64_t)half[1] << 32) | half[0]);
+            row_next = row_after;
+#pragma unroll
+            for (int j = 0; j < PX; ++j) addr[j] = addr_next[j];
+        }
+    }
+}
+
+// the same from global memory (maps that do not fit LDS and whose window does not either): plain 22.10 terms, a bounds
+// test per pixel, only the in-map lanes issue a load
+template <int PX>
+__device__ __forceinline__ void ego_pixels_global(const EgoArgs& a, const EgoImage& I, const uint8_t* __restrict__ src,
+                                                  LdsI32 row_tab, uint8_t* __restrict__ image, int cg, int r0, int rstep)
 {
     const uint32_t border = (uint32_t)a.border;
     const uint64_t border8 = (uint64_t)border * 0x0101010101010101ull;
-    int x_lo = G.x_lo, x_hi = G.x_hi, y_hi = G.y_hi;   // ring coordinates (staged sampling)
-    const int y_lo = 0, pitch = G.pitch;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // v_med3 takes one scalar operand at most: keep the clamp bounds in vector registers for the whole image instead of
-    // having them copied there again for every group of pixels
-    asm volatile("" : "+v"(x_lo), "+v"(x_hi), "+v"(y_hi));
-#endif
     for (int xg = PX * cg; xg < a.dcols; xg += 128) {
         const int x0 = min(xg, a.dcols - PX);
         int ccx[PX], ccy[PX];
@@ -299,37 +476,17 @@ __device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, 
             uint64_t packed = border8;
             if (rx != kRowOff) {
                 uint32_t half[2] = {0, 0};
-                if (STAGED) {
-                    // Every address on the border ring of the LDS copy is valid: clamp, read.  Packing four pixels
-                    // takes two operations instead of four: the third byte arrives already shifted (ds_read_u8_d16_hi
-                    // puts it into bits 16..23; on this ECC target the low half comes back zero), one v_perm_b32 places
-                    // bytes one and three, one v_or3_b32 joins the three registers.
-                    uint32_t val[PX];
 #pragma unroll
-                    for (int j = 0; j < PX; ++j) {
-                        // (saturate_cast<short> never bites: |X|, |Y| < 2^21 and maps are < 2^15)
-                        const int X = (rx + ccx[j]) >> 10, Y = (ry + ccy[j]) >> 10;
-                        const int xc = clamp_med3(X, x_lo, x_hi), yc = clamp_med3(Y, y_lo, y_hi);
-                        const uint32_t addr = (uint32_t)(__mul24(yc, pitch) + xc);
-                        val[j] = (j & 3) == 2 ? lds_byte_shifted_16(addr) : lds_byte_at(addr);
-                    }
-                    lds_reads_done();
-#pragma unroll
-                    for (int k = 0; k < PX / 4; ++k)   // (b3 << 24) | (b1 << 8), then | b0 | (b2 << 16)
-                        half[k] = __builtin_amdgcn_perm(val[4 * k + 3], val[4 * k + 1], 0x040c000cu) | val[4 * k] | val[4 * k + 2];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < PX; ++j) {   // global gather: only the in-map lanes issue a load
-                        const int X = (rx + ccx[j]) >> 10, Y = (ry + ccy[j]) >> 10;
-                        uint32_t val = border;
-                        if ((unsigned)X < (unsigned)I.vc && (unsigned)Y < (unsigned)I.vr)
-                            val = (uint32_t)src[(uint32_t)__mul24(Y, a.cols) + (uint32_t)X];
-                        half[j >> 2] |= val << (8 * (j & 3));
-                    }
+                for (int j = 0; j < PX; ++j) {
+                    const int X = (rx + ccx[j]) >> 10, Y = (ry + ccy[j]) >> 10;
+                    uint32_t val = border;
+                    if ((unsigned)X < (unsigned)I.vc && (unsigned)Y < (unsigned)I.vr)
+                        val = (uint32_t)src[(uint32_t)__mul24(Y, a.cols) + (uint32_t)X];
+                    half[j >> 2] |= val << (8 * (j & 3));
                 }
                 packed = ((uint64_t)half[1] << 32) | half[0];
             }
-            uint8_t* const p = image + (int64_t)y * a.dcols + x0;
+            uint8_t* const p = image + (uint32_t)(__mul24(y, a.dcols) + x0);
             if (PX == 8)
                 *reinterpret_cast<u64_unaligned*>(p) = packed;
             else
@@ -338,9 +495,20 @@ __device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, 
     }
 }
 
+template <bool STAGED, int PX>
+__device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, const EgoStage& G,
+                                           const uint8_t* __restrict__ src, LdsI32 row_tab, uint8_t* __restrict__ image,
+                                           int cg, int rl, int r_first, int rstep, int parts)
+{
+    if (STAGED) ego_pixels_lds<PX>(a, I, G, row_tab, image, cg, rl, r_first, rstep, parts);
+    else ego_pixels_global<PX>(a, I, src, row_tab, image, cg, r_first + rl, rstep);
+}
 
-// One WAVEFRONT per image, persistent workgroups of 4 waves that stage a shared costmap in LDS once and then walk
-// over images.
+
+constexpr int kEgoWaves = 8;   // wavefronts (= images in flight) per workgroup of ego_costmap_kernel
+
+// One WAVEFRONT per image, persistent workgroups of kEgoWaves waves that stage a shared costmap in LDS once and then
+// walk over images.
 //   * transforms: lane l of a wave prepares the (inverted) warp matrix of the wave's l-th image, so the float64
 //     sin / cos / inversion work is done once per image by one lane; the wave then takes the images one by one and
 //     broadcasts that lane's matrix (v_readlane -> scalar registers).
@@ -348,28 +516,30 @@ __device__ __forceinline__ void ego_pixels(const EgoArgs& a, const EgoImage& I, 
 //     registers, the per-row terms come from a small per-wave LDS table, and the 8 pixels leave as one 64-bit store
 //     (image rows are dcols bytes apart, so these stores are generally unaligned).
 //   * rows whose source segment lies entirely off the map are filled with the border value without sampling: the
-//     source coordinates are monotone in x, so it is enough to look at the row's two ends.
+//     source coordinates are monotone in x, so it is enough to look at the row's two ends; such rows, the rows
+//     entirely inside the map and the ones in between form intervals of the image (ego_row_terms finds their bounds).
 //   * shared map: the LDS copy carries a one-cell ring of the border value and the source coordinates are clamped
-//     onto it (v_med3), so a pixel is add, add, shift, shift, clamp, clamp, multiply-add, LDS byte read, pack --
-//     no bounds compare and no select.  The ring offset and the LDS base address ride in the per-row terms.
-// LDS: [shared map + ring, dword padded] [4 waves x drows x {X0 (kRowOff = row is off the map), Y0}]
+//     onto it where a row can leave the map, so a pixel is add, add, v_perm (both integer parts into one register),
+//     [v_pk_max, v_pk_min,] v_dot2 (address), LDS byte read, pack -- no bounds compare and no select (ego_pixels).
+//     The ring offset rides in the per-row terms.
+// LDS: [shared map + ring, padded to 8 bytes] [kEgoWaves x ((drows x {X0, Y0}) + row bounds)]
 // STAGED = false: maps that do not fit LDS are sampled straight from global memory.
 template <bool STAGED, int PX>
-__global__ void __launch_bounds__(256) ego_costmap_kernel(const EgoArgs a)
+__global__ void __launch_bounds__(64 * kEgoWaves) ego_costmap_kernel(const EgoArgs a)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const int pitch = a.cols + 2;
-    const int map_bytes = STAGED ? (((a.rows + 2) * pitch + 3) & ~3) : 0;
+    const int map_bytes = STAGED ? (((a.rows + 2) * pitch + 7) & ~7) : 0;
     const LdsU8 lmap = (LdsU8)ego_lds;
-    const LdsI32 row_tab = (LdsI32)(lmap + map_bytes) + wave * (2 * a.drows);
+    const LdsI32 row_tab = (LdsI32)(lmap + map_bytes) + wave * ego_table_ints(a);
     if (STAGED)
         ego_stage_map(a, a.data, a.valid_rows ? a.valid_rows[0] : a.rows, a.valid_cols ? a.valid_cols[0] : a.cols, lmap,
-                      pitch, map_bytes);
+                      pitch, map_bytes, blockDim.x);
     const int lds_base = (int)(uint32_t)(uintptr_t)lmap;   // (source coordinates become raw LDS byte addresses)
     constexpr int kGroups = 128 / PX, kRows = 64 / kGroups;   // lanes of a wave: kRows image rows x kGroups pixel groups
     const int cg = lane % kGroups, rl = lane / kGroups;
     const int64_t P = (int64_t)a.drows * a.dcols;
-    const int64_t first = (int64_t)blockIdx.x * 4 + wave, stride = (int64_t)gridDim.x * 4;
+    const int64_t first = (int64_t)blockIdx.x * waves + wave, stride = (int64_t)gridDim.x * waves;
     for (int64_t base = first; base < a.n_images; base += 64 * stride) {
         EgoXform T;
         memset(&T, 0, sizeof(T));
@@ -384,7 +554,7 @@ __global__ void __launch_bounds__(256) ego_costmap_kernel(const EgoArgs a)
             G.pitch = pitch;
             ego_row_terms<STAGED>(a, I, G, row_tab, lane, 64);
             wave_lds_sync();
-            ego_pixels<STAGED, PX>(a, I, G, a.data + I.g * a.map_stride, row_tab, a.out + img * P, cg, rl, kRows);
+            ego_pixels<STAGED, PX>(a, I, G, a.data + I.g * a.map_stride, row_tab, a.out + img * P, cg, rl, 0, kRows, 1);
             wave_lds_sync();   // the table is rewritten for the next image
         }
     }
@@ -403,10 +573,10 @@ __global__ void __launch_bounds__(256) ego_costmap_binned_kernel(const EgoArgs a
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pitch = a.cols + 2;
-    const int map_bytes = ((a.rows + 2) * pitch + 3) & ~3;
+    const int map_bytes = ((a.rows + 2) * pitch + 7) & ~7;   // (the tables behind it are read 8 bytes at a time: a misaligned ds_read_b64 takes 33 LDS cycles instead of 2)
     const LdsU8 lmap = (LdsU8)ego_lds;
     const LdsI32 tables = (LdsI32)(lmap + map_bytes);
-    const LdsI32 wave_tab = tables + wave * (2 * a.drows);
+    const LdsI32 wave_tab = tables + wave * ego_table_ints(a);
     const int lds_base = (int)(uint32_t)(uintptr_t)lmap;
     constexpr int kGroups = 128 / PX, kRows = 64 / kGroups;
     const int cg = lane % kGroups, rl = lane / kGroups;
@@ -439,7 +609,7 @@ __global__ void __launch_bounds__(256) ego_costmap_binned_kernel(const EgoArgs a
                 G.pitch = pitch;
                 ego_row_terms<true>(a, I, G, wave_tab, lane, 64);
                 wave_lds_sync();
-                ego_pixels<true, PX>(a, I, G, nullptr, wave_tab, a.out + img * P, cg, rl, kRows);
+                ego_pixels<true, PX>(a, I, G, nullptr, wave_tab, a.out + img * P, cg, rl, 0, kRows, 1);
                 wave_lds_sync();
             }
         }
@@ -460,7 +630,7 @@ __global__ void __launch_bounds__(256) ego_costmap_binned_kernel(const EgoArgs a
                 G.pitch = pitch;
                 ego_row_terms<true>(a, I, G, tables, threadIdx.x, 256);
                 __syncthreads();
-                ego_pixels<true, PX>(a, I, G, nullptr, tables, a.out + img * P, cg, wave * kRows + rl, 4 * kRows);
+                ego_pixels<true, PX>(a, I, G, nullptr, tables, a.out + img * P, cg, rl, wave * kRows, 4 * kRows, 4);
             }
         }
         pos = run_end;
@@ -548,14 +718,14 @@ __global__ void __launch_bounds__(256) ego_costmap_window_kernel(const EgoArgs a
                 const EgoStage G = ego_stage_of(lds_base, c0, r0, w, h);
                 ego_row_terms<true>(a, I, G, tables, threadIdx.x, 256);
                 __syncthreads();
-                ego_pixels<true, PX>(a, I, G, nullptr, tables, a.out + img * P, cg, wave * kRows + rl, 4 * kRows);
+                ego_pixels<true, PX>(a, I, G, nullptr, tables, a.out + img * P, cg, rl, wave * kRows, 4 * kRows, 4);
             } else {
                 // (cannot happen for windows the host accepted; kept as a safe fallback: sample from global memory)
                 EgoStage G = ego_stage_of(0, 0, 0, I.vc, I.vr);
                 ego_row_terms<false>(a, I, G, tables, threadIdx.x, 256);
                 __syncthreads();
-                ego_pixels<false, PX>(a, I, G, a.data + I.g * a.map_stride, tables, a.out + img * P, cg, wave * kRows + rl,
-                                      4 * kRows);
+                ego_pixels<false, PX>(a, I, G, a.data + I.g * a.map_stride, tables, a.out + img * P, cg, rl, wave * kRows,
+                                      4 * kRows, 4);
             }
         }
     }

@@ -1831,8 +1831,8 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
         a.win_ox = window_origin[0];
         a.win_oy = window_origin[1];
     }
-    const size_t map_bytes = ((size_t)(a.rows + 2) * (a.cols + 2) + 3) & ~(size_t)3;   // LDS copy with a border ring
-    const size_t row_bytes = (size_t)a.drows * 2 * sizeof(int32_t);                   // one row table
+    const size_t map_bytes = ((size_t)(a.rows + 2) * (a.cols + 2) + 7) & ~(size_t)7;   // LDS copy with a border ring
+    const size_t row_bytes = ((size_t)a.drows * 2 + kEgoBoundInts) * sizeof(int32_t);   // one table: row terms, row bounds
     a.border = border_value;
     a.out = out;
     a.n_envs = h->n;
@@ -1890,7 +1890,7 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
         // diagonal (+ 2 px of rounding, + ring) squared
         const double diag = std::sqrt((double)a.drows * a.drows + (double)a.dcols * a.dcols);
         const size_t side = (size_t)std::ceil(diag) + 5;
-        const size_t win_bytes = (side * side + 3) & ~(size_t)3;
+        const size_t win_bytes = (side * side + 7) & ~(size_t)7;
         if (!a.stage_map && win_bytes + row_bytes <= 60 * 1024) {
             a.win_lds_bytes = (int32_t)win_bytes;
             const size_t lds = win_bytes + row_bytes;
@@ -1903,20 +1903,22 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
             HIP_TRY(hipGetLastError());
             return BCP_OK;
         }
-        const size_t lds = 4 * row_bytes + (a.stage_map ? map_bytes : 0);
+        const int waves = kEgoWaves;
+        const size_t lds = waves * row_bytes + (a.stage_map ? map_bytes : 0);
         const void* fn = a.stage_map ? (px8 ? (const void*)ego_costmap_kernel<true, 8> : (const void*)ego_costmap_kernel<true, 4>)
                                      : (px8 ? (const void*)ego_costmap_kernel<false, 8> : (const void*)ego_costmap_kernel<false, 4>);
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
-        const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)std::max(per_cu, 1) * cus));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * waves, lds));
+        const dim3 grid((unsigned)std::min<int64_t>((n + waves - 1) / waves, (int64_t)std::max(per_cu, 1) * cus));
+        const dim3 wide(64 * waves);
         if (a.stage_map) {
-            if (px8) hipLaunchKernelGGL((ego_costmap_kernel<true, 8>), grid, block, lds, st, a);
-            else hipLaunchKernelGGL((ego_costmap_kernel<true, 4>), grid, block, lds, st, a);
+            if (px8) hipLaunchKernelGGL((ego_costmap_kernel<true, 8>), grid, wide, lds, st, a);
+            else hipLaunchKernelGGL((ego_costmap_kernel<true, 4>), grid, wide, lds, st, a);
         } else {
-            if (px8) hipLaunchKernelGGL((ego_costmap_kernel<false, 8>), grid, block, lds, st, a);
-            else hipLaunchKernelGGL((ego_costmap_kernel<false, 4>), grid, block, lds, st, a);
+            if (px8) hipLaunchKernelGGL((ego_costmap_kernel<false, 8>), grid, wide, lds, st, a);
+            else hipLaunchKernelGGL((ego_costmap_kernel<false, 4>), grid, wide, lds, st, a);
         }
     }
     HIP_TRY(hipGetLastError());

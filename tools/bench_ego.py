@@ -2,6 +2,9 @@
 133 x 117 window.  Usage: python tools/bench_ego.py [n] [pool]"""
 import sys, os, numpy as np, torch
 sys.path.insert(0, '.')
+from bc_gym_planning_env_amd import _lib
+if os.environ.get("BCP_LIB"):   # an experimental build of the library
+    _lib.LIB_PATH = os.environ["BCP_LIB"]
 from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams, mini_env
 from bc_gym_planning_env_amd.egocentric import BatchedEgocentricCostmap
 

@@ -1,5 +1,8 @@
 import sys, os, numpy as np, torch
 sys.path.insert(0, '.')
+from bc_gym_planning_env_amd import _lib
+if os.environ.get("BCP_LIB"):   # an experimental build of the library
+    _lib.LIB_PATH = os.environ["BCP_LIB"]
 from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
 from bc_gym_planning_env_amd.egocentric import BatchedColoredEgoCostmap, BatchedEgocentricCostmap
 g = np.load('tests/golden/' + (sys.argv[1] if len(sys.argv) > 1 else 'g12_colored_ego.npz'))
