@@ -108,9 +108,32 @@ __device__ __forceinline__ OuterLookups outer_lookups_issue(const CullDesc& C, i
     return L;
 }
 
+// What the outer test needs of a CullDesc, as a value: a kernel fetches it (scalar loads) before its barriers, so that
+// the loads are not queued behind them on the critical path.
+struct OuterParams {
+    int32_t reach, pad, width, height, n_out, near_tx, t_out;
+    double out_x[kMaxSamples], axis_y;
+};
+
+__device__ __forceinline__ OuterParams outer_params(const CullDesc& C)
+{
+    OuterParams o;
+    o.reach = C.reach;
+    o.pad = C.pad;
+    o.width = C.width;
+    o.height = C.height;
+    o.n_out = C.n_out;
+    o.near_tx = C.near_tx;
+    o.t_out = C.t_out;
+#pragma unroll
+    for (int i = 0; i < kMaxSamples; ++i) o.out_x[i] = C.out_x[i];
+    o.axis_y = C.axis_y;
+    return o;
+}
+
 // the same lookups from the 1-bit tiles (CullDesc::near) of this pose's map entry, in global memory or staged in LDS
 template <typename WordPtr>
-__device__ __forceinline__ OuterLookups outer_lookups_near(const CullDesc& C, WordPtr tiles, int rows, int cols, int px, int py,
+__device__ __forceinline__ OuterLookups outer_lookups_near(const OuterParams& C, WordPtr tiles, int rows, int cols, int px, int py,
                                                            double c, double s)
 {
     OuterLookups L;
@@ -131,6 +154,15 @@ __device__ __forceinline__ OuterLookups outer_lookups_near(const CullDesc& C, Wo
     for (int i = 0; i < kMaxSamples; ++i)   // as the byte field reads: 0 = closer than t_out, 255 = not
         L.val[i] = bit[i] >= 0 ? (((word[i] >> bit[i]) & 1u) ? 0 : 255) : (i < C.n_out ? not_stored : 255);
     return L;
+}
+
+__device__ __forceinline__ int outer_lookups_verdict(const OuterParams& C, const OuterLookups& L)
+{
+    if (L.off_map) return kFree;
+    int near_out = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxSamples; ++i) near_out |= L.val[i] < C.t_out;
+    return near_out ? kAmbiguous : kFree;
 }
 
 __device__ __forceinline__ int outer_lookups_verdict(const CullDesc& C, const OuterLookups& L)

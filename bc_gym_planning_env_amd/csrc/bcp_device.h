@@ -90,6 +90,10 @@ struct Pose {
     double x, y, th;
 };
 
+// cos and sin of one angle with ONE range reduction: ocml's sincos runs the reduction and the two kernel polynomials its
+// sin and cos run, once -- the values are the ones cos(x) / sin(x) return (the golden trajectories are the check)
+__device__ __forceinline__ void cos_sin(double x, double& c, double& s) { sincos(x, &s, &c); }
+
 // robot_models/differential_drive.py:21-40
 __device__ __forceinline__ Pose kinematic_step(Pose p, double v, double w, double dt)
 {
@@ -100,8 +104,10 @@ __device__ __forceinline__ Pose kinematic_step(Pose p, double v, double w, doubl
     double v_factor = v * dt * sinc;
     double a = p.th + half_wdt;
     Pose o;
-    o.x = p.x + v_factor * cos(a);
-    o.y = p.y + v_factor * sin(a);
+    double ca, sa;
+    cos_sin(a, ca, sa);
+    o.x = p.x + v_factor * ca;
+    o.y = p.y + v_factor * sa;
     o.th = normalize_angle(p.th + w * dt);
     return o;
 }
@@ -139,7 +145,8 @@ __device__ __forceinline__ Pose kinematic_step_noise(Pose p, double v, double w,
 __device__ __forceinline__ int path_velocity(Pose p0, Pose p1, double dt, double& v, double& w)
 {
     double dx = p1.x - p0.x, dy = p1.y - p0.y;
-    double c0 = cos(p0.th), s0 = sin(p0.th);
+    double c0, s0;
+    cos_sin(p0.th, c0, s0);
     double sign = signd(c0 * dx + s0 * dy);
     if (sign == 0.0) sign = signd(s0 * dy);
     double ds = sqrt(dx * dx + dy * dy) * sign;
@@ -172,8 +179,10 @@ __device__ __forceinline__ int robot_step(const DevParams& P, Robot& r, double c
         } else {
             new_wa = clipd(cmd1, -P.max_wheel_angle, P.max_wheel_angle);
         }
-        double des_v = cmd0 * cos(new_wa);
-        double des_w = cmd0 * sin(new_wa) / P.L;
+        double cw, sw;
+        cos_sin(new_wa, cw, sw);
+        double des_v = cmd0 * cw;
+        double des_w = cmd0 * sw / P.L;
         if (P.dynamic_model) {            // tricycle_model.py:157-188
             double acc_v = (des_v - r.v) / P.dt;
             double acc_w = (des_w - r.w) / P.dt;

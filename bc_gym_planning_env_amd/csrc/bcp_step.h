@@ -326,6 +326,7 @@ __device__ __forceinline__ bool way_point_reached(const DevParams& P, double sx,
 }
 
 // way points in LDS (shared path): one candidate at a time, first hit from the top wins
+// (four at a time, like the global-memory form below, measured no faster: the scan is not bound by the LDS round trip)
 template <typename PathPtr>
 __device__ __forceinline__ int last_reached_from(const DevParams& P, PathPtr path, PathWindow w, int m, int target,
                                                  double x, double y, double th)
@@ -567,7 +568,8 @@ __device__ __forceinline__ bool collides_wave(const DevParams& P, const MapDesc&
     }
     const int px = (int)rint((x - ox) * map.inv_res);   // world_to_pixel, coordinate_transformations.py:185-205
     const int py = (int)rint((y - oy) * map.inv_res);
-    const double c = cos(th), s = sin(th);
+    double c, s;
+    cos_sin(th, c, s);
     int cls = active ? classify(cull, map.shared ? 0 : env, map.rows, map.cols, px, py, c, s) : kFree;
     bool hit = cls == kHit;
     uint64_t amb = __ballot(cls == kAmbiguous);
@@ -798,7 +800,7 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
 // ---- loads shared by the step kernels ------------------------------------------------------------------------
 template <bool PLAIN, typename A>
 __device__ __forceinline__ void load_env(const A& a, uint64_t seed, uint64_t step_counter, int64_t i, bool active,
-                                         Pending& q, double& cmd0, double& cmd1)
+                                         Pending& q, double& cmd0, double& cmd1, bool draw_noise = true)
 {
     const DevParams& P = a.S->P;
     Robot& r = q.r;
@@ -840,7 +842,7 @@ __device__ __forceinline__ void load_env(const A& a, uint64_t seed, uint64_t ste
             q.z[0] = as_global(a.noise_z)[3 * i + 0];
             q.z[1] = as_global(a.noise_z)[3 * i + 1];
             q.z[2] = as_global(a.noise_z)[3 * i + 2];
-        } else {
+        } else if (draw_noise) {
             device_normals(seed, (uint64_t)(a.S->env_id_base + i), step_counter, q.z);
         }
     }
@@ -990,7 +992,8 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
         }
         const int px = (int)rint((r.p.x - ox) * a.S->map.inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
         const int py = (int)rint((r.p.y - oy) * a.S->map.inv_res);
-        const double c = cos(r.p.th), s = sin(r.p.th);
+        double c, s;
+        cos_sin(r.p.th, c, s);
         const int64_t map_env = a.S->map.shared ? 0 : g;
         OuterLookups look;
         look.off_map = true;
@@ -1190,6 +1193,14 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     KernArgs a = *(const __attribute__((address_space(4))) StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const uint64_t step_counter = a.tick[0], seed = a.tick[2];   // (StepArgs::tick: counter and seed live on the device)
     const DevParams& P = a.S->P;
+    // what the classification behind barrier 1 needs from *S: asked for first of all -- scalar loads that miss at a kernel
+    // start (~3 k cycles) -- so that they are neither queued behind the barriers nor in front of the movers' loads
+    const OuterParams outer = outer_params(a.S->cull);
+    const double map_inv_res = a.S->map.inv_res;
+    const int map_rows = a.S->map.rows, map_cols = a.S->map.cols;
+    const int64_t near_stride = a.S->cull.near_stride;
+    const double* const map_origins = a.S->map.origins;
+    double org_x = a.S->map.ox, org_y = a.S->map.oy;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool mover = wave < kLocalPairs, scorer = wave >= kLocalPairs && wave < 2 * kLocalPairs;
     const int pair = wave & (kLocalPairs - 1);
@@ -1218,6 +1229,20 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     const int map_words = a.hot.map_shared && a.hot.map_rows * a.hot.map_wpr <= kLocalMapWords ? a.hot.map_rows * a.hot.map_wpr : 0;
 
     DIAG_STAMP(0);
+    const int64_t gi = (int64_t)blockIdx.x * kLocalEnvs + pair * kBlock + lane;
+    const bool active = gi < a.hot.n;
+    const int64_t i = active ? gi : a.hot.n - 1;   // (inactive lanes of the last workgroup shadow env n-1 and never store)
+    // (0) the odometry noise of this step needs nothing from memory -- seed, env id, step counter: the scorer waves, idle
+    //     until the new pose exists, draw it (Philox + float64 Box-Muller, a third of the mover's way to the robot model)
+    //     while the movers' state loads are in flight, and hand it over in LDS
+    const bool noise_by_scorer = P.noise_on && !a.noise_z;
+    if (scorer && noise_by_scorer) {
+        double z[3];
+        device_normals(seed, (uint64_t)(a.S->env_id_base + i), step_counter, z);
+        hand_score[lane] = z[0];
+        hand_score[kBlock + lane] = z[1];
+        hand_score[2 * kBlock + lane] = z[2];
+    }
     // staging: footprint vertices, the shared path with its bounding box and bucket index, the counters
     if (tid < nq) qv[tid] = P.qverts[tid >> 1][tid & 1];
     for (int k = tid; k < npath; k += kLocalWaves * kBlock) qv[nq + k] = as_global(a.hot.path_pts)[k];
@@ -1228,16 +1253,12 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     if (tid >= 960 && tid < 964) ctl[tid - 960] = 0;
     for (int k = tid; k < map_words; k += kLocalWaves * kBlock) lds_map[k] = as_global(a.hot.map_bits)[k];   // (read after the barriers)
 
-    const int64_t gi = (int64_t)blockIdx.x * kLocalEnvs + pair * kBlock + lane;
-    const bool active = gi < a.hot.n;
-    const int64_t i = active ? gi : a.hot.n - 1;   // (inactive lanes of the last workgroup shadow env n-1 and never store)
-
-    // (1) the mover's state / action / noise, the scorer's reward-state words
+    // (1) the mover's state / action, the scorer's reward-state words
     Pending q;
     double cmd0 = 0.0, cmd1 = 0.0;
     double box[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (mover) {
-        load_env<PLAIN>(a, seed, step_counter, i, active, q, cmd0, cmd1);
+        load_env<PLAIN>(a, seed, step_counter, i, active, q, cmd0, cmd1, !noise_by_scorer);
     } else if (scanner) {
         if (!PLAIN) q.min_dist = as_global(a.hot.st.min_dist)[i];   // (PLAIN: the scan only needs the target index)
         q.target = as_global(a.hot.st.target_idx)[i];
@@ -1249,9 +1270,20 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             for (int k = 0; k < 8; ++k) box[k] = a.hot.path_bbox[g * 8 + k];
         }
     }
+    if (mover && map_origins) {   // (per map entry: in flight across barrier 0)
+        const int64_t g = slot_of(a.S, i, q);
+        org_x = as_global(map_origins)[2 * g + 0];
+        org_y = as_global(map_origins)[2 * g + 1];
+    }
+    __syncthreads();   // barrier 0: the noise is in LDS (the movers' loads have landed meanwhile)
     // (2) mover: the robot model (_env_step, envs/base/env.py:442-461); the pose the reward provider will see goes to the scorer
     Robot& r = q.r;
     if (mover) {
+        if (noise_by_scorer) {
+            q.z[0] = hand_score[lane];
+            q.z[1] = hand_score[kBlock + lane];
+            q.z[2] = hand_score[2 * kBlock + lane];
+        }
         q.old = r.p;
         q.drawn = 0;
         DIAG_STAMP(1);   // (the compiler may move loads across this: indicative only)
@@ -1268,26 +1300,21 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     if (mover) {
         // (3a) collision: distance-field classification; an undecided env is parked below
         const int64_t g = slot_of(a.S, i, q);
-        double ox = a.S->map.ox, oy = a.S->map.oy;
-        if (a.S->map.origins) {
-            ox = a.S->map.origins[2 * g + 0];
-            oy = a.S->map.origins[2 * g + 1];
-        }
-        const int px = (int)rint((r.p.x - ox) * a.S->map.inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
-        const int py = (int)rint((r.p.y - oy) * a.S->map.inv_res);
-        const double c = cos(r.p.th), s = sin(r.p.th);
-        const int64_t map_env = a.S->map.shared ? 0 : g;
+        const int px = (int)rint((r.p.x - org_x) * map_inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
+        const int py = (int)rint((r.p.y - org_y) * map_inv_res);
+        double c, s;
+        cos_sin(r.p.th, c, s);
+        const int64_t map_env = a.hot.map_shared ? 0 : g;
         OuterLookups look;
         look.off_map = true;
         if (!(a.flags & (kAblateNoCollision | kAblateNoClassify))) {
             // (a shared field is 18 KB for the 183 x 183 map and stays in the CU's L1: a copy in LDS measured no faster)
             if (a.hot.near)
-                look = outer_lookups_near(a.S->cull, as_global(a.hot.near) + map_env * a.S->cull.near_stride, a.S->map.rows,
-                                          a.S->map.cols, px, py, c, s);
+                look = outer_lookups_near(outer, as_global(a.hot.near) + map_env * near_stride, map_rows, map_cols, px, py, c, s);
             else
-                look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
+                look = outer_lookups_issue(a.S->cull, map_env, map_rows, map_cols, px, py, c, s);
         }
-        const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
+        const int cls = active ? (a.hot.near ? outer_lookups_verdict(outer, look) : outer_lookups_verdict(a.S->cull, look)) : kFree;
         if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
             park = true;
             q.c = c;
