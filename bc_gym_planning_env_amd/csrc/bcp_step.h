@@ -33,7 +33,8 @@ struct MapDesc {
 
 struct PathDesc {
     const double* pts;   // [len][5] = x, y, theta, cos(theta), sin(theta); shared or [N][max_len][5]
-    const double* bbox;  // [8] = xmin, xmax, ymin, ymax of the way points, then the bucket grid x0, 1/wx, y0, 1/wy
+    const double* bbox;  // [kBoxDoubles] per path: xmin, xmax, ymin, ymax of the way points, the bucket grid x0, 1/wx, y0,
+                         // 1/wy, then (private paths) the costmap origin and the path length of the entry -- see kBoxOrigin
     const int16_t* index; // [2 axes][kPathBuckets][2] = first / last way point index that can be reached from a bucket
     const int32_t* lens;
     int32_t max_len, shared;
@@ -78,6 +79,7 @@ struct StepHot {
     int64_t map_env_stride;
     int32_t model, lds_path_doubles, path_shared, pending_cap;
     int32_t map_rows, map_cols, map_wpr, map_shared;
+    int32_t path_max_len;
 };
 
 constexpr int kShards = 64;  // a wave parks into shard (block index % kShards)
@@ -212,6 +214,11 @@ __global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restr
 }
 
 constexpr int kPathBuckets = 64;
+// One 128-byte record per path entry.  With private paths an env needs a handful of small per-entry values every step --
+// bounding box, costmap origin, path length -- that would each cost a memory sector of their own: they share a line.
+constexpr int kBoxDoubles = 16;
+constexpr int kBoxOrigin = 8;   // [8], [9]: origin of the entry's costmap (world_record_kernel)
+constexpr int kBoxLen = 10;     // [10]: number of way points, as a double
 
 // Per path: bounding box of the way points and a 1-D bucket grid per axis over [min - sp, max + sp].
 __device__ __forceinline__ void path_bbox_one(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
@@ -226,7 +233,7 @@ __device__ __forceinline__ void path_bbox_one(const double* __restrict__ xyt, co
         y0 = fmin(y0, q[3 * j + 1]);
         y1 = fmax(y1, q[3 * j + 1]);
     }
-    double* o = bbox + 8 * p;
+    double* o = bbox + kBoxDoubles * p;
     o[0] = x0;
     o[1] = x1;
     o[2] = y0;
@@ -247,6 +254,20 @@ __global__ void path_bbox_kernel(const double* __restrict__ xyt, const int32_t* 
         path_bbox_one(xyt, lens, max_len, sel.entry(it), sp_prune, bbox);
 }
 
+// the rest of a path entry's record: origin of the entry's costmap (or of the shared one) and its length
+__global__ void world_record_kernel(EntrySelect sel, const double* __restrict__ origins, double ox, double oy,
+                                    const int32_t* __restrict__ lens, int max_len, double* __restrict__ bbox)
+{
+    const int64_t total = sel.size();
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = sel.entry(it);
+        double* o = bbox + kBoxDoubles * p;
+        o[kBoxOrigin] = origins ? origins[2 * p] : ox;
+        o[kBoxOrigin + 1] = origins ? origins[2 * p + 1] : oy;
+        o[kBoxLen] = (double)(lens ? lens[p] : max_len);
+    }
+}
+
 // index[p][axis][b] = {first, last} way point whose coordinate lies within sp of bucket b (widened by a guard band
 // that swallows the rounding of the bucket computation); {32767, -1} when there is none.  Any way point with
 // |x_j - x| <= sp_prune for a query x that falls into bucket b is inside [first, last].
@@ -259,7 +280,7 @@ __device__ __forceinline__ void path_index_one(const double* __restrict__ xyt, c
     const int64_t p = t / (2 * kPathBuckets);
     const int m = lens ? lens[p] : max_len;
     const double* q = xyt + p * (int64_t)max_len * 3;
-    const double o = bbox[8 * p + 4 + 2 * axis], w = 1.0 / bbox[8 * p + 5 + 2 * axis];
+    const double o = bbox[kBoxDoubles * p + 4 + 2 * axis], w = 1.0 / bbox[kBoxDoubles * p + 5 + 2 * axis];
     const double guard = 1e-6 * w + 1e-12;
     const double lo = o + b * w - sp_prune - guard, hi = o + (b + 1) * w + sp_prune + guard;
     int first = 32767, last = -1;
@@ -668,8 +689,9 @@ __device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const
 template <bool PLAIN, typename A>
 __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
                                              const PathWindow* free_window = nullptr, bool have_score = false,
-                                             ScoredFree score = ScoredFree())
-{   // (the score travels by value: a pointer to a local made the compiler keep it in scratch memory)
+                                             ScoredFree score = ScoredFree(), int known_len = -1)
+{   // (the score travels by value: a pointer to a local made the compiler keep it in scratch memory;
+    //  known_len >= 0: the caller already holds the length of this env's path)
     const DevParams& P = a.S->P;
     const int pose_delay = PLAIN ? 0 : P.pose_delay, state_delay = PLAIN ? 0 : P.state_delay;
     const bool pure_pursuit = !PLAIN && P.reward_provider == BCP_REWARD_PURE_PURSUIT;
@@ -697,7 +719,7 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
     bool goal;
     const int64_t g = slot_of(a.S, i, q);
     const double* pts = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
-    m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
+    m = known_len >= 0 ? known_len : (a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g]);
     if (pure_pursuit) {
         if (have_score && !hit) {   // the scorer wave has already done it (no collision: the flag it assumed stands)
             rew = score.rew;
@@ -716,7 +738,7 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
             target = score.target;
         } else if (!(a.flags & kAblateNoReward)) {
             // way-point window of the pose: the caller may have looked it up already for the un-rolled-back pose
-            const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : g * 8);
+            const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : g * kBoxDoubles);
             const int16_t* index = a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
             const PathWindow w =
                 (free_window && !hit && !pose_delay) ? *free_window : path_window(P, bbox, index, seen[0], seen[1]);
@@ -946,7 +968,7 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
         } else {
             const int64_t g = a.hot.geom_of_env ? (int64_t)q.geom : i;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) box[k] = a.hot.path_bbox[g * 8 + k];
+            for (int k = 0; k < 8; ++k) box[k] = a.hot.path_bbox[g * kBoxDoubles + k];
         }
     }
     if (tid < nq) qv[tid] = my_q;
@@ -1257,6 +1279,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     Pending q;
     double cmd0 = 0.0, cmd1 = 0.0;
     double box[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int my_len = a.hot.path_max_len;   // way points of this env's path (private paths: from the entry's record)
     if (mover) {
         load_env<PLAIN>(a, seed, step_counter, i, active, q, cmd0, cmd1, !noise_by_scorer);
     } else if (scanner) {
@@ -1267,10 +1290,16 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         if (!a.hot.path_shared) {
             const int64_t g = a.hot.geom_of_env ? (int64_t)q.geom : i;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) box[k] = a.hot.path_bbox[g * 8 + k];
+            for (int k = 0; k < 8; ++k) box[k] = a.hot.path_bbox[g * kBoxDoubles + k];
+            my_len = (int)as_global(a.hot.path_bbox)[g * kBoxDoubles + kBoxLen];
         }
     }
-    if (mover && map_origins) {   // (per map entry: in flight across barrier 0)
+    if (mover && !a.hot.path_shared) {   // private paths: origin and length of the entry share a line (in flight across barrier 0)
+        const int64_t g = slot_of(a.S, i, q);
+        org_x = as_global(a.hot.path_bbox)[g * kBoxDoubles + kBoxOrigin];
+        org_y = as_global(a.hot.path_bbox)[g * kBoxDoubles + kBoxOrigin + 1];
+        my_len = (int)as_global(a.hot.path_bbox)[g * kBoxDoubles + kBoxLen];
+    } else if (mover && map_origins) {   // (private maps with a shared path)
         const int64_t g = slot_of(a.S, i, q);
         org_x = as_global(map_origins)[2 * g + 0];
         org_y = as_global(map_origins)[2 * g + 1];
@@ -1333,8 +1362,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
         else
             win = path_window(P, box, a.S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
-        const int m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
-        const double* gpath = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
+        const int m = my_len;
+        const double* gpath = a.hot.path_pts + (a.hot.path_shared ? 0 : g * (int64_t)a.hot.path_max_len * 5);
         if (PLAIN) {
             // this member's slice of the candidate window [max(lo, target), min(hi, m - 1)], counted from the top
             const int lo = max(win.lo, q.target), hi = min(win.hi, m - 1);
@@ -1401,7 +1430,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             const __attribute__((address_space(3))) int32_t* found = (__attribute__((address_space(3))) int32_t*)hand_score;
             const int last = max(max(found[lane], found[kBlock + lane]), found[2 * kBlock + lane]);
             const int64_t g = slot_of(a.S, i, q);
-            const int m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
+            const int m = my_len;
             sc.min_dist = q.min_dist;
             sc.target = q.target;
             if (lds_path)
@@ -1416,7 +1445,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         }
         DIAG_STAMP(6);    // mover: reward provider done
         if (active && !park)
-            finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, !(a.flags & kAblateNoReward), sc);
+            finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len);
     }
     DIAG_STAMP_W(8, 9);   // helper: past the second barrier
     const double vqx = lane < P.n_verts ? qv[2 * lane] : 0.0, vqy = lane < P.n_verts ? qv[2 * lane + 1] : 0.0;   // (row-by-row fallback)
@@ -1466,7 +1495,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             if (verdict == 0) verdict = __hip_atomic_load(&my_rec->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_s_sleep(1);
         }
-        if (park) finalize_env<PLAIN>(a, i, q, verdict == 2, lds_path, nullptr, !(a.flags & kAblateNoReward), sc);
+        if (park) finalize_env<PLAIN>(a, i, q, verdict == 2, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len);
     }
     DIAG_STAMP(13);            // mover: out of tickets
     DIAG_STAMP_W(8, 14);       // helper: out of tickets

@@ -652,7 +652,7 @@ __global__ void reward_kernel(const StepStatic* __restrict__ S, const double* __
         rew = reward_pure_pursuit(pts, m, x, y, collided && collided[i], min_dist, target);
         reached = hypot(pts[5 * (m - 1)] - x, pts[5 * (m - 1) + 1] - y) < 1.0;   // reward.py:141-150
     } else {
-        const PathWindow w = path_window(P, S->path.bbox + g * 8, S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+        const PathWindow w = path_window(P, S->path.bbox + g * kBoxDoubles, S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
         rew = reward_step(P, pts, w, m, x, y, th, min_dist, target);
         reached = target > m - 1;                                                 // reward.py:66-69
     }
@@ -674,7 +674,7 @@ __global__ void find_last_reached_kernel(const StepStatic* __restrict__ S, const
     const double* pts = S->path.pts + g * (int64_t)S->path.max_len * 5;
     const int m = S->path.shared ? S->path.max_len : S->path.lens[g];
     const double x = poses[3 * i], y = poses[3 * i + 1], th = poses[3 * i + 2];
-    const PathWindow w = path_window(S->P, S->path.bbox + g * 8, S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+    const PathWindow w = path_window(S->P, S->path.bbox + g * kBoxDoubles, S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
     out[i] = last_reached_from(S->P, pts, w, m, 0, x, y, th);
 }
 
@@ -1068,6 +1068,14 @@ static void launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_en
     launch_near_tiles(h, sel, max_entries, s);
 }
 
+// origin and length into the path records of private paths (kBoxOrigin, kBoxLen): needs both the costmaps and the paths
+static void launch_world_records(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
+{
+    if (!h->path_bbox || h->path.shared || !h->map.bits) return;
+    hipLaunchKernelGGL(world_record_kernel, dim3(stride_grid(max_entries, 256, sel.list != nullptr)), dim3(256), 0, s, sel,
+                       h->map.origins, h->map.ox, h->map.oy, h->path.lens, h->path.max_len, h->path_bbox);
+}
+
 static void launch_path_data(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
 {
     const PathDesc& p = h->path;
@@ -1077,6 +1085,7 @@ static void launch_path_data(bcp_handle* h, EntrySelect sel, int64_t max_entries
                        sel, h->dev.sp_prune, h->path_bbox);
     hipLaunchKernelGGL(path_index_kernel, dim3(stride_grid(max_entries * 2 * kPathBuckets, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src,
                        p.lens, p.max_len, sel, h->dev.sp_prune, h->path_bbox, h->path_index);
+    launch_world_records(h, sel, max_entries, s);
 }
 
 extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows, int32_t cols, int32_t shared,
@@ -1190,6 +1199,12 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
     }
     h->have_map = true;
     h->static_dirty = true;
+    if (h->have_path && !h->path.shared) {   // the path records carry the origins
+        const int64_t n_paths = n_slots(h);
+        const EntrySelect all_paths = {nullptr, nullptr, n_paths};
+        launch_world_records(h, all_paths, n_paths, s);
+        HIP_TRY(hipGetLastError());
+    }
     return BCP_OK;
 }
 
@@ -1251,7 +1266,7 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
         h->path5_bytes = bytes;
     }
     const int64_t n_paths = shared ? 1 : n_slots(h);
-    const size_t bb_bytes = (size_t)n_paths * 8 * sizeof(double);
+    const size_t bb_bytes = (size_t)n_paths * kBoxDoubles * sizeof(double);
     if (bb_bytes > h->path_bbox_bytes) {
         if (h->path_bbox) HIP_TRY(hipFree(h->path_bbox));
         h->path_bbox = nullptr;
@@ -1426,6 +1441,7 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     hot.map_cols = S.map.cols;
     hot.map_wpr = S.map.wpr;
     hot.map_shared = S.map.shared;
+    hot.path_max_len = S.path.max_len;
     hot.near = S.cull.on ? S.cull.near : nullptr;
     a.actions = io->actions;
     a.noise_z = io->noise_z;
