@@ -1,15 +1,20 @@
-"""In-kernel s_memtime stamps of step_local_kernel on the metric workload (needs the -DBCP_DIAG build at
-tools/libbcplan_diag.so, see tools/ablate.py): where a workgroup's time goes, in shader cycles."""
+"""In-kernel s_memtime stamps of step_local_kernel on the metric workload (`c4` as an argument: on BASELINE configs[3])
+(needs the -DBCP_DIAG build at tools/libbcplan_diag.so, see tools/ablate.py): where a workgroup's time goes, in shader cycles."""
 import sys, os, ctypes as C, numpy as np, torch
 sys.path.insert(0, '.')
 from bc_gym_planning_env_amd import _lib
 _lib.LIB_PATH = os.path.join('tools', 'libbcplan_diag.so')
 import bench
 n = 65536
-env, g = bench.make_env(n, 0, 0, 1)
 rng = np.random.RandomState(0)
-pool = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(16)])).cuda()
-bench.steady_state(env, pool, rng)
+if "c4" in sys.argv[1:]:   # BASELINE configs[3]: private AisleTurn costmaps and paths
+    env = bench.make_c4_env(n, 0)
+    pool = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(16)])).cuda()
+    bench.steady_state(env, pool, rng)
+else:
+    env, g = bench.make_env(n, 0, 0, 1)
+    pool = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(16)])).cuda()
+    bench.steady_state(env, pool, rng)
 for k in range(50):
     env.step(pool[k % 16])
 torch.cuda.synchronize()
