@@ -476,6 +476,7 @@ __device__ __forceinline__ bool coop_collides_quad(const DevParams& P, double qx
 // owned by the calling wave.  More than kSparseCap lethal cells under the image (filled obstacles) make the function
 // return kSparseTooMany: the caller then rasterises.
 constexpr int kSparseCap = 256;
+constexpr int kSparseFilterFrom = 24;   // lists longer than this are filtered by the footprint's oriented box first
 constexpr int kSparseLdsWords = kSparseCap + 1;   // the list + its fill counter
 enum { kSparseFree = 0, kSparseHit = 1, kSparseTooMany = 2 };
 
@@ -574,8 +575,30 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 q
         }
     }
     wave_lds_sync();
-    const int total = bcast_i((int)list[kSparseCap], 0);
+    int total = bcast_i((int)list[kSparseCap], 0);
     if (total > kSparseCap) return kSparseTooMany;
+    // A long list (the median is 3 cells) sets the pace of its whole workgroup -- and the slowest workgroup that of the
+    // step: drop the cells that lie outside the footprint's own bounding box (robot frame, 2 px of slack for vertex
+    // rounding and Bresenham) first, 64 cells per trip, compacting the list in place.  Short lists skip this: the pass
+    // costs more than testing a dozen cells.
+    if (total > kSparseFilterFrom) {
+        const float cf = (float)c, sf = (float)s;
+        int kept = 0;
+        for (int base = 0; base < total; base += 64) {
+            const bool valid = base + lane < total;
+            const uint32_t cell = valid ? list[base + lane] : 0u;
+            const float x = (float)(umin + (int)(cell & 0xFFFFu)), y = (float)(vmin + (int)(cell >> 16));
+            const float xr = x * cf + y * sf, yr = y * cf - x * sf;
+            const bool keep = valid && xr >= P.qbox[0] - 2.0f && xr <= P.qbox[1] + 2.0f && yr >= P.qbox[2] - 2.0f &&
+                              yr <= P.qbox[3] + 2.0f;
+            const uint64_t keeps = __ballot(keep);
+            wave_lds_sync();   // (every lane has read its cell before anybody overwrites the slots below it)
+            if (keep) list[kept + (int)__popcll(keeps & ((1ull << lane) - 1ull))] = cell;
+            kept += (int)__popcll(keeps);
+        }
+        wave_lds_sync();
+        total = kept;
+    }
     // ---- a group of lanes per cell, a lane per edge
     const int per_pass = 64 / G;
     const uint64_t group_mask = (G == 16 ? 0xFFFFull : 0xFFFFFFFFull) << (G * group);

@@ -523,14 +523,25 @@ __device__ unsigned long long g_diag[kDiagBlocks * 16];
 #define DIAG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 // lane 0 of wave `w` of the workgroup
 #define DIAG_STAMP_W(w, k) do { if (threadIdx.x == (w) * 64 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// maxima over the waves of a workgroup live in the upper half of the array (slot k of workgroup b: (2048 + b) * 16 + k)
+#define DIAG_MAX(k, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) atomicMax(&g_diag[(2048 + blockIdx.x) * 16 + (k)], (unsigned long long)(v)); } while (0)
+#define DIAG_NOW() __builtin_amdgcn_s_memtime()
 extern "C" int bcp_diag_read(unsigned long long* out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(g_diag));
+}
+extern "C" int bcp_diag_clear()
+{
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_diag)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(g_diag));
 }
 
 #else
 #define DIAG_STAMP(k) do { } while (0)
 #define DIAG_STAMP_W(w, k) do { } while (0)
+#define DIAG_MAX(k, v) do { } while (0)
+#define DIAG_NOW() 0ull
 #endif
 
 
@@ -1467,6 +1478,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         const int64_t g = a.hot.map_shared ? 0 : (a.hot.geom_of_env ? (int64_t)e->geom : env);
         const uint32_t* words = a.hot.map_bits + g * a.hot.map_env_stride;
         bool h = false;
+        [[maybe_unused]] const unsigned long long test_from = DIAG_NOW();
+        [[maybe_unused]] int how = 0;
         if (!(a.flags & kAblateNoCoop)) {
             // the lethal cells under the image tested one by one; a map too dense for that is rasterised row by row
             const int verdict = map_words
@@ -1477,7 +1490,9 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             h = verdict == kSparseHit;
             if (verdict == kSparseTooMany)
                 h = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr);
+            how = verdict;
         }
+        DIAG_MAX(0, ((DIAG_NOW() - test_from) << 4) | (unsigned)how);   // the longest exact test of the workgroup, and its kind
         DIAG_STAMP_W(8, 11);   // helper: verdict
         int next = 0;
         if (lane == 0) {

@@ -19,10 +19,15 @@ for k in range(50):
     env.step(pool[k % 16])
 torch.cuda.synchronize()
 L = _lib.load()
+L.bcp_diag_clear()          # (the maxima accumulate: look at ONE step)
+env.step(pool[3])
+torch.cuda.synchronize()
 buf = (C.c_ulonglong * (4096 * 16))()
 L.bcp_diag_read.argtypes = [C.c_void_p]
 L.bcp_diag_read(buf)
-a = np.array(buf[:]).reshape(4096, 16).astype(np.int64)[:n // 256]
+raw = np.array(buf[:]).reshape(4096, 16).astype(np.int64)
+a = raw[:n // 256]
+upper = raw[2048:2048 + n // 256]   # maxima over the waves of a workgroup (DIAG_MAX)
 t0 = a[:, 0].min()
 names = {1: "mover: loads issued .. robot model starts", 2: "mover: robot model done", 3: "mover: past barrier 1",
          4: "mover: classified and parked", 5: "mover: past barrier 2", 6: "mover: reward provider done", 7: "mover: decided envs finished",
@@ -39,3 +44,15 @@ print("  helper: ticket -> verdict  median %d  p90 %d ;  verdict -> verdict post
 end = np.maximum(a[:, 13], a[:, 14]) - t0
 print("workgroup end since the earliest start: median %d  p90 %d  max %d cycles" % (np.median(end), np.percentile(end, 90), end.max()))
 
+# the kernel ends with its slowest workgroup: end time against the number of parked poses
+endw = np.maximum(a[:, 13], a[:, 14]) - a[:, 0]
+for k in sorted(set(a[:, 15].tolist())):
+    sel = a[:, 15] == k
+    print("  parked %2d: %3d workgroups, done after median %6d  max %6d cycles" % (k, sel.sum(), np.median(endw[sel]), endw[sel].max()))
+# the longest exact test of each workgroup: cycles and kind (0 free, 1 hit, 2 too many cells -> row-by-row rasteriser)
+dur, kind = upper[:, 0] >> 4, upper[:, 0] & 15
+for k in (0, 1, 2):
+    sel = (kind == k) & (a[:, 15] > 0)
+    if sel.any():
+        print("  longest test of a workgroup, kind %d: %3d workgroups, median %6d  max %6d cycles; those workgroups end after median %6d max %6d" % (
+            k, sel.sum(), np.median(dur[sel]), dur[sel].max(), np.median(endw[sel]), endw[sel].max()))
