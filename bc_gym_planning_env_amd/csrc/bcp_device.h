@@ -142,11 +142,32 @@ __device__ __forceinline__ Pose kinematic_step_noise(Pose p, double v, double w,
 }
 
 // utilities/path_tools.py:298-323 for the two-row call of tricycle_model.py:520-529
-__device__ __forceinline__ int path_velocity(Pose p0, Pose p1, double dt, double& v, double& w)
+// cos / sin of the heading before the step, when the caller already holds them (by value: a pointer to a local would
+// send them through scratch memory)
+struct KnownHeading {
+    double c0, s0;
+    bool known;
+};
+
+__device__ __forceinline__ KnownHeading no_known_heading()
+{
+    KnownHeading k;
+    k.c0 = k.s0 = 0.0;
+    k.known = false;
+    return k;
+}
+
+__device__ __forceinline__ int path_velocity(Pose p0, Pose p1, double dt, double& v, double& w,
+                                             KnownHeading old_heading = no_known_heading())
 {
     double dx = p1.x - p0.x, dy = p1.y - p0.y;
     double c0, s0;
-    cos_sin(p0.th, c0, s0);
+    if (old_heading.known) {
+        c0 = old_heading.c0;
+        s0 = old_heading.s0;
+    } else {
+        cos_sin(p0.th, c0, s0);
+    }
     double sign = signd(c0 * dx + s0 * dy);
     if (sign == 0.0) sign = signd(s0 * dy);
     double ds = sqrt(dx * dx + dy * dy) * sign;
@@ -165,8 +186,9 @@ struct Robot {
 
 // TricycleRobot.step (robot_models/tricycle_model.py:478-538, with :71-188) and
 // DiffDriveRobot.step (robot_models/differential_drive.py:236-265)
+// (old_heading: step_local_kernel has an idle wave compute cos / sin of the old heading while the state loads are in flight)
 __device__ __forceinline__ int robot_step(const DevParams& P, Robot& r, double cmd0, double cmd1, const double z[3],
-                                          int& drawn)
+                                          int& drawn, KnownHeading old_heading = no_known_heading())
 {
     Pose last = r.p, np_;
     double mv, mw;
@@ -202,7 +224,7 @@ __device__ __forceinline__ int robot_step(const DevParams& P, Robot& r, double c
         np_ = P.noise_on ? kinematic_step_noise(last, cmd0, cmd1, P.dt, P.alpha, z, drawn)
                          : kinematic_step(last, cmd0, cmd1, P.dt);
     }
-    int err = path_velocity(last, np_, P.dt, mv, mw);
+    int err = path_velocity(last, np_, P.dt, mv, mw, old_heading);
     r.p = np_;
     r.v = mv;
     r.w = mw;

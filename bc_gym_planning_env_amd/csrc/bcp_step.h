@@ -1276,6 +1276,15 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         hand_score[kBlock + lane] = z[1];
         hand_score[2 * kBlock + lane] = z[2];
     }
+    //     ... and the first helper wave of the pair cos / sin of the OLD heading, which the robot model needs at its very
+    //     end (path_velocity): one transcendental pair off the mover's chain.  (The tricycle's wheel-angle pair by the
+    //     second helper as well made barrier 0 later than it made the model shorter.)
+    if (!mover && !scorer && member == 1) {
+        double c0, s0;
+        cos_sin(as_global(a.hot.st.angle)[i], c0, s0);
+        hand_pose[lane] = c0;
+        hand_pose[kBlock + lane] = s0;
+    }
     // staging: footprint vertices, the shared path with its bounding box and bucket index, the counters
     if (tid < nq) qv[tid] = P.qverts[tid >> 1][tid & 1];
     for (int k = tid; k < npath; k += kLocalWaves * kBlock) qv[nq + k] = as_global(a.hot.path_pts)[k];
@@ -1327,7 +1336,11 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         q.old = r.p;
         q.drawn = 0;
         DIAG_STAMP(1);   // (the compiler may move loads across this: indicative only)
-        q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn);
+        KnownHeading old_heading;   // (from the helper wave, barrier 0)
+        old_heading.c0 = hand_pose[lane];
+        old_heading.s0 = hand_pose[kBlock + lane];
+        old_heading.known = true;
+        q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn, old_heading);
         const bool delayed = !PLAIN && P.pose_delay > 0 && q.iter + 1 > 1;
         hand_pose[lane] = delayed ? q.popped_pose[0] : r.p.x;
         hand_pose[kBlock + lane] = delayed ? q.popped_pose[1] : r.p.y;
