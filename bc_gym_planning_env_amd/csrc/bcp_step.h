@@ -1213,7 +1213,7 @@ static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles, int staged
 {
     size_t bytes = ((size_t)2 * n_verts + lds_path_doubles + (size_t)kLocalPairs * 6 * kBlock + 8) * sizeof(double);
     bytes += 2 * kBlock * sizeof(uint32_t);          // bucket index of the shared path
-    bytes += 4 * sizeof(int32_t);                    // parked count, ticket counter
+    bytes += 8 * sizeof(int32_t);                    // parked count, ticket counter, movers parked, scans done per pair
     bytes = (bytes + 15) & ~(size_t)15;
     bytes += (size_t)kLocalEnvs * sizeof(ParkedPose);
     bytes += (size_t)kLocalWaves * kSparseLdsWords * sizeof(uint32_t);   // a cell list per wave (coop_collides_sparse)
@@ -1252,9 +1252,9 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     __attribute__((address_space(3))) double* hand_score = hand_pose + 3 * kBlock;
     __attribute__((address_space(3))) double* lds_box = qv + nq + npath + kLocalPairs * 6 * kBlock;   // [8]
     __attribute__((address_space(3))) uint32_t* lds_index = (__attribute__((address_space(3))) uint32_t*)(lds_box + 8);  // [128]
-    __attribute__((address_space(3))) int32_t* ctl = (__attribute__((address_space(3))) int32_t*)(lds_index + 2 * kBlock);   // [4]
+    __attribute__((address_space(3))) int32_t* ctl = (__attribute__((address_space(3))) int32_t*)(lds_index + 2 * kBlock);   // [8]
     const uint32_t rec_off = (uint32_t)((((size_t)(nq + npath + kLocalPairs * 6 * kBlock + 8) * sizeof(double) +
-                                          2 * kBlock * sizeof(uint32_t) + 4 * sizeof(int32_t)) + 15) & ~(size_t)15);
+                                          2 * kBlock * sizeof(uint32_t) + 8 * sizeof(int32_t)) + 15) & ~(size_t)15);
     __attribute__((address_space(3))) ParkedPose* rec =
         (__attribute__((address_space(3))) ParkedPose*)((__attribute__((address_space(3))) char*)lds_dyn + rec_off);
     const LdsU32 cell_list = (LdsU32)(rec + kLocalEnvs) + wave * kSparseLdsWords;
@@ -1292,7 +1292,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         if (tid >= 512 && tid < 520) lds_box[tid - 512] = a.hot.path_bbox[tid - 512];
         if (tid >= 576 && tid < 576 + 128) lds_index[tid - 576] = reinterpret_cast<const uint32_t*>(a.hot.path_index)[tid - 576];
     }
-    if (tid >= 960 && tid < 964) ctl[tid - 960] = 0;
+    if (tid >= 960 && tid < 968) ctl[tid - 960] = 0;
     for (int k = tid; k < map_words; k += kLocalWaves * kBlock) lds_map[k] = as_global(a.hot.map_bits)[k];   // (read after the barriers)
 
     // (1) the mover's state / action, the scorer's reward-state words
@@ -1440,9 +1440,24 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     }
     DIAG_STAMP(4);        // mover: classified and parked
     DIAG_STAMP_W(4, 8);   // scorer of pair 0: scanned
-    __syncthreads();
+    // "Barrier 2" is two counters in LDS instead of an s_barrier: a mover only needs the scan results of ITS pair, and the
+    // other waves only need every mover's poses parked -- the waves that finish their scan first start on the parked
+    // poses while the slowest scan of the workgroup is still running (release adds / acquire polls, workgroup scope).
+    if (mover) {
+        if (lane == 0) __hip_atomic_fetch_add(&ctl[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int scans = PLAIN ? 3 : 1;
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[4 + pair], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < scans)
+            __builtin_amdgcn_s_sleep(1);
+    } else if (scanner && lane == 0) {
+        __hip_atomic_fetch_add(&ctl[4 + pair], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // (everybody: the number of parked poses must be final before a wave draws tickets -- a ticket is consumed by the
+    //  draw, so a wave that compared it with a stale count would drop a pose, and its owner would wait for ever)
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < kLocalPairs)
+        __builtin_amdgcn_s_sleep(1);
     DIAG_STAMP(5);
-    const int n_parked = __builtin_amdgcn_readfirstlane(ctl[0]);   // (scalar: the ticket loop below must stay wave-uniform)
+    // (scalar: the ticket loop below must stay wave-uniform)
+    const int n_parked = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     // (5) movers: the rest of the reward provider, handed to the parked records, then the decided envs are finished;
     //     everybody else goes straight to the parked poses
     ScoredFree sc;
