@@ -350,12 +350,12 @@ __device__ __forceinline__ bool way_point_reached(const DevParams& P, double sx,
 // (four at a time, like the global-memory form below, measured no faster: the scan is not bound by the LDS round trip)
 template <typename PathPtr>
 __device__ __forceinline__ int last_reached_from(const DevParams& P, PathPtr path, PathWindow w, int m, int target,
-                                                 double x, double y, double th)
+                                                 double x, double y, double th, int stride = 1)
 {
     if (target > m - 1) return -1;
     const int lo = max(w.lo, target);
     const int hi = min(w.hi, m - 1);
-    for (int j = hi; j >= lo; --j) {
+    for (int j = hi; j >= lo; j -= stride) {
         const PathPtr s = path + 5 * j;
         // all five values of the way point are fetched up front (one latency instead of three dependent ones)
         if (way_point_reached(P, s[0], s[1], s[2], s[3], s[4], x, y, th)) return j;
@@ -1389,15 +1389,24 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         const int m = my_len;
         const double* gpath = a.hot.path_pts + (a.hot.path_shared ? 0 : g * (int64_t)a.hot.path_max_len * 5);
         if (PLAIN) {
-            // this member's slice of the candidate window [max(lo, target), min(hi, m - 1)], counted from the top
+            // this member's share of the candidate window [max(lo, target), min(hi, m - 1)].  Way points in LDS: every
+            // third candidate (the ones near the target pass the cheap box test and cost ten times the others: contiguous
+            // thirds left the wave with the bottom third scanning 2 k cycles after the one with the top third was done);
+            // way points in memory: a contiguous third, counted from the top (four neighbours per round trip).
             const int lo = max(win.lo, q.target), hi = min(win.hi, m - 1);
-            const int third = (max(hi - lo + 1, 0) + 2) / 3;
-            PathWindow part;
-            part.hi = hi - member * third;
-            part.lo = max(lo, part.hi - third + 1);
             int last;
-            if (lds_path) last = last_reached_from(P, lds_path, part, m, q.target, x, y, th);
-            else last = last_reached_from(P, gpath, part, m, q.target, x, y, th);
+            if (lds_path) {
+                PathWindow part;
+                part.hi = hi - member;
+                part.lo = lo;
+                last = last_reached_from(P, lds_path, part, m, q.target, x, y, th, 3);
+            } else {
+                const int third = (max(hi - lo + 1, 0) + 2) / 3;
+                PathWindow part;
+                part.hi = hi - member * third;
+                part.lo = max(lo, part.hi - third + 1);
+                last = last_reached_from(P, gpath, part, m, q.target, x, y, th);
+            }
             ((__attribute__((address_space(3))) int32_t*)hand_score)[member * kBlock + lane] = last;
         } else {
             double min_dist = q.min_dist;
