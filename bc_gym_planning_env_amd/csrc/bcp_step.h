@@ -1190,9 +1190,12 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
 // So nothing leaves the CU here:
 //   * a workgroup = 256 envs = 4 (mover, scorer) wave pairs as in step_fast_pair_kernel + 8 helper waves: 16 waves, one
 //     workgroup per CU, four waves per SIMD;
+//   * the waves that idle until the new pose exists do what needs no pose: the scorers draw the step's odometry noise, a
+//     helper computes cos / sin of the old heading (barrier 0 hands both to the movers);
 //   * movers park the POSES of their undecided envs in LDS (40 bytes each; the env's state stays in the mover lane's
-//     registers) before the second barrier;
-//   * after it ALL 16 waves draw tickets (an LDS counter) and settle one parked pose each -- the exact test, cell by cell
+//     registers); "barrier 2" is a pair of LDS counters: a mover waits for the three scan results of its pair, everybody
+//     for all four movers' parked poses;
+//   * then ALL 16 waves draw tickets (an LDS counter) and settle one parked pose each -- the exact test, cell by cell
 //     (coop_collides_sparse) -- and post the verdict in the record, while the movers first finish their decided envs;
 //   * a mover lane that parked an env waits for its verdict (a few hundred cycles, LDS) and finishes the env itself:
 //     rollback on a hit, reward, done, in-kernel reset, stores -- in SIMD with the wave's other parked lanes.
@@ -1238,8 +1241,9 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     const bool mover = wave < kLocalPairs, scorer = wave >= kLocalPairs && wave < 2 * kLocalPairs;
     const int pair = wave & (kLocalPairs - 1);
     // PLAIN (continuous reward, no delays): the backward scan for the last reached way point -- the longest stretch of
-    // the reward provider -- is split three ways between the pair's scorer and its two helper waves (member 0 takes the
-    // top third of the candidate window, ...); the mover takes the maximum and does the rest of the provider itself.
+    // the reward provider -- is split three ways between the pair's scorer and its two helper waves (every third
+    // candidate of the window each; contiguous thirds for paths in global memory); the mover takes the maximum and does
+    // the rest of the provider itself.
     const bool scanner = PLAIN ? !mover : scorer;
     const int member = (wave >> 2) - 1;   // 0 = scorer, 1 / 2 = helpers (PLAIN only)
 
