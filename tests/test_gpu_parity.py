@@ -425,6 +425,64 @@ def test_private_maps_and_paths_vs_oracle(torch_cuda, oracle, mode):
     assert tot_r > 100
 
 
+@pytest.mark.parametrize("combo", ["private-maps-shared-path", "shared-map-private-paths"])
+def test_mixed_shared_and_private_geometry_vs_oracle(torch_cuda, oracle, combo):
+    """The two mixed cases: per-env costmaps (own origins) under one shared path, and one shared costmap under per-env
+    paths of different length -- the step finds the origin and the path length of an env in different places for each."""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    names = ["g8_traj_aisle_c4_00.npz", "g8_traj_aisle_c4_10.npz", "g8_traj_aisle_c4_01.npz", "g8_traj_aisle_c4_11.npz"]
+    gs = [load(nm) for nm in names]
+    n, steps = 768, 40
+    rng = np.random.RandomState(21)
+    res = float(gs[0]["resolution"])
+    params = EnvParams(resolution=res, refine_path=False)
+    if combo == "private-maps-shared-path":
+        # the same walls, shifted by a different whole number of cells per env: private maps with origins of their own
+        base = gs[0]["costmap"]
+        shifts = [(0, 0), (3, -2), (-4, 5), (7, 1)]
+        cms = []
+        for i in range(n):
+            dy, dx = shifts[i % 4]
+            cms.append(CostMap2D(np.roll(base, (dy, dx), axis=(0, 1)), res, gs[0]["origin"] - res * np.array([dx, dy], dtype=np.float64)))
+        path = gs[0]["path"]
+        env = BatchedPlanEnv(cms, path, params, n_envs=n, auto_reset=True, seed=5)
+        maps = np.stack([c.get_data() for c in cms])
+        origins = np.stack([c.get_origin() for c in cms])
+        pbuf = np.repeat(path[None], n, axis=0)
+        lens = [len(path)] * n
+    else:
+        cm = CostMap2D(gs[0]["costmap"], res, gs[0]["origin"])
+        paths = [gs[0]["path"][:len(gs[0]["path"]) - 2 * (i % 5)] for i in range(n)]
+        env = BatchedPlanEnv(cm, paths, params, n_envs=n, auto_reset=True, seed=5)
+        maps = np.repeat(cm.get_data()[None], n, axis=0)
+        origins = np.repeat(cm.get_origin()[None], n, axis=0)
+        max_len = max(len(p_) for p_ in paths)
+        pbuf = np.zeros((n, max_len, 3))
+        for i, p_ in enumerate(paths):
+            pbuf[i, :len(p_)] = p_
+        lens = [len(p_) for p_ in paths]
+    p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE)
+    ref = oracle.OracleBatch(p, n, maps, origins, res, pbuf, lens=lens)
+    ref.reset_from_paths()
+    np.testing.assert_array_equal(env.state.target_idx.cpu().numpy(), ref.target_idx)
+    zout = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    tot_r = tot_c = 0
+    for t in range(steps):
+        a = env.action_space.sample_batch(n, rng)
+        a[:, 0] *= 2.0
+        env.step(a, noise_z_out=zout)
+        ref.step(a.astype(np.float64), z_in(zout.cpu().numpy()), auto_reset=True, threads=8)
+        np.testing.assert_array_equal(env.done.cpu().numpy(), ref.done)
+        np.testing.assert_array_equal(env.collided_now.cpu().numpy(), ref.collided_now)
+        np.testing.assert_array_equal(env.state.target_idx.cpu().numpy(), ref.target_idx)
+        np.testing.assert_allclose(env.state.robot.cpu().numpy(), np.stack(ref.st), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(env.reward.cpu().numpy(), ref.reward, rtol=0, atol=ATOL)
+        tot_r += int((ref.reward == 1.0).sum())
+        tot_c += int(ref.collided_now.sum())
+    assert tot_r > 100
+
+
 def test_full_size_properties_65536(torch_cuda, oracle):
     """BASELINE size (65 536 envs, tricycle + noise, shared 183x183 map): size-independent properties.
       * replicas fed identical actions and normals stay bit-identical;
