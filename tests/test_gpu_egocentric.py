@@ -107,7 +107,8 @@ def test_random_poses_vs_oracle(torch_cuda, oracle, shared):
     from bc_gym_planning_env_amd import _lib
     f64p = C.POINTER(C.c_double)
     for org, size, border in (((-0.5, -2.0), (3.5, 4.0), 0), ((-1.0, -1.0), (2.0, 2.0), 255), (None, None, 7),
-                              ((-3.0, -0.7), (6.05, 1.45), 100)):
+                              ((-3.0, -0.7), (6.05, 1.45), 100),
+                              ((-0.1, -0.15), (0.3, 0.25), 9)):   # (6 x 5 px: the 4-pixels-per-lane kernels)
         o = None if org is None else np.array(org, dtype=np.float64)
         s = None if size is None else np.array(size, dtype=np.float64)
         shape = (C.c_int32 * 2)()
