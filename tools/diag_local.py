@@ -56,3 +56,9 @@ for k in (0, 1, 2):
     if sel.any():
         print("  longest test of a workgroup, kind %d: %3d workgroups, median %6d  max %6d cycles; those workgroups end after median %6d max %6d" % (
             k, sel.sum(), np.median(dur[sel]), dur[sel].max(), np.median(endw[sel]), endw[sel].max()))
+# the ten workgroups that end last: where did they lose the time?
+order = np.argsort(-endw)[:10]
+print("  latest workgroups: parked | robot model done, barrier 1, parked, scans in, reward done, decided done, out | longest test (kind)")
+for b in order:
+    d = a[b] - a[b, 0]
+    print("   wg %3d: %2d | %6d %6d %6d %6d %6d %6d %6d | %6d (%d)" % (b, a[b, 15], d[2], d[3], d[4], d[5], d[6], d[7], d[13], dur[b], kind[b]))
