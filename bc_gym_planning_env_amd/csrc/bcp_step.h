@@ -700,9 +700,10 @@ __device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const
 template <bool PLAIN, typename A>
 __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
                                              const PathWindow* free_window = nullptr, bool have_score = false,
-                                             ScoredFree score = ScoredFree(), int known_len = -1)
+                                             ScoredFree score = ScoredFree(), int known_len = -1, bool score_fits_hit = false)
 {   // (the score travels by value: a pointer to a local made the compiler keep it in scratch memory;
-    //  known_len >= 0: the caller already holds the length of this env's path)
+    //  known_len >= 0: the caller already holds the length of this env's path;
+    //  score_fits_hit: `score` was computed for the rolled-back pose of a colliding env -- continuous provider only)
     const DevParams& P = a.S->P;
     const int pose_delay = PLAIN ? 0 : P.pose_delay, state_delay = PLAIN ? 0 : P.state_delay;
     const bool pure_pursuit = !PLAIN && P.reward_provider == BCP_REWARD_PURE_PURSUIT;
@@ -743,7 +744,7 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
     } else {
         // the scorer wave has already done it (step_fast_pair_kernel) for the pose State exposes if nothing collides --
         // which, with a pose delay, is an earlier pose whatever this step's verdict (from the second step of an episode on)
-        if (have_score && (!hit || (pose_delay && iter > 1))) {
+        if (have_score && (!hit || score_fits_hit || (pose_delay && iter > 1))) {
             rew = score.rew;
             min_dist = score.min_dist;
             target = score.target;
@@ -1546,12 +1547,30 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     // (7) movers: the envs they parked are finished by the lane that holds their state, as soon as the verdicts are in
     //     (every parked pose has been claimed by now -- by this wave or by one that is working on it)
     if (mover && __ballot(park)) {
+        // While the verdicts are on their way: the reward a parked env gets IF its pose collides (provider run for the
+        // rolled-back pose) -- the longest part of finishing such an env, and the step ends with the workgroups that
+        // hold one.  Shared path in LDS, continuous provider without delays; otherwise finalize_env computes it itself.
+        const bool hit_score = PLAIN && lds_path && a.hot.path_shared && !(a.flags & kAblateNoReward);
+        ScoredFree sc_hit = sc;
+        if (hit_score && park) {
+            double md = q.min_dist;
+            int tg = q.target;
+            const PathWindow w = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index,
+                                             q.old.x, q.old.y);
+            sc_hit.rew = reward_step(P, lds_path, w, my_len, q.old.x, q.old.y, q.old.th, md, tg);
+            sc_hit.min_dist = md;
+            sc_hit.target = tg;
+        }
         int verdict = park ? 0 : 1;
         while (__ballot(verdict == 0)) {
             if (verdict == 0) verdict = __hip_atomic_load(&my_rec->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_s_sleep(1);
         }
-        if (park) finalize_env<PLAIN>(a, i, q, verdict == 2, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len);
+        if (park) {
+            const bool fits = hit_score && verdict == 2;
+            if (fits) sc = sc_hit;
+            finalize_env<PLAIN>(a, i, q, verdict == 2, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len, fits);
+        }
     }
     DIAG_STAMP(13);            // mover: out of tickets
     DIAG_STAMP_W(8, 14);       // helper: out of tickets
