@@ -20,9 +20,13 @@ def env_block(n_total, rank, world_size):
     return first, count
 
 
-def init_from_env(backend=None, timeout_s=180):
+def init_from_env(backend=None, timeout_s=180, force=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run, or bench.py's own
     launcher).  Returns (rank, world_size, local_rank).
+
+    A single rank needs no process group and gets none -- unless `force` (or BCP_DIST_FORCE=1) asks for one: the group,
+    the communicator and every collective of DoneGather then run for real at world size 1, which is how the RCCL
+    branch is exercised on a box with one GPU (tests/test_gpu_sharding.py).
 
     The transport is an explicit choice: `backend`, else BCP_DIST_BACKEND, else "nccl" (RCCL over xGMI) -- there is no
     fallback.  RCCL needs one GPU per rank; with fewer GPUs than ranks the call fails at once and names the rehearsal
@@ -33,13 +37,17 @@ def init_from_env(backend=None, timeout_s=180):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("BCP_DIST_FORCE", "0") not in ("", "0")
+    if (world > 1 or force) and not dist.is_initialized():
         import datetime
         if backend is None:
             backend = os.environ.get("BCP_DIST_BACKEND") or "nccl"
         if backend not in ("nccl", "gloo"):
             raise RuntimeError("BCP_DIST_BACKEND must be 'nccl' (RCCL) or 'gloo' (rehearsal), got %r" % (backend,))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29517")
         kwargs = {}
         if backend == "nccl":
             gpus = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
@@ -67,12 +75,15 @@ class DoneGather(object):
 
     def __init__(self, n_local, device, group=None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # with a process group every gather is a collective, also at world size 1 (init_from_env(force=True));
+        # without one there is nothing to gather from
+        self.collective = dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.collective else 1
         self.n_local = int(n_local)
         self.out = torch.zeros(self.world * self.n_local, dtype=torch.uint8, device=device)
 
     def __call__(self, done_local, async_op=False):
-        if self.world == 1:
+        if not self.collective:
             self.out.copy_(done_local)
             return None if async_op else self.out
         if self.out.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -99,7 +110,7 @@ class DoneGather(object):
             self._work[k].wait()
             self._work[k] = None
         self._stage[k].copy_(done_local)
-        if self.world == 1:
+        if not self.collective:
             self._outs[k].copy_(self._stage[k])
         elif self.out.is_cuda and dist.get_backend(self.group) == "gloo":
             host = torch.empty(self.out.shape, dtype=torch.uint8)

@@ -14,6 +14,11 @@ Workload (BASELINE.json configs[2], "C3"): 65 536 replicas per GPU of the Random
 device (Philox4x32-10), float32 actions ~ U(action_space) pre-staged in HBM, reset-on-done inside the kernel.
 A "step" is one pass of the hot path over all envs of the rank.  With N > 1 ranks the env index space is sharded in
 contiguous blocks (weak scaling); the done masks go into a device-side ring that is all-gathered every 8 steps.
+
+Timed region: barrier + synchronize, then `reps` x `--steps` steps back to back, then every rank drains ITS OWN stream
+and gathers and stops its clock (the closing barrier comes after and is not timed); `reps` is chosen so that the region
+lasts >= 50 ms (one 20-step block is 0.3 ms: shorter than a host synchronisation is exact).  value = envs x reps x steps
+/ MAX over ranks of the wall time; the device time of the same region (HIP events) is printed beside it.
 """
 import argparse
 import glob
@@ -31,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 65536
+MIN_REGION_MS = 50.0     # the timed region lasts at least this long (see run_rank: reps)
 # ALGORITHMIC bytes per env-step (DESIGN.md "Bytes"): SoA state in + out (7 f64 robot + min_dist f64 +
 # target_idx i32 + current_iter i32 + robot_collided u8 = 73 B each way) + action 2 x f32 + reward f64 + done u8.
 # The shared costmap / path are LDS- and cache-resident and contribute no compulsory HBM traffic.
@@ -42,9 +48,13 @@ METRIC = "env-steps/sec at N=65536 RandomMiniEnv, 1/2/4/8 MI355X; % HBM roofline
 
 
 # ------------------------------------------------------------------------------------------------ launcher (no GPU)
-def spawn_ranks(args):
-    """Start one fresh process per rank and relay rank 0's output.  Nothing here imports torch or touches the GPU."""
+def spawn_ranks(args, script=None, argv=None):
+    """Start one fresh process per rank and relay rank 0's output.  Nothing here imports torch or touches the GPU.
+    (`script` / `argv`: the rank program, bench.py with this command line by default; the CPU test of the launcher
+    runs its own rank program at world size 8.)"""
     n = args.gpus
+    script = os.path.abspath(script or __file__)
+    argv = sys.argv[1:] if argv is None else list(argv)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -53,7 +63,7 @@ def spawn_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, cwd=os.getcwd()))
     deadline = time.time() + float(os.environ.get("BCP_BENCH_TIMEOUT", "1500"))
     rc = 0
@@ -390,14 +400,15 @@ def run_rank(args):
     torch.cuda.set_device(device)
     n = args.envs_per_gpu
     env, g = make_env(n, device, env_id_base=rank * n, seed=2024)
-    backend = dist.get_backend() if world > 1 else None
+    sharded = dist.is_initialized()     # world > 1, or a forced group at world size 1 (BCP_DIST_FORCE=1)
+    backend = dist.get_backend() if sharded else None
     # Multi-GPU: the only cross-rank traffic is the done mask.  Every rank writes its mask of step k into row k % 8 of a
     # ring (the step kernel stores it there directly) and the ring is all-gathered every 8 steps, asynchronously
     # (the gather of one block of 8 steps overlaps the kernels of the next): 1/8 collective per step.
     gather_every = 8
-    ring = torch.zeros(gather_every, n, dtype=torch.uint8, device=torch.device("cuda", device)) if world > 1 else None
-    gather = bdist.DoneGather(gather_every * n, torch.device("cuda", device)) if world > 1 else None
-    if world > 1:
+    ring = torch.zeros(gather_every, n, dtype=torch.uint8, device=torch.device("cuda", device)) if sharded else None
+    gather = bdist.DoneGather(gather_every * n, torch.device("cuda", device)) if sharded else None
+    if sharded:
         # the first collectives run here, untimed (communicator set-up)
         gather.launch(ring.view(-1))
         gather.flush()
@@ -416,11 +427,24 @@ def run_rank(args):
         if k % gather_every == gather_every - 1:
             gather.launch(ring.view(-1))
 
-    def barrier():
-        if world > 1:
+    def drain():
+        """This rank's own work is finished: its gathers have landed and its stream is empty.  No collective in here."""
+        if gather is not None:
             gather.flush()
-            dist.barrier()
         torch.cuda.synchronize()
+
+    def barrier():
+        drain()
+        if sharded:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if not sharded:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=env.device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     # Pre-roll to the steady state of the rollout (untimed set-up): every env gets a random episode phase, then one
     # full timeout's worth of steps runs, so that at any timed step the batch holds envs at all stages of an
@@ -431,29 +455,51 @@ def run_rank(args):
             gather.launch(ring.view(-1))
     barrier()
 
-    for k in range(args.warmup):
-        one_step(k)
-    barrier()
     stream = torch.cuda.current_stream(env.device)  # the stream libbcplan launches on
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0 = 0
+    for k in range(args.warmup):
+        one_step(k0 + k)
+    k0 += args.warmup
+    # How long is one block of `steps` steps?  (an untimed probe, so that --warmup 0 works too.)  A block shorter
+    # than MIN_REGION_MS is no instrument -- at the driver's --steps 20 it lasts 0.3 ms and one host synchronisation is
+    # 9 % of it -- so the timed region repeats the block `reps` times back to back; `steps` stays what was asked for,
+    # ms_per_step and value are per step.  Every rank uses the same `reps` (MAX of the probes).
+    probe = max(1, min(args.steps, 32))
+    barrier()
+    ev0.record(stream)
+    for k in range(probe):
+        one_step(k0 + k)
+    ev1.record(stream)
+    k0 += probe
+    drain()
+    probe_ms = max_over_ranks(ev0.elapsed_time(ev1) / probe)
+    reps = args.reps if args.reps > 0 else int(min(8192, max(1, np.ceil(MIN_REGION_MS / max(probe_ms * args.steps, 1e-6)))))
+    k0 = (k0 + gather_every - 1) // gather_every * gather_every   # (the ring starts the region at row 0)
+    total = reps * args.steps
+
+    # ---- the timed region: barrier + synchronize | reps x steps steps | this rank's stream and gathers drained ----
+    # The clock of a rank stops when ITS work is done (drain: no collective); the closing barrier comes after it and
+    # is not part of what `value` is computed from; the job's time is the MAX over ranks.  Beside the wall clock the
+    # device time of the same region (HIP events on the launch stream, MAX over ranks).
+    barrier()
     t0 = time.perf_counter()
     ev0.record(stream)
-    for k in range(args.steps):
-        one_step(args.warmup + k)
+    for k in range(total):
+        one_step(k0 + k)
     ev1.record(stream)
+    drain()
+    elapsed_local = time.perf_counter() - t0
     barrier()
-    elapsed = time.perf_counter() - t0
-    stream_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=env.device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    stream_ms_local = ev0.elapsed_time(ev1)
+    elapsed = max_over_ranks(elapsed_local)
+    stream_ms = max_over_ranks(stream_ms_local)
     env.check_errors()
 
     # The step's launches run back to back on one stream; their combined average duration is measured live with HIP
     # events recorded on the launch stream around the timed region (at N=1 the region holds nothing but these
     # launches).  The per-kernel split of the same command is in profiles/ (rocprofv3 --kernel-trace --stats).
-    step_ms = stream_ms / args.steps if world == 1 else env.time_steps(pool[0], max(20, min(args.steps, 200)))
+    step_ms = stream_ms / total
     achieved = BYTES_PER_ENV_STEP * n / (step_ms * 1e-3) / 1e9
     traffic = traffic_src = None
     if n == ENVS_PER_GPU:   # PMC passes cannot run inside bench.py; the newest committed summary is quoted and named
@@ -466,12 +512,19 @@ def run_rank(args):
         kernels = env.step_kernels()
         out = {
             "metric": METRIC,
-            "value": total_envs * args.steps / elapsed,
+            "value": total_envs * total / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / total * 1e3,
+            "reps": reps,
+            "timed_region": {"steps_timed": total, "wall_ms": elapsed * 1e3, "device_ms": stream_ms,
+                             "device_ms_per_step": stream_ms / total,
+                             "what": "reps x steps steps back to back between barrier + synchronize and the drain of "
+                                     "every rank's own stream and gathers; wall = MAX over ranks of the host clock, "
+                                     "device = MAX over ranks of HIP events on the launch stream; the closing barrier "
+                                     "is outside both"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -483,7 +536,7 @@ def run_rank(args):
                        "sharding": ("env blocks per rank, done masks ring-buffered on the device and all-gathered (%s) every "
                                     "8 steps, overlapped with the next steps"
                                     % ("RCCL" if backend == "nccl" else "gloo through the host: REHEARSAL transport, not a scaling number"))
-                       if world > 1 else "single GPU"},
+                       if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernels, "kernel_ms": step_ms,
@@ -506,7 +559,7 @@ def run_rank(args):
                 out["aux"] = {"error": repr(exc)}
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -517,6 +570,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--reps", type=int, default=0, help="repeat the block of --steps steps this many times inside the "
+                    "timed region (default: as many as make the region last %.0f ms)" % MIN_REGION_MS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the informational legs (observation, pools, C2 / C4)")
     args = ap.parse_args()

@@ -58,3 +58,41 @@ def test_done_gather_world2(tmp_path):
     mp.spawn(_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
     blocks = [np.load(os.path.join(str(tmp_path), "ok_%d.npy" % r)) for r in range(world)]
     assert blocks[0][0] == 0 and blocks[0][0] + blocks[0][1] == blocks[1][0] and blocks[1][0] + blocks[1][1] == n_total
+
+
+def test_bench_launcher_world8_ring(capfd):
+    """bench.py's own launcher (spawn_ranks: fresh rank processes, free port, exit-code relay) at the world size the
+    driver's scaling run uses, with the rendezvous and the done-mask ring of bench.py over gloo on the CPU: 8 ranks,
+    64 steps, every rank checks every mask it gathered (tests/ranks/ring_rank.py)."""
+    import argparse
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    env_before = dict(os.environ)
+    os.environ["BCP_DIST_BACKEND"] = "gloo"
+    os.environ["BCP_BENCH_TIMEOUT"] = "240"
+    try:
+        rc = bench.spawn_ranks(argparse.Namespace(gpus=8), script=os.path.join(ROOT, "tests", "ranks", "ring_rank.py"),
+                               argv=["512", "64"])
+    finally:
+        os.environ.clear()
+        os.environ.update(env_before)
+    assert rc == 0
+    line = [x for x in capfd.readouterr().out.splitlines() if x.startswith("{")][-1]
+    got = json.loads(line)
+    assert got == {"world": 8, "backend": "gloo", "masks_checked": 8 * 8 * 64}
+
+
+def test_bench_launcher_relays_a_failing_rank(tmp_path):
+    """A rank that dies stops the job: the launcher returns its exit code instead of waiting for the others."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    code = "import os, sys, time\nif os.environ['RANK'] == '2':\n    sys.exit(7)\ntime.sleep(60)\n"
+    path = str(tmp_path / "failing_rank.py")
+    with open(path, "w") as f:
+        f.write(code)
+    import time
+    t0 = time.time()
+    rc = bench.spawn_ranks(argparse.Namespace(gpus=4), script=path, argv=[])
+    assert rc == 7 and time.time() - t0 < 30

@@ -146,3 +146,77 @@ def test_rccl_refuses_more_ranks_than_gpus(launcher):
                      env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1",
                           "MASTER_PORT": str(_free_port()), "BCP_DIST_BACKEND": ""}, timeout=120)
     assert r["rc"] != 0 and "BCP_DIST_BACKEND=gloo" in r["err"]
+
+
+def _single_process_masks(torch, n, steps):
+    from sharded_rank import global_actions, make_shard
+    env = make_shard(n, 0, 0)
+    acts = global_actions(n, steps)
+    expect = []
+    for k in range(steps):
+        env.step(torch.from_numpy(acts[k]).cuda())
+        expect.append(env.done.cpu().numpy().copy())
+    return np.stack(expect), env.state.robot.cpu().numpy()
+
+
+def test_rccl_branch_at_world_size_one(torch_cuda, launcher, tmp_path):
+    """The RCCL path for real, on the one GPU of this box: BCP_DIST_FORCE=1 makes init_from_env build a `nccl` process
+    group at world size 1 (device_id path, communicator set-up) and DoneGather take its collective branch --
+    all_gather_into_tensor per step, and the pipelined form bench.py uses (staging copy on the step's stream,
+    asynchronous work handles, wait two launches later) -- while the rank steps a real shard with done_out = ring row.
+    What it gathered must be the single-process masks."""
+    torch = torch_cuda
+    n, steps = 8192, 48
+    out = str(tmp_path / "rank0.npz")
+    script = os.path.join(ROOT, "tests", "ranks", "sharded_rank.py")
+    r = launcher.run([sys.executable, script, out, str(n), str(steps)],
+                     env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "LOCAL_WORLD_SIZE": "1",
+                          "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "BCP_DIST_BACKEND": "nccl",
+                          "BCP_DIST_FORCE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=420, cwd=ROOT)
+    assert r["rc"] == 0, r["err"][-3000:]
+    got = np.load(out)
+    assert str(got["backend"]) == "nccl"
+    expect, robot = _single_process_masks(torch, n, steps)
+    assert expect.sum() > n // 2
+    np.testing.assert_array_equal(got["done_per_step"], expect)
+    np.testing.assert_array_equal(got["done_ring"], expect)
+    np.testing.assert_array_equal(got["robot"], robot)
+
+
+def _bench_line(result):
+    assert result["rc"] == 0, result["err"][-3000:]
+    lines = [x for x in result["out"].splitlines() if x.startswith("{")]
+    assert len(lines) == 1, result["out"][-2000:]
+    import json
+    return json.loads(lines[0])
+
+
+def test_bench_rccl_at_world_size_one(launcher):
+    """bench.py itself through the RCCL ring (forced group at N = 1): the line says so, and the timed region obeys its
+    rules -- reps x steps steps, wall time within a few percent of the HIP-event time of the same region."""
+    r = launcher.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                      "--envs-per-gpu", "16384", "--no-aux", "--no-cpu-baseline"],
+                     env={"BCP_DIST_FORCE": "1", "BCP_DIST_BACKEND": "nccl", "MASTER_ADDR": "127.0.0.1",
+                          "MASTER_PORT": str(_free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=600, cwd=ROOT)
+    line = _bench_line(r)
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and "RCCL" in line["config"]["sharding"]
+    tr = line["timed_region"]
+    assert line["reps"] >= 1 and tr["steps_timed"] == line["reps"] * 20 and tr["wall_ms"] >= 45.0
+    assert abs(line["ms_per_step"] - tr["wall_ms"] / tr["steps_timed"]) < 1e-9
+    assert line["value"] == pytest.approx(16384 * tr["steps_timed"] / (tr["wall_ms"] * 1e-3), rel=1e-9)
+    assert tr["device_ms"] <= tr["wall_ms"] * 1.001
+
+
+def test_bench_four_rank_rehearsal_on_one_gpu(launcher):
+    """`BCP_DIST_BACKEND=gloo python bench.py --gpus 4 --envs-per-gpu 8192` on this box's one GPU: bench.py's own
+    launcher, the rendezvous, four rank processes stepping real shards, the ring and the MAX-over-ranks timing, end to
+    end.  (Four, not eight: a GPU box of this pool admits at most 6 processes on its card and this session is one of
+    them; the launcher and the ring at world size 8 run on the CPU in tests/test_distributed_gloo.py.)"""
+    r = launcher.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "20", "--warmup", "5",
+                      "--envs-per-gpu", "8192", "--no-aux", "--no-cpu-baseline", "--reps", "4"],
+                     env={"BCP_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "BCP_BENCH_TIMEOUT": "500"},
+                     timeout=600, cwd=ROOT)
+    line = _bench_line(r)
+    assert line["n_gpus"] == 4 and line["config"]["envs_total"] == 4 * 8192 and line["scaling"] == "weak"
+    assert "REHEARSAL" in line["config"]["sharding"] and line["reps"] == 4
+    assert line["timed_region"]["steps_timed"] == 80 and line["value"] > 0
