@@ -185,15 +185,49 @@ struct Robot {
 };
 
 // TricycleRobot.step (robot_models/tricycle_model.py:478-538, with :71-188) and
-// DiffDriveRobot.step (robot_models/differential_drive.py:236-265)
-// (old_heading: step_local_kernel has an idle wave compute cos / sin of the old heading while the state loads are in flight)
-__device__ __forceinline__ int robot_step(const DevParams& P, Robot& r, double cmd0, double cmd1, const double z[3],
-                                          int& drawn, KnownHeading old_heading = no_known_heading())
+// DiffDriveRobot.step (robot_models/differential_drive.py:236-265), in two halves:
+//   robot_step_begin: everything that needs neither the odometry noise nor the old heading's cos / sin -- the tricycle's
+//                     front-wheel column, cos / sin of the new wheel angle and the velocity model (tricycle_model.py:127-188);
+//   robot_step_end:   the (noisy) kinematic step and the measured velocities (differential_drive.py:21-74,
+//                     path_tools.py:298-323).
+// step_local_kernel runs the first half while the noise and the old heading are still being computed by other waves.
+// the robot constants of DevParams by value: a kernel fetches them once, ahead of time (step_local_kernel)
+struct RobotConsts {
+    int32_t model, dynamic_model, model_front_column_pid, noise_on;
+    double dt, L, max_wheel_angle, max_wheel_speed, max_lin_acc, max_ang_acc, p_gain;
+    double alpha[6];
+};
+
+__device__ __forceinline__ RobotConsts robot_consts(const DevParams& P)
 {
-    Pose last = r.p, np_;
-    double mv, mw;
+    RobotConsts c;
+    c.model = P.model;
+    c.dynamic_model = P.dynamic_model;
+    c.model_front_column_pid = P.model_front_column_pid;
+    c.noise_on = P.noise_on;
+    c.dt = P.dt;
+    c.L = P.L;
+    c.max_wheel_angle = P.max_wheel_angle;
+    c.max_wheel_speed = P.max_wheel_speed;
+    c.max_lin_acc = P.max_lin_acc;
+    c.max_ang_acc = P.max_ang_acc;
+    c.p_gain = P.p_gain;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c.alpha[k] = P.alpha[k];
+    return c;
+}
+
+struct RobotDrive {
+    double v, w;          // what goes into the kinematic step
+    bool noisy;           // ... through kinematic_step_noise (tricycle: only the dynamic model is noisy, tricycle_model.py:489-519)
+};
+
+template <typename Params>   // DevParams or RobotConsts
+__device__ __forceinline__ RobotDrive robot_step_begin(const Params& P, Robot& r, double cmd0, double cmd1)
+{
+    RobotDrive d;
     if (P.model == BCP_MODEL_TRICYCLE) {
-        double wa = r.wheel, new_wa, nv, nw;
+        double wa = r.wheel, new_wa;
         if (P.model_front_column_pid) {   // tricycle_model.py:127-154
             double max_delta = P.max_wheel_speed * P.dt;
             double delta = clipd(P.p_gain * (cmd1 - wa), -max_delta, max_delta);
@@ -210,25 +244,47 @@ __device__ __forceinline__ int robot_step(const DevParams& P, Robot& r, double c
             double acc_w = (des_w - r.w) / P.dt;
             double lin = clipd(acc_v, -2 * P.max_lin_acc, P.max_lin_acc);
             double ang = clipd(acc_w, -P.max_ang_acc, P.max_ang_acc);
-            nv = r.v + lin * P.dt;
-            nw = r.w + ang * P.dt;
+            double nv = r.v + lin * P.dt;
+            double nw = r.w + ang * P.dt;
             if (0.0 > nv) nv = 0.0;
-            np_ = P.noise_on ? kinematic_step_noise(last, nv, nw, P.dt, P.alpha, z, drawn)
-                             : kinematic_step(last, nv, nw, P.dt);
+            d.v = nv;
+            d.w = nw;
+            d.noisy = P.noise_on != 0;
         } else {                          // tricycle_kinematic_step :38-68
-            np_ = kinematic_step(last, des_v, des_w, P.dt);
+            d.v = des_v;
+            d.w = des_w;
+            d.noisy = false;
         }
         r.steer = wa - cmd1;              // :532
         r.wheel = new_wa;
     } else {
-        np_ = P.noise_on ? kinematic_step_noise(last, cmd0, cmd1, P.dt, P.alpha, z, drawn)
-                         : kinematic_step(last, cmd0, cmd1, P.dt);
+        d.v = cmd0;
+        d.w = cmd1;
+        d.noisy = P.noise_on != 0;
     }
-    int err = path_velocity(last, np_, P.dt, mv, mw, old_heading);
+    return d;
+}
+
+// (old_heading: step_local_kernel has an idle wave compute cos / sin of the old heading while the state loads are in flight)
+template <typename Params>   // DevParams or RobotConsts
+__device__ __forceinline__ int robot_step_end(const Params& P, Robot& r, RobotDrive d, const double z[3], int& drawn,
+                                              KnownHeading old_heading = no_known_heading())
+{
+    const Pose last = r.p;
+    const Pose np_ = d.noisy ? kinematic_step_noise(last, d.v, d.w, P.dt, P.alpha, z, drawn) : kinematic_step(last, d.v, d.w, P.dt);
+    double mv, mw;
+    const int err = path_velocity(last, np_, P.dt, mv, mw, old_heading);
     r.p = np_;
     r.v = mv;
     r.w = mw;
     return err;
+}
+
+__device__ __forceinline__ int robot_step(const DevParams& P, Robot& r, double cmd0, double cmd1, const double z[3],
+                                          int& drawn, KnownHeading old_heading = no_known_heading())
+{
+    const RobotDrive d = robot_step_begin(P, r, cmd0, cmd1);
+    return robot_step_end(P, r, d, z, drawn, old_heading);
 }
 
 // Philox4x32-10 (Salmon et al., SC'11), counter = (env_lo, env_hi, step_lo, step_hi), key = seed.
@@ -252,21 +308,50 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 // np.random.normal draws of robot_models/differential_drive.py:43-52 (parity runs replay exact values through noise_z).
 // u = (k + 1/2) 2^-32 lies in (0, 1); r = sqrt(-2 ln u) <= 6.66; the angle 2 pi k 2^-32 goes through sincospi (exact
 // argument reduction).  The only departure from N(0, 1) is the 2^-32 lattice of the uniforms: |z| <= 6.66, mass beyond
-// that 2.7e-11 (numpy's 53-bit uniforms reach 8.6 sigma).  Measured cost against the earlier float32 fast-math version:
-// +2 % of the step; tests/test_gpu_noise.py checks the distribution.
+// that 2.7e-11 (numpy's 53-bit uniforms reach 8.6 sigma).  tests/test_gpu_noise.py checks the distribution.
+//
+// The stream (round 3): Philox words (c0, c1) make Box-Muller pair A, (c2, c3) pair B, and
+//     z[1] = A.cos,  z[2] = A.sin,  z[0] = B.cos
+// -- the two slots PlanEnv's noise model draws (alpha1 = alpha2 = 0: slot 0 is never consumed, envs/base/env.py:228-231) are
+// the two halves of ONE pair, so a step that cannot draw slot 0 computes one logarithm, one square root and one sincospi
+// per env instead of two each.  (Rounds 1-2: z[0], z[1] = pair A, z[2] = B.sin.)
+template <int PAIR>   // 0 = A, 1 = B
+__device__ __forceinline__ void box_muller_pair(const uint32_t c[4], double& cos_part, double& sin_part)
+{
+    const double k = 2.3283064365386963e-10;  // 2^-32
+    const double u = ((double)c[2 * PAIR] + 0.5) * k;
+    const double r = sqrt(-2.0 * log(u));
+    double sn, cs;
+    sincospi(2.0 * ((double)c[2 * PAIR + 1] * k), &sn, &cs);
+    cos_part = r * cs;
+    sin_part = r * sn;
+}
+
+// slots 1 and 2 (pair A)
+__device__ __forceinline__ void device_normals_12(uint64_t seed, uint64_t env, uint64_t step, double& z1, double& z2)
+{
+    uint32_t c[4] = {(uint32_t)env, (uint32_t)(env >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    box_muller_pair<0>(c, z1, z2);
+}
+
+// slot 0 (pair B)
+__device__ __forceinline__ double device_normal_0(uint64_t seed, uint64_t env, uint64_t step)
+{
+    uint32_t c[4] = {(uint32_t)env, (uint32_t)(env >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    double z0, twin;
+    box_muller_pair<1>(c, z0, twin);
+    return z0;
+}
+
 __device__ __forceinline__ void device_normals(uint64_t seed, uint64_t env, uint64_t step, double z[3])
 {
     uint32_t c[4] = {(uint32_t)env, (uint32_t)(env >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const double k = 2.3283064365386963e-10;  // 2^-32
-    const double u0 = ((double)c[0] + 0.5) * k, u2 = ((double)c[2] + 0.5) * k;
-    const double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
-    double s0, c0, s1, c1;
-    sincospi(2.0 * ((double)c[1] * k), &s0, &c0);
-    sincospi(2.0 * ((double)c[3] * k), &s1, &c1);
-    z[0] = r0 * c0;
-    z[1] = r0 * s0;
-    z[2] = r1 * s1;
+    double twin;
+    box_muller_pair<0>(c, z[1], z[2]);
+    box_muller_pair<1>(c, z[0], twin);
 }
 
 }  // namespace bcp

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 
 #include "bcp_device.h"
@@ -67,20 +68,32 @@ struct StepStatic {
 // with the kernel arguments: the first vector loads then depend on the argument fetch alone and overlap the (cold, the
 // kernel boundary emptied the L2) scalar fetch of *S instead of queueing behind it.  A copy of the corresponding *S fields.
 struct StepHot {
-    DevState st;
+    DevState st;               // (x .. collided first: what every configuration loads; the five delay-queue arrays last)
+    // ---- the rest of what step_local_kernel's prologue uses, contiguous (fetched in one go: fetch / pin_words)
     int64_t n;
+    int64_t env_id_base;
     int32_t* geom_of_env;
     const double* path_pts;
     const double* path_bbox;
     const int16_t* path_index;
-    struct Pending* pending;
     const uint32_t* map_bits;
+    const double* qverts;      // = &S->P.qverts[0][0]
+    const double* map_origins; // per-entry map origins [.,2] or nullptr
+    int32_t model, lds_path_doubles, path_shared, path_max_len;
+    int32_t map_rows, map_cols, map_wpr, map_shared;
+    int32_t noise_on, n_verts, control_delay, pose_delay, state_delay;
+    int32_t dynamic_model, model_front_column_pid;
+    int32_t noise_slot0;       // alpha1 > 0 or alpha2 > 0: the noise model can consume slot 0 (differential_drive.py:62)
+    int32_t pending_cap;
+    // ---- used later in a step
     const uint32_t* near;
     int64_t map_env_stride;
-    int32_t model, lds_path_doubles, path_shared, pending_cap;
-    int32_t map_rows, map_cols, map_wpr, map_shared;
-    int32_t path_max_len;
+    struct Pending* pending;
 };
+constexpr int kHotStateWords = 11 * 2;                                   // x .. collided
+constexpr int kHotPrologueWords = (9 * 8 + 17 * 4) / 4;                 // n .. pending_cap
+static_assert(offsetof(DevState, collided) == 10 * 8 && offsetof(StepHot, st) == 0, "x .. collided lead DevState");
+static_assert(offsetof(StepHot, pending_cap) + 4 - offsetof(StepHot, n) == kHotPrologueWords * 4, "the prologue block of StepHot");
 
 constexpr int kShards = 64;  // a wave parks into shard (block index % kShards)
 
@@ -386,6 +399,27 @@ __device__ __forceinline__ int last_reached_from(const DevParams& P, const doubl
     return -1;
 }
 
+// find_last_reached for ONE pose by all 64 lanes of a wave (way points in LDS): lane l takes candidate hi - l, the first
+// lane that reports "reached" holds the last reached index.  Wave-uniform arguments and result.
+__device__ __forceinline__ int coop_last_reached(const DevParams& P, LdsF64 path, PathWindow w, int m, int target, double x,
+                                                 double y, double th)
+{
+    if (target > m - 1) return -1;
+    const int lo = max(w.lo, target), hi = min(w.hi, m - 1);
+    const int ln = (int)__lane_id();
+    for (int top = hi; top >= lo; top -= 64) {
+        const int j = top - ln;
+        bool ok = false;
+        if (j >= lo) {
+            const LdsF64 s = path + 5 * j;
+            ok = way_point_reached(P, s[0], s[1], s[2], s[3], s[4], x, y, th);
+        }
+        const uint64_t mask = __ballot(ok);
+        if (mask) return top - ((int)__ffsll((unsigned long long)mask) - 1);
+    }
+    return -1;
+}
+
 template <typename PathPtr>
 __device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path, PathWindow w, int m, double x, double y,
                                               double th, double& min_dist, int& target)
@@ -526,6 +560,13 @@ __device__ unsigned long long g_diag[kDiagBlocks * 16];
 // maxima over the waves of a workgroup live in the upper half of the array (slot k of workgroup b: (2048 + b) * 16 + k)
 #define DIAG_MAX(k, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) atomicMax(&g_diag[(2048 + blockIdx.x) * 16 + (k)], (unsigned long long)(v)); } while (0)
 #define DIAG_NOW() __builtin_amdgcn_s_memtime()
+// further stamps of lane 0 of wave `w`, in the upper half next to the maxima: slot k = 1 .. 15 of workgroup b at (2048 + b) * 16 + k
+#define DIAG_STAMP_U(w, k) do { if (threadIdx.x == (w) * 64 && blockIdx.x < 2048) g_diag[(2048 + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DIAG_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// lane 0 of EVERY wave: row (base + workgroup), slot = wave number (base = 1024, 1536: arrival at barrier 0 / 1)
+#define DIAG_STAMP_WAVES(base) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) g_diag[((base) + blockIdx.x) * 16 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); } while (0)
+// maximum over ALL lanes of the workgroup (not only lane 0 of each wave)
+#define DIAG_MAX_ALL(k, v) do { if (blockIdx.x < 2048) atomicMax(&g_diag[(2048 + blockIdx.x) * 16 + (k)], (unsigned long long)(v)); } while (0)
 extern "C" int bcp_diag_read(unsigned long long* out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(g_diag));
@@ -542,6 +583,10 @@ extern "C" int bcp_diag_clear()
 #define DIAG_STAMP_W(w, k) do { } while (0)
 #define DIAG_MAX(k, v) do { } while (0)
 #define DIAG_NOW() 0ull
+#define DIAG_STAMP_U(w, k) do { } while (0)
+#define DIAG_WAIT_VMEM() do { } while (0)
+#define DIAG_STAMP_WAVES(base) do { } while (0)
+#define DIAG_MAX_ALL(k, v) do { } while (0)
 #endif
 
 
@@ -670,6 +715,43 @@ struct Pending {
     double popped_pose[3], popped_state[7];
 };
 
+// An env's initial state, fetched ahead of time for a lane that may well end its episode this step (time-out reached,
+// pose not yet cleared of a collision): the in-kernel reset then finds it in registers instead of paying a memory round
+// trip at the very end of the step.
+struct InitAhead {
+    double x, y, th, v, w, steer, wheel, min_dist;
+    int32_t target, iter, collided;
+    bool have;
+};
+
+__device__ __forceinline__ InitAhead no_init_ahead()
+{
+    InitAhead p;
+    p.x = p.y = p.th = p.v = p.w = p.steer = p.wheel = p.min_dist = 0.0;
+    p.target = p.iter = p.collided = 0;
+    p.have = false;
+    return p;
+}
+
+template <typename SP>
+__device__ __forceinline__ InitAhead fetch_init_ahead(SP S, int64_t k, bool tri)
+{
+    InitAhead p;
+    p.x = as_global(S->init.x)[k];
+    p.y = as_global(S->init.y)[k];
+    p.th = as_global(S->init.angle)[k];
+    p.v = as_global(S->init.v)[k];
+    p.w = as_global(S->init.w)[k];
+    p.steer = tri ? as_global(S->init.steer)[k] : 0.0;
+    p.wheel = tri ? as_global(S->init.wheel)[k] : 0.0;
+    p.min_dist = as_global(S->init.min_dist)[k];
+    p.target = as_global(S->init.target_idx)[k];
+    p.iter = as_global(S->init.cur_iter)[k];
+    p.collided = (int32_t)as_global(S->init.collided)[k];
+    p.have = true;
+    return p;
+}
+
 // reward-provider outcome for the pose as it is when nothing collides, computed ahead of the collision verdict
 struct ScoredFree {
     double rew, min_dist;
@@ -687,7 +769,8 @@ struct ParkedPose {
 };
 
 // entry of the non-shared map / path arrays that env i uses
-__device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const Pending& q)
+template <typename SP>   // const StepStatic* in global memory, or step_local_kernel's copy of the block in LDS
+__device__ __forceinline__ int64_t slot_of(SP S, int64_t i, const Pending& q)
 {
     return S->geom_of_env ? (int64_t)q.geom : i;
 }
@@ -697,18 +780,19 @@ __device__ __forceinline__ int64_t slot_of(const StepStatic* S, int64_t i, const
 // PLAIN = true (no delays, continuous reward provider -- see step_is_plain) compiles the delay queues and the
 // pure-pursuit branch out.
 // (A: StepArgs by value, or by reference into the kernel-argument segment -- only a.S, the output pointers and a.flags are used)
-template <bool PLAIN, typename A>
-__device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
+template <bool PLAIN, typename A, typename SP>
+__device__ __forceinline__ void finalize_env_from(const A& a, SP S, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
                                              const PathWindow* free_window = nullptr, bool have_score = false,
-                                             ScoredFree score = ScoredFree(), int known_len = -1, bool score_fits_hit = false)
+                                             ScoredFree score = ScoredFree(), int known_len = -1, bool score_fits_hit = false,
+                                             InitAhead ahead = no_init_ahead())
 {   // (the score travels by value: a pointer to a local made the compiler keep it in scratch memory;
     //  known_len >= 0: the caller already holds the length of this env's path;
     //  score_fits_hit: `score` was computed for the rolled-back pose of a colliding env -- continuous provider only)
-    const DevParams& P = a.S->P;
+    const DevParams& P = *(const DevParams*)&S->P;   // (S may point into LDS: step_local_kernel)
     const int pose_delay = PLAIN ? 0 : P.pose_delay, state_delay = PLAIN ? 0 : P.state_delay;
     const bool pure_pursuit = !PLAIN && P.reward_provider == BCP_REWARD_PURE_PURSUIT;
     const bool tri = P.model == BCP_MODEL_TRICYCLE;
-    const int64_t n = a.S->n;
+    const int64_t n = S->n;
     Robot& r = q.r;
     if (hit) {  // robot.set_pose(*old_position): pose restored, v = w = 0 (tricycle_model.py:471-476)
         r.p = q.old;
@@ -722,16 +806,16 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
     // State.pose / State.robot_state: what the reward provider and the observation see (env.py:377-394)
     double seen[3] = {r.p.x, r.p.y, r.p.th};
     double seen_rs[7] = {r.p.x, r.p.y, r.p.th, r.v, r.w, r.steer, r.wheel};
-    if (pose_delay) fifo_push<3>(a.S->st.pose_q, pose_delay, n, i, iter, seen, q.popped_pose);
-    if (state_delay) fifo_push<7>(a.S->st.state_q, state_delay, n, i, iter, seen_rs, q.popped_state);
+    if (pose_delay) fifo_push<3>(S->st.pose_q, pose_delay, n, i, iter, seen, q.popped_pose);
+    if (state_delay) fifo_push<7>(S->st.state_q, state_delay, n, i, iter, seen_rs, q.popped_state);
 
     // shared path: uniform pointers (scalar cache); private paths: per-lane pointers
     double rew = 0.0;
     int m;
     bool goal;
-    const int64_t g = slot_of(a.S, i, q);
-    const double* pts = a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5);
-    m = known_len >= 0 ? known_len : (a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g]);
+    const int64_t g = slot_of(S, i, q);
+    const double* pts = S->path.pts + (S->path.shared ? 0 : g * (int64_t)S->path.max_len * 5);
+    m = known_len >= 0 ? known_len : (S->path.shared ? S->path.max_len : S->path.lens[g]);
     if (pure_pursuit) {
         if (have_score && !hit) {   // the scorer wave has already done it (no collision: the flag it assumed stands)
             rew = score.rew;
@@ -750,11 +834,11 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
             target = score.target;
         } else if (!(a.flags & kAblateNoReward)) {
             // way-point window of the pose: the caller may have looked it up already for the un-rolled-back pose
-            const double* bbox = a.S->path.bbox + (a.S->path.shared ? 0 : g * kBoxDoubles);
-            const int16_t* index = a.S->path.index + (a.S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
+            const double* bbox = S->path.bbox + (S->path.shared ? 0 : g * kBoxDoubles);
+            const int16_t* index = S->path.index + (S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
             const PathWindow w =
                 (free_window && !hit && !pose_delay) ? *free_window : path_window(P, bbox, index, seen[0], seen[1]);
-            if (lds_path && a.S->path.shared)  // way points staged in LDS by the step kernel
+            if (lds_path && S->path.shared)  // way points staged in LDS by the step kernel
                 rew = reward_step(P, lds_path, w, m, seen[0], seen[1], seen[2], min_dist, target);
             else
                 rew = reward_step(P, pts, w, m, seen[0], seen[1], seen[2], min_dist, target);
@@ -776,25 +860,26 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
 
     if (done && (a.flags & BCP_STEP_AUTO_RESET)) {  // PlanEnv.reset(): set_state(initial_state) (env.py:293-303)
         int64_t k = i;
-        if (a.S->geom_of_env) {  // RandomMiniEnv.reset(): the env moves on to its next geometry (mini_env.py:469-481).
+        if (S->geom_of_env) {  // RandomMiniEnv.reset(): the env moves on to its next geometry (mini_env.py:469-481).
             // Computed from the entry the step started with, so kernel 2 redoing an env that kernel 1 already reset
             // lands on the same geometry (a hit always ends the episode, so both reset or neither does).
-            k = a.S->next_geom ? as_global(a.S->next_geom)[g] : g;
-            as_global(a.S->geom_of_env)[i] = (int32_t)k;
+            k = S->next_geom ? as_global(S->next_geom)[g] : g;
+            as_global(S->geom_of_env)[i] = (int32_t)k;
         }
-        r.p.x = as_global(a.S->init.x)[k];
-        r.p.y = as_global(a.S->init.y)[k];
-        r.p.th = as_global(a.S->init.angle)[k];
-        r.v = as_global(a.S->init.v)[k];
-        r.w = as_global(a.S->init.w)[k];
+        if (!ahead.have) ahead = fetch_init_ahead(S, k, tri);   // (fetched ahead only without a geometry pool: entry = env)
+        r.p.x = ahead.x;
+        r.p.y = ahead.y;
+        r.p.th = ahead.th;
+        r.v = ahead.v;
+        r.w = ahead.w;
         if (tri) {
-            r.steer = as_global(a.S->init.steer)[k];
-            r.wheel = as_global(a.S->init.wheel)[k];
+            r.steer = ahead.steer;
+            r.wheel = ahead.wheel;
         }
-        min_dist = as_global(a.S->init.min_dist)[k];
-        target = as_global(a.S->init.target_idx)[k];
-        iter = as_global(a.S->init.cur_iter)[k];
-        collided = as_global(a.S->init.collided)[k] != 0;
+        min_dist = ahead.min_dist;
+        target = ahead.target;
+        iter = ahead.iter;
+        collided = ahead.collided != 0;
         // the restored State exposes the initial pose / robot state; its queues are empty (pushes restart at k = 1)
         seen[0] = r.p.x;
         seen[1] = r.p.y;
@@ -823,12 +908,21 @@ __device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, 
     as_global(a.hot.st.collided)[i] = (uint8_t)collided;
     if (pose_delay) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a.S->st.pose_seen[c * n + i] = seen[c];
+        for (int c = 0; c < 3; ++c) S->st.pose_seen[c * n + i] = seen[c];
     }
     if (state_delay) {
 #pragma unroll
-        for (int c = 0; c < 7; ++c) a.S->st.state_seen[c * n + i] = seen_rs[c];
+        for (int c = 0; c < 7; ++c) S->st.state_seen[c * n + i] = seen_rs[c];
     }
+}
+
+// (the parameter block where the launch arguments point to: the two-launch and the general step kernels)
+template <bool PLAIN, typename A>
+__device__ __forceinline__ void finalize_env(const A& a, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
+                                             const PathWindow* free_window = nullptr, bool have_score = false,
+                                             ScoredFree score = ScoredFree(), int known_len = -1, bool score_fits_hit = false)
+{
+    finalize_env_from<PLAIN>(a, a.S, i, q, hit, lds_path, free_window, have_score, score, known_len, score_fits_hit);
 }
 
 // ---- loads shared by the step kernels ------------------------------------------------------------------------
@@ -836,48 +930,52 @@ template <bool PLAIN, typename A>
 __device__ __forceinline__ void load_env(const A& a, uint64_t seed, uint64_t step_counter, int64_t i, bool active,
                                          Pending& q, double& cmd0, double& cmd1, bool draw_noise = true)
 {
-    const DevParams& P = a.S->P;
+    // (no branch in here: the pointers are adjacent launch arguments, fetched by a few wide scalar loads in one go; an
+    //  array a configuration does not have -- the tricycle's two values, the pool entry -- is read from a stand-in)
     Robot& r = q.r;
+    const bool tri = a.hot.model == BCP_MODEL_TRICYCLE;
+    const double* const p_steer = tri ? a.hot.st.steer : a.hot.st.x;
+    const double* const p_wheel = tri ? a.hot.st.wheel : a.hot.st.x;
+    const int32_t* const p_geom = a.hot.geom_of_env ? a.hot.geom_of_env : a.hot.st.target_idx;
     r.p.x = as_global(a.hot.st.x)[i];
     r.p.y = as_global(a.hot.st.y)[i];
     r.p.th = as_global(a.hot.st.angle)[i];
     r.v = as_global(a.hot.st.v)[i];
     r.w = as_global(a.hot.st.w)[i];
-    const bool tri = a.hot.model == BCP_MODEL_TRICYCLE;
-    r.steer = tri ? as_global(a.hot.st.steer)[i] : 0.0;
-    r.wheel = tri ? as_global(a.hot.st.wheel)[i] : 0.0;
+    const double v_steer = as_global(p_steer)[i], v_wheel = as_global(p_wheel)[i];
     q.min_dist = as_global(a.hot.st.min_dist)[i];
     q.target = as_global(a.hot.st.target_idx)[i];
     q.iter = as_global(a.hot.st.cur_iter)[i];
     q.collided = as_global(a.hot.st.collided)[i] != 0;
-    q.geom = a.hot.geom_of_env ? as_global(a.hot.geom_of_env)[i] : 0;
-    if (a.flags & BCP_STEP_ACTIONS_F32) {
-        const GlobalPtr<const float> c = as_global(reinterpret_cast<const float*>(a.actions)) + 2 * i;   // (one 8-byte load)
-        cmd0 = (double)c[0];
-        cmd1 = (double)c[1];
-    } else {
-        const GlobalPtr<const double> c = as_global(reinterpret_cast<const double*>(a.actions)) + 2 * i;   // (one 16-byte load)
-        cmd0 = c[0];
-        cmd1 = c[1];
-    }
-    if (!PLAIN && P.control_delay && active) {   // the robot executes the command given control_delay steps ago (env.py:371-373)
+    const int32_t v_geom = as_global(p_geom)[i];
+    r.steer = tri ? v_steer : 0.0;
+    r.wheel = tri ? v_wheel : 0.0;
+    q.geom = a.hot.geom_of_env ? v_geom : 0;
+    // the action, float32 [N,2] or float64 [N,2], as two 8-byte words read without a branch (float32: the same word twice);
+    // they are only looked at below, so the loads above and the caller's next ones are all in flight together
+    const bool f32 = (a.flags & BCP_STEP_ACTIONS_F32) != 0;
+    const GlobalPtr<const uint64_t> aw = as_global(reinterpret_cast<const uint64_t*>(a.actions)) + (f32 ? i : 2 * i);
+    const uint64_t a_lo = aw[0], a_hi = aw[f32 ? 0 : 1];
+    cmd0 = f32 ? (double)__uint_as_float((uint32_t)a_lo) : __longlong_as_double((long long)a_lo);
+    cmd1 = f32 ? (double)__uint_as_float((uint32_t)(a_lo >> 32)) : __longlong_as_double((long long)a_hi);
+    if (!PLAIN && a.hot.control_delay && active) {   // the robot executes the command given control_delay steps ago (env.py:371-373)
         double cmd[2] = {cmd0, cmd1};
-        fifo_delay<2>(a.hot.st.control_q, P.control_delay, a.hot.n, i, q.iter + 1, cmd);
+        fifo_delay<2>(a.hot.st.control_q, a.hot.control_delay, a.hot.n, i, q.iter + 1, cmd);
         cmd0 = cmd[0];
         cmd1 = cmd[1];
     }
     if (!PLAIN) {   // what this step's pushes will displace (k = iter + 1)
-        fifo_peek<3>(a.hot.st.pose_q, P.pose_delay, a.hot.n, i, q.iter + 1, q.popped_pose);
-        fifo_peek<7>(a.hot.st.state_q, P.state_delay, a.hot.n, i, q.iter + 1, q.popped_state);
+        fifo_peek<3>(a.hot.st.pose_q, a.hot.pose_delay, a.hot.n, i, q.iter + 1, q.popped_pose);
+        fifo_peek<7>(a.hot.st.state_q, a.hot.state_delay, a.hot.n, i, q.iter + 1, q.popped_state);
     }
     q.z[0] = q.z[1] = q.z[2] = 0.0;
-    if (P.noise_on) {
+    if (a.hot.noise_on) {
         if (a.noise_z) {
             q.z[0] = as_global(a.noise_z)[3 * i + 0];
             q.z[1] = as_global(a.noise_z)[3 * i + 1];
             q.z[2] = as_global(a.noise_z)[3 * i + 2];
         } else if (draw_noise) {
-            device_normals(seed, (uint64_t)(a.S->env_id_base + i), step_counter, q.z);
+            device_normals(seed, (uint64_t)(a.hot.env_id_base + i), step_counter, q.z);
         }
     }
 }
@@ -1213,6 +1311,9 @@ typedef const __attribute__((address_space(4))) StepArgs& KernArgs;   // the lau
 
 constexpr int kLocalMapWords = 4096;   // a shared lethal bitmap of up to 16 KB is staged in LDS for the exact tests
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kStaticChunks = (int)((sizeof(StepStatic) + 15) / 16);   // *S in 16-byte pieces
+
 static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles, int staged_map_words)
 {
     size_t bytes = ((size_t)2 * n_verts + lds_path_doubles + (size_t)kLocalPairs * 6 * kBlock + 8) * sizeof(double);
@@ -1221,26 +1322,104 @@ static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles, int staged
     bytes = (bytes + 15) & ~(size_t)15;
     bytes += (size_t)kLocalEnvs * sizeof(ParkedPose);
     bytes += (size_t)kLocalWaves * kSparseLdsWords * sizeof(uint32_t);   // a cell list per wave (coop_collides_sparse)
-    return bytes + (size_t)staged_map_words * sizeof(uint32_t);
+    bytes += (size_t)staged_map_words * sizeof(uint32_t);
+    bytes = (bytes + 15) & ~(size_t)15;
+    return bytes + kStaticChunks * 16;   // the parameter block *S
 }
 
+// A launch-argument value fetched NOW: the empty asm makes every 32-bit word of `v` an opaque scalar register at this
+// point, so the compiler can neither sink the fetch into a later basic block nor fetch the field again.  At a kernel start
+// every first touch of an argument line is a scalar-cache miss of ~450 cycles (measured: tools/diag_local.py), and hipcc
+// fetches an argument where it is first used, block by block, each fetch with its own wait -- nine dependent round trips
+// = 4.3 k cycles before the mover's last load was issued.  Fetched together (fetch_words: plain loads of adjacent words,
+// merged into wide fetches) and then pinned (pin_words), the prologue's arguments arrive in ONE round trip.
+template <int NW>
+__device__ __forceinline__ void fetch_words(const __attribute__((address_space(4))) void* p, uint32_t (&w)[NW])
+{
+    const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)p;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) w[k] = src[k];
+}
+
+template <int NW>
+__device__ __forceinline__ void pin_words(uint32_t (&w)[NW])
+{
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        asm("" : "+s"(w[k]));   // (not volatile: a volatile asm counts as a store, and every later fetch of a uniform
+                                //  address -- the parameter block *S -- would turn into a vector load)
+        w[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[k]);   // (tells the compiler the word is wave-uniform; folds away)
+    }
+}
+
+// what the prologue of step_local_kernel needs from the launch arguments (same member names as StepArgs: load_env takes either)
+struct PrologueArgs {
+    StepHot hot;
+    const StepStatic* S;
+    const void* actions;
+    const double* noise_z;
+    uint64_t* tick;
+    uint32_t flags;
+};
+
+// a wave-uniform 64-bit value that arrived through a vector load
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+static_assert(kStaticChunks <= 128, "*S is staged by the last two waves");
 template <bool WIDE, bool PLAIN>
 __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const StepArgs launch_args)
 {
     KernArgs a = *(const __attribute__((address_space(4))) StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    const uint64_t step_counter = a.tick[0], seed = a.tick[2];   // (StepArgs::tick: counter and seed live on the device)
-    const DevParams& P = a.S->P;
-    // what the classification behind barrier 1 needs from *S: asked for first of all -- scalar loads that miss at a kernel
-    // start (~3 k cycles) -- so that they are neither queued behind the barriers nor in front of the movers' loads
-    const OuterParams outer = outer_params(a.S->cull);
-    const double map_inv_res = a.S->map.inv_res;
-    const int map_rows = a.S->map.rows, map_cols = a.S->map.cols;
-    const int64_t near_stride = a.S->cull.near_stride;
-    const double* const map_origins = a.S->map.origins;
-    double org_x = a.S->map.ox, org_y = a.S->map.oy;
+    DIAG_STAMP_WAVES(512);    // every wave: first instruction
+#ifdef BCP_PRIO
+    // static issue priority by role: the four waves of a SIMD (mover, scorer, helper 1, helper 2 of one pair) compete for its
+    // issue slots, and the mover's chain is the workgroup's critical path
+    if (threadIdx.x < 256) __builtin_amdgcn_s_setprio(3);
+    else if (threadIdx.x < 512) __builtin_amdgcn_s_setprio(2);
+    else if (threadIdx.x < 768) __builtin_amdgcn_s_setprio(1);
+#endif
+    // The prologue is ONE memory round trip: everything a wave asks for first -- the mover's state and action, a scanner's
+    // target index, the old heading of the helper that takes its cos / sin, every wave's share of the staging data -- is
+    // addressed from the launch arguments alone (StepHot) and issued back to back before anything is waited for; the
+    // parameter block *S (scalar loads that miss at a kernel start) is asked for behind them and is in by the time the
+    // vector loads land.  (Round 2 staged array by array -- load, wait, LDS store -- and only then issued the state loads:
+    // five dependent round trips, 4.1 k cycles until the state had landed; tools/diag_local.py.)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool mover = wave < kLocalPairs, scorer = wave >= kLocalPairs && wave < 2 * kLocalPairs;
     const int pair = wave & (kLocalPairs - 1);
+    // (the launch arguments the prologue uses, fetched together before the first branch: pin_sgpr)
+    PrologueArgs L;
+    {
+        constexpr int kStateWords = PLAIN ? kHotStateWords : (int)(sizeof(DevState) / 4);
+        uint32_t w_st[kStateWords], w_hot[kHotPrologueWords], w_io[4], w_tick[2], w_flags[1];
+        fetch_words(&a.hot.st, w_st);
+        fetch_words(&a.hot.n, w_hot);
+        fetch_words(&a.actions, w_io);          // actions, noise_z
+        fetch_words(&a.tick, w_tick);
+        fetch_words(&a.flags, w_flags);
+        pin_words(w_st);
+        pin_words(w_hot);
+        pin_words(w_io);
+        pin_words(w_tick);
+        pin_words(w_flags);
+        __builtin_memset(&L.hot, 0, sizeof(L.hot));
+        __builtin_memcpy(&L.hot.st, w_st, sizeof(w_st));
+        __builtin_memcpy(&L.hot.n, w_hot, sizeof(w_hot));
+        __builtin_memcpy(&L.actions, &w_io[0], 8);
+        __builtin_memcpy(&L.noise_z, &w_io[2], 8);
+        __builtin_memcpy(&L.tick, w_tick, 8);
+        L.flags = w_flags[0];
+        L.S = a.S;   // (not pinned: a pointer that went through the asm is no longer known to be uniform, nor global)
+    }
+    const int hot_n_verts = L.hot.n_verts, hot_npath = L.hot.lds_path_doubles, hot_path_shared = L.hot.path_shared;
+    const int hot_map_rows = L.hot.map_rows, hot_map_cols = L.hot.map_cols, hot_map_wpr = L.hot.map_wpr;
+    const int hot_map_shared = L.hot.map_shared, hot_noise_on = L.hot.noise_on, hot_max_len = L.hot.path_max_len;
+    const int64_t hot_n = L.hot.n;
     // PLAIN (continuous reward, no delays): the backward scan for the last reached way point -- the longest stretch of
     // the reward provider -- is split three ways between the pair's scorer and its two helper waves (every third
     // candidate of the window each; contiguous thirds for paths in global memory); the mover takes the maximum and does
@@ -1250,8 +1429,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
 
     // ---- LDS
     __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
-    const int nq = 2 * P.n_verts;
-    const int npath = a.hot.lds_path_doubles;
+    const int nq = 2 * hot_n_verts;
+    const int npath = hot_npath;
     const LdsF64 lds_path = npath ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
     __attribute__((address_space(3))) double* hand_pose = qv + nq + npath + pair * 6 * kBlock;
     __attribute__((address_space(3))) double* hand_score = hand_pose + 3 * kBlock;
@@ -1264,104 +1443,209 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         (__attribute__((address_space(3))) ParkedPose*)((__attribute__((address_space(3))) char*)lds_dyn + rec_off);
     const LdsU32 cell_list = (LdsU32)(rec + kLocalEnvs) + wave * kSparseLdsWords;
     const LdsU32 lds_map = (LdsU32)(rec + kLocalEnvs) + kLocalWaves * kSparseLdsWords;
-    const int map_words = a.hot.map_shared && a.hot.map_rows * a.hot.map_wpr <= kLocalMapWords ? a.hot.map_rows * a.hot.map_wpr : 0;
+    const int map_words = ((hot_map_shared != 0) & (hot_map_rows * hot_map_wpr <= kLocalMapWords)) ? hot_map_rows * hot_map_wpr : 0;
+    // the parameter block *S, copied into LDS by the prologue: behind barrier 0 every wave reads its parameters from there.
+    // (Scalar fetches of *S take 1.3 - 2.2 k cycles at a kernel start, and a wave that holds the ~60 words it needs of the
+    //  block in scalar registers from the start has none left for the launch arguments.)
+    const uint32_t static_off = (uint32_t)(((size_t)((__attribute__((address_space(3))) char*)(lds_map + map_words) -
+                                                     (__attribute__((address_space(3))) char*)lds_dyn) + 15) & ~(size_t)15);
+    __attribute__((address_space(3))) u32x4* lds_static = (__attribute__((address_space(3))) u32x4*)((__attribute__((address_space(3))) char*)lds_dyn + static_off);
+    const __attribute__((address_space(3))) StepStatic* SL = (const __attribute__((address_space(3))) StepStatic*)lds_static;
 
     DIAG_STAMP(0);
+    DIAG_STAMP_WAVES(768);    // every wave: launch arguments fetched
     const int64_t gi = (int64_t)blockIdx.x * kLocalEnvs + pair * kBlock + lane;
-    const bool active = gi < a.hot.n;
-    const int64_t i = active ? gi : a.hot.n - 1;   // (inactive lanes of the last workgroup shadow env n-1 and never store)
-    // (0) the odometry noise of this step needs nothing from memory -- seed, env id, step counter: the scorer waves, idle
-    //     until the new pose exists, draw it (Philox + float64 Box-Muller, a third of the mover's way to the robot model)
-    //     while the movers' state loads are in flight, and hand it over in LDS
-    const bool noise_by_scorer = P.noise_on && !a.noise_z;
-    if (scorer && noise_by_scorer) {
-        double z[3];
-        device_normals(seed, (uint64_t)(a.S->env_id_base + i), step_counter, z);
-        hand_score[lane] = z[0];
-        hand_score[kBlock + lane] = z[1];
-        hand_score[2 * kBlock + lane] = z[2];
-    }
-    //     ... and the first helper wave of the pair cos / sin of the OLD heading, which the robot model needs at its very
-    //     end (path_velocity): one transcendental pair off the mover's chain.  (The tricycle's wheel-angle pair by the
-    //     second helper as well made barrier 0 later than it made the model shorter.)
-    if (!mover && !scorer && member == 1) {
-        double c0, s0;
-        cos_sin(as_global(a.hot.st.angle)[i], c0, s0);
-        hand_pose[lane] = c0;
-        hand_pose[kBlock + lane] = s0;
-    }
-    // staging: footprint vertices, the shared path with its bounding box and bucket index, the counters
-    if (tid < nq) qv[tid] = P.qverts[tid >> 1][tid & 1];
-    for (int k = tid; k < npath; k += kLocalWaves * kBlock) qv[nq + k] = as_global(a.hot.path_pts)[k];
-    if (a.hot.path_shared) {
-        if (tid >= 512 && tid < 520) lds_box[tid - 512] = a.hot.path_bbox[tid - 512];
-        if (tid >= 576 && tid < 576 + 128) lds_index[tid - 576] = reinterpret_cast<const uint32_t*>(a.hot.path_index)[tid - 576];
-    }
-    if (tid >= 960 && tid < 968) ctl[tid - 960] = 0;
-    for (int k = tid; k < map_words; k += kLocalWaves * kBlock) lds_map[k] = as_global(a.hot.map_bits)[k];   // (read after the barriers)
+    const bool active = gi < hot_n;
+    const int64_t i = active ? gi : hot_n - 1;   // (inactive lanes of the last workgroup shadow env n-1 and never store)
+    const bool noise_by_waves = (hot_noise_on != 0) & (L.noise_z == nullptr);   // the step's odometry noise is drawn here, by idle waves
 
-    // (1) the mover's state / action, the scorer's reward-state words
+    // (0) the step counter and the noise seed live on the device (StepArgs::tick): two dependent scalar fetches, first in
+    //     line for the waves that draw the noise (the last wave also moves the counter on at the end); movers never read them
+    //     (vector loads of a uniform address: a scalar fetch would share its counter with the fetches of *S below, and a
+    //      wave waiting for the one waits for all of them)
+    uint64_t tick_counter = 0, tick_seed = 0;
+    if (!mover) {
+        int zero;
+        asm("v_mov_b32 %0, 0" : "=v"(zero));   // (opaque: keeps these loads on the vector side)
+        const GlobalPtr<const uint64_t> t = as_global((const uint64_t*)L.tick) + zero;
+        tick_counter = t[0];
+        tick_seed = t[2];
+    }
+    // (1) every wave's own loads: the mover's state / action, a scanner's reward-state words, the old heading for the
+    //     helper that takes its cos / sin
     Pending q;
     double cmd0 = 0.0, cmd1 = 0.0;
     double box[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int my_len = a.hot.path_max_len;   // way points of this env's path (private paths: from the entry's record)
+    double old_angle = 0.0;
+    double own_org_x = 0.0, own_org_y = 0.0, own_len = 0.0;   // (only ever written by the loads below: a later assignment
+                                                               //  to a register a load is in flight to would wait for it)
+    const bool own_origin = !hot_path_shared || L.hot.map_origins != nullptr;
     if (mover) {
-        load_env<PLAIN>(a, seed, step_counter, i, active, q, cmd0, cmd1, !noise_by_scorer);
-    } else if (scanner) {
-        if (!PLAIN) q.min_dist = as_global(a.hot.st.min_dist)[i];   // (PLAIN: the scan only needs the target index)
-        q.target = as_global(a.hot.st.target_idx)[i];
-        q.geom = a.hot.geom_of_env ? as_global(a.hot.geom_of_env)[i] : 0;
-        q.collided = PLAIN ? 0 : (int32_t)(as_global(a.hot.st.collided)[i] != 0);
-        if (!a.hot.path_shared) {
-            const int64_t g = a.hot.geom_of_env ? (int64_t)q.geom : i;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) box[k] = a.hot.path_bbox[g * kBoxDoubles + k];
-            my_len = (int)as_global(a.hot.path_bbox)[g * kBoxDoubles + kBoxLen];
+        load_env<PLAIN>(L, 0, 0, i, active, q, cmd0, cmd1, false);
+        if (!hot_path_shared) {   // private paths: origin and length of the entry share a line
+            const int64_t g = L.hot.geom_of_env ? (int64_t)q.geom : i;
+            own_org_x = as_global(L.hot.path_bbox)[g * kBoxDoubles + kBoxOrigin];
+            own_org_y = as_global(L.hot.path_bbox)[g * kBoxDoubles + kBoxOrigin + 1];
+            own_len = as_global(L.hot.path_bbox)[g * kBoxDoubles + kBoxLen];
+        } else if (L.hot.map_origins) {   // (private maps with a shared path)
+            const int64_t g = L.hot.geom_of_env ? (int64_t)q.geom : i;
+            own_org_x = as_global(L.hot.map_origins)[2 * g + 0];
+            own_org_y = as_global(L.hot.map_origins)[2 * g + 1];
         }
+    } else {
+        if (scanner) {
+            if (!PLAIN) q.min_dist = as_global(L.hot.st.min_dist)[i];   // (PLAIN: the scan only needs the target index)
+            q.target = as_global(L.hot.st.target_idx)[i];
+            q.geom = L.hot.geom_of_env ? as_global(L.hot.geom_of_env)[i] : 0;
+            q.collided = PLAIN ? 0 : (int32_t)(as_global(L.hot.st.collided)[i] != 0);
+            if (!hot_path_shared) {
+                const int64_t g = L.hot.geom_of_env ? (int64_t)q.geom : i;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) box[k] = as_global(L.hot.path_bbox)[g * kBoxDoubles + k];
+                own_len = as_global(L.hot.path_bbox)[g * kBoxDoubles + kBoxLen];
+            }
+        }
+        if (member == 1) old_angle = as_global(L.hot.st.angle)[i];
     }
-    if (mover && !a.hot.path_shared) {   // private paths: origin and length of the entry share a line (in flight across barrier 0)
-        const int64_t g = slot_of(a.S, i, q);
-        org_x = as_global(a.hot.path_bbox)[g * kBoxDoubles + kBoxOrigin];
-        org_y = as_global(a.hot.path_bbox)[g * kBoxDoubles + kBoxOrigin + 1];
-        my_len = (int)as_global(a.hot.path_bbox)[g * kBoxDoubles + kBoxLen];
-    } else if (mover && map_origins) {   // (private maps with a shared path)
-        const int64_t g = slot_of(a.S, i, q);
-        org_x = as_global(map_origins)[2 * g + 0];
-        org_y = as_global(map_origins)[2 * g + 1];
-    }
-    __syncthreads();   // barrier 0: the noise is in LDS (the movers' loads have landed meanwhile)
-    // (2) mover: the robot model (_env_step, envs/base/env.py:442-461); the pose the reward provider will see goes to the scorer
-    Robot& r = q.r;
+    //     ... and the mover the seven robot constants of the model's first half (dt .. p_gain, adjacent in DevParams), by
+    //     vector loads of a uniform address: they arrive with the state, in vector registers, and scalar registers stay free
+    double rc[7] = {0, 0, 0, 0, 0, 0, 0};
     if (mover) {
-        if (noise_by_scorer) {
+        int zero;
+        asm("v_mov_b32 %0, 0" : "=v"(zero));   // (opaque: keeps these loads on the vector side)
+        const GlobalPtr<const double> pc = as_global(&a.S->P.dt) + zero;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) rc[u] = pc[u];
+    }
+    // (2) every wave's share of the staging data, into registers: footprint vertices, the shared path with its bounding
+    //     box and bucket index, the shared lethal bitmap (<= 4 words per thread), the parameter block *S (16 bytes per thread
+    //     of the last two waves)
+    u32x4 st_static = {0u, 0u, 0u, 0u};
+    if (tid >= 896 && tid < 896 + kStaticChunks) st_static = as_global(reinterpret_cast<const u32x4*>(a.S))[tid - 896];
+    const double st_q = tid < nq ? as_global(L.hot.qverts)[tid] : 0.0;
+    const double st_path = tid < npath ? as_global(L.hot.path_pts)[tid] : 0.0;
+    double st_box = 0.0;
+    uint32_t st_index = 0;
+    if (hot_path_shared) {
+        if (tid >= 512 && tid < 520) st_box = as_global(L.hot.path_bbox)[tid - 512];
+        if (tid >= 576 && tid < 576 + 128) st_index = as_global(reinterpret_cast<const uint32_t*>(L.hot.path_index))[tid - 576];
+    }
+    uint32_t st_map[kLocalMapWords / (kLocalWaves * kBlock)];
+#pragma unroll
+    for (int u = 0; u < kLocalMapWords / (kLocalWaves * kBlock); ++u) {
+        const int k = u * kLocalWaves * kBlock + tid;
+        st_map[u] = k < map_words ? as_global(L.hot.map_bits)[k] : 0u;
+    }
+    DIAG_STAMP_U(0, 10);   // mover: own + staging loads issued
+    DIAG_STAMP_U(4, 11);   // scorer: the same
+    DIAG_STAMP_WAVES(1280);   // every wave: prologue loads issued
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t step_counter = mover ? 0 : uniform_u64(tick_counter), seed = mover ? 0 : uniform_u64(tick_seed);
+    // (5) what needs no pose.  The odometry noise of this step needs nothing but seed, env id and step counter: Philox +
+    //     float64 Box-Muller.  Slots 1 and 2 -- the ones PlanEnv's noise model draws -- are the two halves of one pair
+    //     (device_normals): the scorer draws them; slot 0, when the model can consume it at all, the pair's second helper;
+    if (noise_by_waves && scorer) {
+        double z1, z2;
+        device_normals_12(seed, (uint64_t)(L.hot.env_id_base + i), step_counter, z1, z2);
+        hand_score[kBlock + lane] = z1;
+        hand_score[2 * kBlock + lane] = z2;
+        DIAG_STAMP_U(4, 1);   // scorer: noise drawn
+    }
+    if (noise_by_waves && member == 2) hand_score[lane] = L.hot.noise_slot0 ? device_normal_0(seed, (uint64_t)(L.hot.env_id_base + i), step_counter) : 0.0;
+    //     the first helper cos / sin of the OLD heading, which the robot model needs at its very end (path_velocity);
+    if (!mover && member == 1) {
+        double c0, s0;
+        cos_sin(old_angle, c0, s0);
+        hand_pose[lane] = c0;
+        hand_pose[kBlock + lane] = s0;
+        DIAG_STAMP_U(8, 2);   // helper: cos / sin of the old heading
+    }
+    //     the mover the first half of the robot model (_env_step, envs/base/env.py:442-461): front-wheel column, cos / sin
+    //     of the new wheel angle, velocity model
+    Robot& r = q.r;
+    RobotDrive drive;
+    drive.v = drive.w = 0.0;
+    drive.noisy = false;
+    if (mover) {
+        q.old = r.p;
+        q.drawn = 0;
+#ifdef BCP_DIAG
+        DIAG_WAIT_VMEM();
+        DIAG_STAMP_U(0, 3);    // mover: state loads landed (diagnostic build only: the wait is not in the shipping kernel)
+#endif
+        RobotConsts robot;
+        robot.model = L.hot.model;
+        robot.dynamic_model = L.hot.dynamic_model;
+        robot.model_front_column_pid = L.hot.model_front_column_pid;
+        robot.noise_on = hot_noise_on;
+        robot.dt = rc[0];
+        robot.L = rc[1];
+        robot.max_wheel_angle = rc[2];
+        robot.max_wheel_speed = rc[3];
+        robot.max_lin_acc = rc[4];
+        robot.max_ang_acc = rc[5];
+        robot.p_gain = rc[6];
+        drive = robot_step_begin(robot, r, cmd0, cmd1);
+        DIAG_STAMP_U(0, 12);   // mover: first half of the robot model done
+    }
+    // (6) staging data into LDS
+    if (tid < nq) qv[tid] = st_q;
+    if (tid < npath) qv[nq + tid] = st_path;
+    for (int k = kLocalWaves * kBlock + tid; k < npath; k += kLocalWaves * kBlock) qv[nq + k] = as_global(L.hot.path_pts)[k];   // (long paths)
+    if (hot_path_shared) {
+        if (tid >= 512 && tid < 520) lds_box[tid - 512] = st_box;
+        if (tid >= 576 && tid < 576 + 128) lds_index[tid - 576] = st_index;
+    }
+    if (tid >= 960 && tid < 968) ctl[tid - 960] = 0;
+#pragma unroll
+    for (int u = 0; u < kLocalMapWords / (kLocalWaves * kBlock); ++u) {
+        const int k = u * kLocalWaves * kBlock + tid;
+        if (k < map_words) lds_map[k] = st_map[u];   // (read after the barriers)
+    }
+    if (tid >= 896 && tid < 896 + kStaticChunks) lds_static[tid - 896] = st_static;
+    DIAG_STAMP_WAVES(1024);
+    __syncthreads();   // barrier 0: noise, old heading and the parameter block are in LDS
+    const DevParams& P = *(const DevParams*)&SL->P;
+    const int map_rows = hot_map_rows, map_cols = hot_map_cols;
+    const int my_len = hot_path_shared ? hot_max_len : (int)own_len;   // way points of this env's path
+    // (7) mover: the second half of the robot model; the pose the reward provider will see goes to the scanning waves
+    if (mover) {
+        if (noise_by_waves) {
             q.z[0] = hand_score[lane];
             q.z[1] = hand_score[kBlock + lane];
             q.z[2] = hand_score[2 * kBlock + lane];
         }
-        q.old = r.p;
-        q.drawn = 0;
         DIAG_STAMP(1);   // (the compiler may move loads across this: indicative only)
         KnownHeading old_heading;   // (from the helper wave, barrier 0)
         old_heading.c0 = hand_pose[lane];
         old_heading.s0 = hand_pose[kBlock + lane];
         old_heading.known = true;
-        q.err = robot_step(P, r, cmd0, cmd1, q.z, q.drawn, old_heading);
+        q.err = robot_step_end(P, r, drive, q.z, q.drawn, old_heading);
         const bool delayed = !PLAIN && P.pose_delay > 0 && q.iter + 1 > 1;
         hand_pose[lane] = delayed ? q.popped_pose[0] : r.p.x;
         hand_pose[kBlock + lane] = delayed ? q.popped_pose[1] : r.p.y;
         hand_pose[2 * kBlock + lane] = delayed ? q.popped_pose[2] : r.p.th;
         DIAG_STAMP(2);
     }
+    DIAG_STAMP_WAVES(1536);
     __syncthreads();
     DIAG_STAMP(3);
-    bool hit = false, park = false;
+    bool hit = false, park = false, parkable = false;
+    InitAhead ahead = no_init_ahead();
     if (mover) {
         // (3a) collision: distance-field classification; an undecided env is parked below
-        const int64_t g = slot_of(a.S, i, q);
+        // (its parameters are read from the LDS copy of *S here, where they are used: held from barrier 0 on they cost
+        //  25 vector registers across the robot model)
+        const OuterParams outer = outer_params(*(const CullDesc*)&SL->cull);
+        const double map_inv_res = SL->map.inv_res;
+        const int64_t near_stride = SL->cull.near_stride;
+        const double org_x = own_origin ? own_org_x : SL->map.ox, org_y = own_origin ? own_org_y : SL->map.oy;
+        const int64_t g = slot_of(SL, i, q);
         const int px = (int)rint((r.p.x - org_x) * map_inv_res);  // world_to_pixel, coordinate_transformations.py:185-205
         const int py = (int)rint((r.p.y - org_y) * map_inv_res);
         double c, s;
         cos_sin(r.p.th, c, s);
+        DIAG_STAMP_U(0, 4);    // mover: cos / sin of the new heading
         const int64_t map_env = a.hot.map_shared ? 0 : g;
         OuterLookups look;
         look.off_map = true;
@@ -1370,9 +1654,11 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             if (a.hot.near)
                 look = outer_lookups_near(outer, as_global(a.hot.near) + map_env * near_stride, map_rows, map_cols, px, py, c, s);
             else
-                look = outer_lookups_issue(a.S->cull, map_env, map_rows, map_cols, px, py, c, s);
+                look = outer_lookups_issue(*(const CullDesc*)&SL->cull, map_env, map_rows, map_cols, px, py, c, s);
         }
-        const int cls = active ? (a.hot.near ? outer_lookups_verdict(outer, look) : outer_lookups_verdict(a.S->cull, look)) : kFree;
+        const int cls = active ? (a.hot.near ? outer_lookups_verdict(outer, look) : outer_lookups_verdict(*(const CullDesc*)&SL->cull, look)) : kFree;
+        DIAG_STAMP_U(0, 5);    // mover: classified
+        parkable = cls == kAmbiguous;
         if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
             park = true;
             q.c = c;
@@ -1385,14 +1671,15 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     } else if (scanner && !(a.flags & kAblateNoReward)) {
         // (3b) the reward provider for the pose as it stands if nothing collides
         const double x = hand_pose[lane], y = hand_pose[kBlock + lane], th = hand_pose[2 * kBlock + lane];
-        const int64_t g = slot_of(a.S, i, q);
+        const int64_t g = slot_of(SL, i, q);
         PathWindow win;
-        if (a.S->path.shared)
+        if (SL->path.shared)
             win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
         else
-            win = path_window(P, box, a.S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+            win = path_window(P, box, SL->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
         const int m = my_len;
         const double* gpath = a.hot.path_pts + (a.hot.path_shared ? 0 : g * (int64_t)a.hot.path_max_len * 5);
+        DIAG_STAMP_U(4, 6);    // scorer: candidate window known
         if (PLAIN) {
             // this member's share of the candidate window [max(lo, target), min(hi, m - 1)].  Way points in LDS: every
             // third candidate (the ones near the target pass the cheap box test and cost ten times the others: contiguous
@@ -1413,6 +1700,9 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
                 last = last_reached_from(P, gpath, part, m, q.target, x, y, th);
             }
             ((__attribute__((address_space(3))) int32_t*)hand_score)[member * kBlock + lane] = last;
+            DIAG_STAMP_U(8, 7);     // helper 1 of pair 0: scanned
+            DIAG_STAMP_U(12, 8);    // helper 2 of pair 0: scanned
+            DIAG_MAX(9, max(hi - lo + 1, 0));   // longest candidate window among the lanes 0 of the workgroup's waves
         } else {
             double min_dist = q.min_dist;
             int target = q.target;
@@ -1430,6 +1720,11 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             hand_score[2 * kBlock + lane] = (double)target;
         }
     }
+    // (3c) a lane whose episode may end this step -- time-out reached, or a pose the classification could not clear -- asks
+    //      for its env's initial state now; the in-kernel reset at the end of the step then needs no memory round trip
+    if (mover && (a.flags & BCP_STEP_AUTO_RESET) && !a.hot.geom_of_env && active &&
+        (parkable || q.iter + 1 >= P.iteration_timeout))
+        ahead = fetch_init_ahead(SL, i, a.hot.model == BCP_MODEL_TRICYCLE);
     // (4) movers park the undecided poses in LDS right away (one LDS atomic per wave hands out the slots)
     __attribute__((address_space(3))) ParkedPose* my_rec = rec;
     if (mover) {
@@ -1482,14 +1777,14 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         if (PLAIN) {
             const __attribute__((address_space(3))) int32_t* found = (__attribute__((address_space(3))) int32_t*)hand_score;
             const int last = max(max(found[lane], found[kBlock + lane]), found[2 * kBlock + lane]);
-            const int64_t g = slot_of(a.S, i, q);
+            const int64_t g = slot_of(SL, i, q);
             const int m = my_len;
             sc.min_dist = q.min_dist;
             sc.target = q.target;
             if (lds_path)
                 sc.rew = reward_from_last(P, lds_path, m, last, r.p.x, r.p.y, sc.min_dist, sc.target);
             else
-                sc.rew = reward_from_last(P, a.S->path.pts + (a.S->path.shared ? 0 : g * (int64_t)a.S->path.max_len * 5), m,
+                sc.rew = reward_from_last(P, SL->path.pts + (SL->path.shared ? 0 : g * (int64_t)SL->path.max_len * 5), m,
                                           last, r.p.x, r.p.y, sc.min_dist, sc.target);
         } else {
             sc.rew = hand_score[lane];
@@ -1498,7 +1793,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         }
         DIAG_STAMP(6);    // mover: reward provider done
         if (active && !park)
-            finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len);
+            finalize_env_from<PLAIN>(a, SL, i, q, hit, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len, false, ahead);
     }
     DIAG_STAMP_W(8, 9);   // helper: past the second barrier
     const double vqx = lane < P.n_verts ? qv[2 * lane] : 0.0, vqy = lane < P.n_verts ? qv[2 * lane + 1] : 0.0;   // (row-by-row fallback)
@@ -1547,29 +1842,37 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     // (7) movers: the envs they parked are finished by the lane that holds their state, as soon as the verdicts are in
     //     (every parked pose has been claimed by now -- by this wave or by one that is working on it)
     if (mover && __ballot(park)) {
-        // While the verdicts are on their way: the reward a parked env gets IF its pose collides (provider run for the
-        // rolled-back pose) -- the longest part of finishing such an env, and the step ends with the workgroups that
-        // hold one.  Shared path in LDS, continuous provider without delays; otherwise finalize_env computes it itself.
-        const bool hit_score = PLAIN && lds_path && a.hot.path_shared && !(a.flags & kAblateNoReward);
-        ScoredFree sc_hit = sc;
-        if (hit_score && park) {
-            double md = q.min_dist;
-            int tg = q.target;
-            const PathWindow w = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index,
-                                             q.old.x, q.old.y);
-            sc_hit.rew = reward_step(P, lds_path, w, my_len, q.old.x, q.old.y, q.old.th, md, tg);
-            sc_hit.min_dist = md;
-            sc_hit.target = tg;
-        }
         int verdict = park ? 0 : 1;
         while (__ballot(verdict == 0)) {
             if (verdict == 0) verdict = __hip_atomic_load(&my_rec->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_s_sleep(1);
         }
+        // A pose that really collides is rolled back, and the reward provider runs for the OLD pose: the scan for its last
+        // reached way point by the whole wave, a candidate per lane (one lane walking the window alone took ~5 k cycles, and
+        // the step ends with the workgroups that hold such an env).  Shared path in LDS, continuous provider without delays;
+        // otherwise finalize_env_from computes it itself.
+        const bool hit_score = PLAIN && lds_path && a.hot.path_shared && !(a.flags & kAblateNoReward);
+        int last_hit = -1;
+        if (hit_score) {
+            uint64_t hits = __ballot(park && verdict == 2);
+            while (hits) {
+                const int src = (int)__ffsll((unsigned long long)hits) - 1;
+                hits &= hits - 1;
+                const double ox = bcast_d(q.old.x, src), oy = bcast_d(q.old.y, src), oth = bcast_d(q.old.th, src);
+                const int tg = bcast_i(q.target, src);
+                const PathWindow w = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, ox, oy);
+                const int found = coop_last_reached(P, lds_path, w, my_len, tg, ox, oy, oth);
+                if (lane == src) last_hit = found;
+            }
+        }
         if (park) {
             const bool fits = hit_score && verdict == 2;
-            if (fits) sc = sc_hit;
-            finalize_env<PLAIN>(a, i, q, verdict == 2, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len, fits);
+            if (fits) {
+                sc.min_dist = q.min_dist;
+                sc.target = q.target;
+                sc.rew = reward_from_last(P, lds_path, my_len, last_hit, q.old.x, q.old.y, sc.min_dist, sc.target);
+            }
+            finalize_env_from<PLAIN>(a, SL, i, q, verdict == 2, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len, fits, ahead);
         }
     }
     DIAG_STAMP(13);            // mover: out of tickets
@@ -1577,7 +1880,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
 #ifdef BCP_DIAG
     if (tid == 0 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 16 + 15] = (unsigned long long)n_parked;
 #endif
-    if ((a.flags & kStepAdvances) && tid == 0) {   // the last workgroup to get here moves the step counter on
+    if ((a.flags & kStepAdvances) && tid == (kLocalWaves - 1) * kBlock) {   // the last workgroup to get here moves the step counter on
         unsigned int* ticket = reinterpret_cast<unsigned int*>(a.tick + 3);
         if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
             *ticket = 0u;

@@ -1443,6 +1443,17 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     hot.map_shared = S.map.shared;
     hot.path_max_len = S.path.max_len;
     hot.near = S.cull.on ? S.cull.near : nullptr;
+    hot.noise_on = S.P.noise_on;
+    hot.n_verts = S.P.n_verts;
+    hot.control_delay = S.P.control_delay;
+    hot.pose_delay = S.P.pose_delay;
+    hot.state_delay = S.P.state_delay;
+    hot.dynamic_model = S.P.dynamic_model;
+    hot.noise_slot0 = (S.P.alpha[0] > 0.0 || S.P.alpha[1] > 0.0) ? 1 : 0;
+    hot.model_front_column_pid = S.P.model_front_column_pid;
+    hot.env_id_base = S.env_id_base;
+    hot.qverts = &h->dev_static->P.qverts[0][0];
+    hot.map_origins = S.map.origins;
     a.actions = io->actions;
     a.noise_z = io->noise_z;
     a.noise_z_out = io->noise_z_out;

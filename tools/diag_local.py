@@ -41,6 +41,20 @@ print("helper wave 8 had a ticket in %d of %d workgroups; parked poses per workg
 h = a[had] if had.any() else a[:1]
 print("  helper: ticket -> verdict  median %d  p90 %d ;  verdict -> verdict posted  median %d  p90 %d" % (
     np.median(h[:, 11] - h[:, 10]), np.percentile(h[:, 11] - h[:, 10], 90), np.median(h[:, 12] - h[:, 11]), np.percentile(h[:, 12] - h[:, 11], 90)))
+unames = {1: "scorer: noise drawn", 2: "helper: cos / sin of the old heading", 3: "mover: state loads landed (diag wait)",
+          4: "mover: cos / sin of the new heading", 5: "mover: classified", 6: "scorer: candidate window known",
+          7: "helper 1: scanned", 8: "helper 2: scanned", 10: "mover: prologue loads issued", 11: "scorer: prologue loads issued",
+          12: "mover: first half of the robot model"}
+for k in sorted(unames):
+    d = upper[:, k] - a[:, 0]
+    print("  %-45s since kernel entry: median %6d  p90 %6d  max %6d" % (unames[k], np.median(d), np.percentile(d, 90), d.max()))
+print("  longest candidate window among the lanes 0 of a workgroup's waves: median %d  p90 %d  max %d way points" % (
+    np.median(upper[:, 9]), np.percentile(upper[:, 9], 90), upper[:, 9].max()))
+first = raw[512:512 + n // 256].min(axis=1, keepdims=True)   # the first instruction of the workgroup's earliest wave
+print("  stamp 0 (wave 0, arguments fetched) since the workgroup's first instruction: median %d" % np.median(a[:, 0] - first[:, 0]))
+for base, what in ((512, "first instruction"), (768, "launch arguments fetched"), (1280, "prologue loads issued"), (1024, "arrival at barrier 0"), (1536, "arrival at barrier 1")):
+    w = raw[base:base + n // 256] - first
+    print("  %-26s by wave (median cycles since the workgroup's first instruction): %s" % (what, " ".join("%5d" % v for v in np.median(w, axis=0))))
 end = np.maximum(a[:, 13], a[:, 14]) - t0
 print("workgroup end since the earliest start: median %d  p90 %d  max %d cycles" % (np.median(end), np.percentile(end, 90), end.max()))
 
