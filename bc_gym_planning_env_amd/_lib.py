@@ -11,7 +11,7 @@ MAX_VERTS = 32
 MODEL_TRICYCLE, MODEL_DIFFDRIVE = 0, 1
 REWARD_CONTINUOUS, REWARD_PURE_PURSUIT = 0, 1
 STEP_AUTO_RESET, STEP_ACTIONS_F32 = 1, 2
-ERR_ANGLE_JUMP, ERR_TIME_ORDER = 1, 2
+ERR_ANGLE_JUMP, ERR_TIME_ORDER, ERR_INTERNAL = 1, 2, 4
 TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL, TUNE_DEFER, TUNE_EDT_LDS, TUNE_FUSED = 0, 1, 2, 3, 4, 5
 E_NO_DEVICE = -2
 
@@ -78,6 +78,7 @@ SYMBOLS = {
     "bcp_reset_masked": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "bcp_broadcast_state": (C.c_int, [_H, C.c_int64, C.c_void_p, C.c_void_p]),
     "bcp_step": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_void_p]),
+    "bcp_expired_waits": (C.c_int, [_H, C.POINTER(C.c_int64), C.c_void_p]),
     "bcp_robot_step": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcp_pose_collides": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "bcp_is_robot_colliding": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -705,8 +705,13 @@ class BatchedPlanEnv(object):
         return self._obs, self.reward, done, self._info
 
     def check_errors(self):
-        """Raise what the reference would have raised during the last step (synchronises)."""
-        bad = torch.nonzero(self.err).flatten()
+        """Raise what the reference would have raised during the last step (synchronises); and a RuntimeError if a
+        wait inside the step kernel ever gave up (bcp_expired_waits: a defect of the library, not of the data)."""
+        gave_up = C.c_int64()
+        _lib.check(self._lib.bcp_expired_waits(self._h, C.byref(gave_up), self._stream()))
+        if gave_up.value:
+            raise RuntimeError("libbcplan: %d bounded wait(s) of the step kernel ran into their limit" % gave_up.value)
+        bad = torch.nonzero(self.err & _lib.ERR_ANGLE_JUMP).flatten()
         if len(bad):
             raise Exception("Path has missing/corrupted angle data at env indices: %s" % bad.cpu().numpy())
 

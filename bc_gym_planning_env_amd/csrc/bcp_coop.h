@@ -156,6 +156,41 @@ __device__ __forceinline__ OuterLookups outer_lookups_near(const OuterParams& C,
     return L;
 }
 
+// The outer test on the 1-bit tiles in one piece, as step_local_kernel's movers run it: straight-line code (a sample that
+// is not stored reads word 0 and is masked out afterwards: no branch per sample, all eight loads in flight together), and
+// the sample offsets in float32.  The offsets only select WHICH pixel stands for a sample; kSlackOuter budgets 0.7072 px
+// for that choice against the 0.70711 px of an exactly rounded centre, and a float32 offset (|offset| < 128 px, relative
+// error 1.2e-7 in cos / sin and in the fused multiply-add) is within 3e-5 px of the float64 one: a tie can fall the
+// other way, to a pixel 0.50003 px from the centre per axis, 0.70715 px in all -- inside the budget, so "free" still
+// means what it means in classify_outer (the verdict tests against the oracle cover both forms).
+template <typename WordPtr>
+__device__ __forceinline__ int classify_near(const OuterParams& C, WordPtr tiles, int rows, int cols, int px, int py, double c,
+                                             double s)
+{
+    if (px + C.reach < 0 || px - C.reach >= cols || py + C.reach < 0 || py - C.reach >= rows) return kFree;
+    const float cf = (float)c, sf = (float)s, ay = (float)C.axis_y;
+    const float ay_c = ay * cf, ay_s = ay * sf;
+    const int x0 = px + C.pad, y0 = py + C.pad;
+    uint32_t word[kMaxSamples];
+    int bit[kMaxSamples];
+#pragma unroll
+    for (int i = 0; i < kMaxSamples; ++i) {
+        const float ox = (float)C.out_x[i];
+        const int x = x0 + (int)rintf(fmaf(ox, cf, -ay_s)), y = y0 + (int)rintf(fmaf(ox, sf, ay_c));
+        const bool stored = (i < C.n_out) & ((unsigned)x < (unsigned)C.width) & ((unsigned)y < (unsigned)C.height);
+        const int at = ((y >> 5) * C.near_tx + (x >> 5)) * 32 + (y & 31);
+        bit[i] = stored ? (x & 31) : 32;
+        word[i] = tiles[stored ? at : 0];
+    }
+    // a sample outside the stored (padded) rectangle is more than `pad` px away from every cell of the map
+    const bool unstored_is_near = min(C.pad + 1, 255) < C.t_out;
+    uint32_t near = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxSamples; ++i)
+        near |= bit[i] < 32 ? ((word[i] >> bit[i]) & 1u) : (uint32_t)((i < C.n_out) & unstored_is_near);
+    return near ? kAmbiguous : kFree;
+}
+
 __device__ __forceinline__ int outer_lookups_verdict(const OuterParams& C, const OuterLookups& L)
 {
     if (L.off_map) return kFree;

@@ -125,7 +125,7 @@ struct StepArgs {
     // the single-kernel step) reads it, tick[1] = as kernel 2 reads it, tick[2] = seed, tick[3] = ticket of the
     // single-kernel step.  Two-kernel step: kernel 1 copies tick[0] to tick[1], kernel 2 stores tick[1] + 1 to tick[0]
     // -- each word is only written while no kernel that reads it is running.  Single-kernel step: the last workgroup
-    // to finish (ticket) advances tick[0].
+    // to finish (ticket) advances tick[0].  tick[4] counts the bounded waits of step_local_kernel that gave up (bcp_expired_waits).
     uint64_t* tick;
     int32_t* pending_base;     // [2][kShards] or nullptr
     int32_t* adapt_base;       // [2] thresholds + [2][kShards] in-place counters, or nullptr (no adaptation)
@@ -1309,22 +1309,25 @@ constexpr int kLocalEnvs = kLocalPairs * kBlock;
 typedef const __attribute__((address_space(4))) StepArgs& KernArgs;   // the launch arguments where they lie: scalar loads on
                                                                       // demand instead of ~500 bytes pinned in SGPRs
 
+constexpr int kScanItems = 1024;       // candidates of a pair's 64 envs that the flat scan list holds (bytes of LDS)
 constexpr int kLocalMapWords = 4096;   // a shared lethal bitmap of up to 16 KB is staged in LDS for the exact tests
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kStaticChunks = (int)((sizeof(StepStatic) + 15) / 16);   // *S in 16-byte pieces
 
-static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles, int staged_map_words)
+static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles, int staged_map_words, bool plain = true)
 {
     size_t bytes = ((size_t)2 * n_verts + lds_path_doubles + (size_t)kLocalPairs * 6 * kBlock + 8) * sizeof(double);
     bytes += 2 * kBlock * sizeof(uint32_t);          // bucket index of the shared path
-    bytes += 8 * sizeof(int32_t);                    // parked count, ticket counter, movers parked, scans done per pair
+    bytes += 16 * sizeof(int32_t);                   // parked count, ticket counter, movers parked, -, scans done per pair [4], scan lists ready per pair [4], - [4]
     bytes = (bytes + 15) & ~(size_t)15;
     bytes += (size_t)kLocalEnvs * sizeof(ParkedPose);
     bytes += (size_t)kLocalWaves * kSparseLdsWords * sizeof(uint32_t);   // a cell list per wave (coop_collides_sparse)
     bytes += (size_t)staged_map_words * sizeof(uint32_t);
     bytes = (bytes + 15) & ~(size_t)15;
-    return bytes + kStaticChunks * 16;   // the parameter block *S
+    bytes += kStaticChunks * 16;   // the parameter block *S
+    if (!plain) bytes += (size_t)10 * kLocalEnvs * sizeof(double);   // delay queues: what the step's pushes will hand back
+    return bytes;
 }
 
 // A launch-argument value fetched NOW: the empty asm makes every 32-bit word of `v` an opaque scalar register at this
@@ -1371,6 +1374,18 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
 }
 
 static_assert(kStaticChunks <= 128, "*S is staged by the last two waves");
+// A spin on an LDS word another wave of the workgroup will set (`cond` true = keep waiting, wave-uniform).  Bounded: a wait
+// that the hand-off protocol guarantees to end within ~20 k cycles gives up after kPollLimit trips (~10^7 cycles) and sets
+// `expired`; the wave carries on with what it has and reports BCP_ERR_INTERNAL at the end.  (hipcc 7.2 has turned two
+// shapes of exactly these loops into endless spins, DESIGN.md "Compiler notes": a miscompile must fail a test, not wedge the GPU.)
+constexpr int kPollLimit = 1 << 16;
+#ifdef BCP_VAR_UNBOUNDED
+#define BOUNDED_POLL(cond, expired) do { while (cond) __builtin_amdgcn_s_sleep(1); } while (0)
+#else
+#define BOUNDED_POLL(cond, expired) do { int trips_ = 0; while (cond) { __builtin_amdgcn_s_sleep(1); if (++trips_ > kPollLimit) { (expired) = true; break; } } } while (0)
+#endif
+constexpr uint32_t kDiagWithholdVerdicts = 1u << 23;   // -DBCP_DIAG builds: parked poses are tested but their verdicts never posted
+
 template <bool WIDE, bool PLAIN>
 __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const StepArgs launch_args)
 {
@@ -1379,9 +1394,11 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
 #ifdef BCP_PRIO
     // static issue priority by role: the four waves of a SIMD (mover, scorer, helper 1, helper 2 of one pair) compete for its
     // issue slots, and the mover's chain is the workgroup's critical path
+#if BCP_PRIO == 1
     if (threadIdx.x < 256) __builtin_amdgcn_s_setprio(3);
-    else if (threadIdx.x < 512) __builtin_amdgcn_s_setprio(2);
-    else if (threadIdx.x < 768) __builtin_amdgcn_s_setprio(1);
+#elif BCP_PRIO == 2
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(3);
+#endif
 #endif
     // The prologue is ONE memory round trip: everything a wave asks for first -- the mover's state and action, a scanner's
     // target index, the old heading of the helper that takes its cos / sin, every wave's share of the staging data -- is
@@ -1436,9 +1453,9 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     __attribute__((address_space(3))) double* hand_score = hand_pose + 3 * kBlock;
     __attribute__((address_space(3))) double* lds_box = qv + nq + npath + kLocalPairs * 6 * kBlock;   // [8]
     __attribute__((address_space(3))) uint32_t* lds_index = (__attribute__((address_space(3))) uint32_t*)(lds_box + 8);  // [128]
-    __attribute__((address_space(3))) int32_t* ctl = (__attribute__((address_space(3))) int32_t*)(lds_index + 2 * kBlock);   // [8]
+    __attribute__((address_space(3))) int32_t* ctl = (__attribute__((address_space(3))) int32_t*)(lds_index + 2 * kBlock);   // [16]
     const uint32_t rec_off = (uint32_t)((((size_t)(nq + npath + kLocalPairs * 6 * kBlock + 8) * sizeof(double) +
-                                          2 * kBlock * sizeof(uint32_t) + 8 * sizeof(int32_t)) + 15) & ~(size_t)15);
+                                          2 * kBlock * sizeof(uint32_t) + 16 * sizeof(int32_t)) + 15) & ~(size_t)15);
     __attribute__((address_space(3))) ParkedPose* rec =
         (__attribute__((address_space(3))) ParkedPose*)((__attribute__((address_space(3))) char*)lds_dyn + rec_off);
     const LdsU32 cell_list = (LdsU32)(rec + kLocalEnvs) + wave * kSparseLdsWords;
@@ -1451,6 +1468,10 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
                                                      (__attribute__((address_space(3))) char*)lds_dyn) + 15) & ~(size_t)15);
     __attribute__((address_space(3))) u32x4* lds_static = (__attribute__((address_space(3))) u32x4*)((__attribute__((address_space(3))) char*)lds_dyn + static_off);
     const __attribute__((address_space(3))) StepStatic* SL = (const __attribute__((address_space(3))) StepStatic*)lds_static;
+    // delay queues (PLAIN = false): the ten values this step's pushes into the pose / robot-state queues will hand back are
+    // fetched with the state (fifo_peek) and needed when the env is finished; in between they wait in LDS, not in 20 vector
+    // registers of a wave that has none to spare
+    __attribute__((address_space(3))) double* fifo_stash = (__attribute__((address_space(3))) double*)(lds_static + kStaticChunks) + pair * kBlock + lane;
 
     DIAG_STAMP(0);
     DIAG_STAMP_WAVES(768);    // every wave: launch arguments fetched
@@ -1509,8 +1530,9 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     }
     //     ... and the mover the seven robot constants of the model's first half (dt .. p_gain, adjacent in DevParams), by
     //     vector loads of a uniform address: they arrive with the state, in vector registers, and scalar registers stay free
+    //     (PLAIN only: with delay queues the first half runs behind barrier 0, on the constants in LDS)
     double rc[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (mover) {
+    if (PLAIN && mover) {
         int zero;
         asm("v_mov_b32 %0, 0" : "=v"(zero));   // (opaque: keeps these loads on the vector side)
         const GlobalPtr<const double> pc = as_global(&a.S->P.dt) + zero;
@@ -1520,21 +1542,26 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     // (2) every wave's share of the staging data, into registers: footprint vertices, the shared path with its bounding
     //     box and bucket index, the shared lethal bitmap (<= 4 words per thread), the parameter block *S (16 bytes per thread
     //     of the last two waves)
+    //     (with delay queues a mover already holds ten more values in flight: it fetches its share of the staging data
+    //      behind the first half of the robot model instead -- a second round trip for it, but no register spills)
+    const bool stage_early = PLAIN || !mover;
     u32x4 st_static = {0u, 0u, 0u, 0u};
     if (tid >= 896 && tid < 896 + kStaticChunks) st_static = as_global(reinterpret_cast<const u32x4*>(a.S))[tid - 896];
-    const double st_q = tid < nq ? as_global(L.hot.qverts)[tid] : 0.0;
-    const double st_path = tid < npath ? as_global(L.hot.path_pts)[tid] : 0.0;
-    double st_box = 0.0;
+    double st_q = 0.0, st_path = 0.0, st_box = 0.0;
     uint32_t st_index = 0;
-    if (hot_path_shared) {
-        if (tid >= 512 && tid < 520) st_box = as_global(L.hot.path_bbox)[tid - 512];
-        if (tid >= 576 && tid < 576 + 128) st_index = as_global(reinterpret_cast<const uint32_t*>(L.hot.path_index))[tid - 576];
-    }
-    uint32_t st_map[kLocalMapWords / (kLocalWaves * kBlock)];
+    uint32_t st_map[kLocalMapWords / (kLocalWaves * kBlock)] = {};
+    if (stage_early) {
+        if (tid < nq) st_q = as_global(L.hot.qverts)[tid];
+        if (tid < npath) st_path = as_global(L.hot.path_pts)[tid];
+        if (hot_path_shared) {
+            if (tid >= 512 && tid < 520) st_box = as_global(L.hot.path_bbox)[tid - 512];
+            if (tid >= 576 && tid < 576 + 128) st_index = as_global(reinterpret_cast<const uint32_t*>(L.hot.path_index))[tid - 576];
+        }
 #pragma unroll
-    for (int u = 0; u < kLocalMapWords / (kLocalWaves * kBlock); ++u) {
-        const int k = u * kLocalWaves * kBlock + tid;
-        st_map[u] = k < map_words ? as_global(L.hot.map_bits)[k] : 0u;
+        for (int u = 0; u < kLocalMapWords / (kLocalWaves * kBlock); ++u) {
+            const int k = u * kLocalWaves * kBlock + tid;
+            if (k < map_words) st_map[u] = as_global(L.hot.map_bits)[k];
+        }
     }
     DIAG_STAMP_U(0, 10);   // mover: own + staging loads issued
     DIAG_STAMP_U(4, 11);   // scorer: the same
@@ -1573,6 +1600,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         DIAG_WAIT_VMEM();
         DIAG_STAMP_U(0, 3);    // mover: state loads landed (diagnostic build only: the wait is not in the shipping kernel)
 #endif
+      if (PLAIN) {
         RobotConsts robot;
         robot.model = L.hot.model;
         robot.dynamic_model = L.hot.dynamic_model;
@@ -1587,8 +1615,24 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         robot.p_gain = rc[6];
         drive = robot_step_begin(robot, r, cmd0, cmd1);
         DIAG_STAMP_U(0, 12);   // mover: first half of the robot model done
+      }
+        if (!PLAIN) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) fifo_stash[k * kLocalEnvs] = q.popped_pose[k];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) fifo_stash[(3 + k) * kLocalEnvs] = q.popped_state[k];
+        }
     }
     // (6) staging data into LDS
+    if (!stage_early) {   // (movers of a configuration with delay queues: see (2); tid < 256)
+        if (tid < nq) st_q = as_global(a.hot.qverts)[tid];
+        if (tid < npath) st_path = as_global(a.hot.path_pts)[tid];
+#pragma unroll
+        for (int u = 0; u < kLocalMapWords / (kLocalWaves * kBlock); ++u) {
+            const int k = u * kLocalWaves * kBlock + tid;
+            if (k < map_words) st_map[u] = as_global(a.hot.map_bits)[k];
+        }
+    }
     if (tid < nq) qv[tid] = st_q;
     if (tid < npath) qv[nq + tid] = st_path;
     for (int k = kLocalWaves * kBlock + tid; k < npath; k += kLocalWaves * kBlock) qv[nq + k] = as_global(L.hot.path_pts)[k];   // (long paths)
@@ -1596,7 +1640,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         if (tid >= 512 && tid < 520) lds_box[tid - 512] = st_box;
         if (tid >= 576 && tid < 576 + 128) lds_index[tid - 576] = st_index;
     }
-    if (tid >= 960 && tid < 968) ctl[tid - 960] = 0;
+    if (tid >= 960 && tid < 976) ctl[tid - 960] = 0;
 #pragma unroll
     for (int u = 0; u < kLocalMapWords / (kLocalWaves * kBlock); ++u) {
         const int k = u * kLocalWaves * kBlock + tid;
@@ -1620,17 +1664,19 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         old_heading.c0 = hand_pose[lane];
         old_heading.s0 = hand_pose[kBlock + lane];
         old_heading.known = true;
+        if (!PLAIN) drive = robot_step_begin(P, r, cmd0, cmd1);
         q.err = robot_step_end(P, r, drive, q.z, q.drawn, old_heading);
         const bool delayed = !PLAIN && P.pose_delay > 0 && q.iter + 1 > 1;
-        hand_pose[lane] = delayed ? q.popped_pose[0] : r.p.x;
-        hand_pose[kBlock + lane] = delayed ? q.popped_pose[1] : r.p.y;
-        hand_pose[2 * kBlock + lane] = delayed ? q.popped_pose[2] : r.p.th;
+        hand_pose[lane] = delayed ? fifo_stash[0] : r.p.x;
+        hand_pose[kBlock + lane] = delayed ? fifo_stash[kLocalEnvs] : r.p.y;
+        hand_pose[2 * kBlock + lane] = delayed ? fifo_stash[2 * kLocalEnvs] : r.p.th;
         DIAG_STAMP(2);
     }
     DIAG_STAMP_WAVES(1536);
     __syncthreads();
     DIAG_STAMP(3);
     bool hit = false, park = false, parkable = false;
+    bool poll_expired = false;   // (wave-uniform) one of the bounded waits below gave up
     InitAhead ahead = no_init_ahead();
     if (mover) {
         // (3a) collision: distance-field classification; an undecided env is parked below
@@ -1647,16 +1693,20 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         cos_sin(r.p.th, c, s);
         DIAG_STAMP_U(0, 4);    // mover: cos / sin of the new heading
         const int64_t map_env = a.hot.map_shared ? 0 : g;
-        OuterLookups look;
-        look.off_map = true;
-        if (!(a.flags & (kAblateNoCollision | kAblateNoClassify))) {
+        int cls = kFree;
+#ifdef BCP_DIAG
+        if (!(a.flags & (kAblateNoCollision | kAblateNoClassify)))
+#endif
+        {
             // (a shared field is 18 KB for the 183 x 183 map and stays in the CU's L1: a copy in LDS measured no faster)
-            if (a.hot.near)
-                look = outer_lookups_near(outer, as_global(a.hot.near) + map_env * near_stride, map_rows, map_cols, px, py, c, s);
-            else
-                look = outer_lookups_issue(*(const CullDesc*)&SL->cull, map_env, map_rows, map_cols, px, py, c, s);
+            if (a.hot.near) {
+                cls = classify_near(outer, as_global(a.hot.near) + map_env * near_stride, map_rows, map_cols, px, py, c, s);
+            } else {
+                const OuterLookups look = outer_lookups_issue(*(const CullDesc*)&SL->cull, map_env, map_rows, map_cols, px, py, c, s);
+                cls = outer_lookups_verdict(*(const CullDesc*)&SL->cull, look);
+            }
         }
-        const int cls = active ? (a.hot.near ? outer_lookups_verdict(outer, look) : outer_lookups_verdict(*(const CullDesc*)&SL->cull, look)) : kFree;
+        if (!active) cls = kFree;
         DIAG_STAMP_U(0, 5);    // mover: classified
         parkable = cls == kAmbiguous;
         if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
@@ -1672,27 +1722,87 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         // (3b) the reward provider for the pose as it stands if nothing collides
         const double x = hand_pose[lane], y = hand_pose[kBlock + lane], th = hand_pose[2 * kBlock + lane];
         const int64_t g = slot_of(SL, i, q);
+        const int m = my_len;
+        const double* gpath = a.hot.path_pts + (a.hot.path_shared ? 0 : g * (int64_t)a.hot.path_max_len * 5);
+        if (PLAIN && lds_path) {
+            // Shared path in LDS: the candidates of the pair's 64 envs as ONE list, shared out evenly between the three
+            // scanning waves.  More than half of the envs of a rollout are nowhere near the path (no candidate at all) while
+            // a few have ten: with a lane per env the waves ran as many trips as their unluckiest lane (four) for an average
+            // of less than one useful candidate per lane and trip.  The scorer looks up every env's window, numbers the
+            // candidates (prefix sum over the wave), writes the list -- item k -> env -- and releases it; then every wave
+            // takes the items k = 64 * (3 r + member) + lane, tests way point lo(env) + (k - first(env)) against the env's
+            // pose and keeps the largest reached index per env with an LDS maximum.  (`hand_score` is free by now: the noise
+            // it carried was read behind barrier 0.)
+            __attribute__((address_space(3))) int32_t* res = (__attribute__((address_space(3))) int32_t*)hand_score;        // [64]
+            __attribute__((address_space(3))) uint32_t* lo_first = (__attribute__((address_space(3))) uint32_t*)(res + kBlock);   // [64]: lo | first << 16
+            __attribute__((address_space(3))) uint8_t* items = (__attribute__((address_space(3))) uint8_t*)(res + 2 * kBlock);   // [kScanItems]
+            int total;
+            if (member == 0) {
+                const PathWindow win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
+                DIAG_STAMP_U(4, 6);    // scorer: candidate window known
+                const int lo = max(win.lo, q.target), hi = min(win.hi, m - 1);
+                const int cnt = max(hi - lo + 1, 0);
+                // inclusive prefix sum over the wave: four DPP row shifts inside every 16-lane row (lanes shifted in from
+                // outside a row read 0), then the totals of the rows below (three v_readlane) -- no LDS round trip
+                int incl = cnt;
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
+                const int t0 = bcast_i(incl, 15), t1 = bcast_i(incl, 31), t2 = bcast_i(incl, 47);
+                incl += (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+                total = bcast_i(incl, 63);
+                const int first = incl - cnt;
+                res[lane] = -1;
+                if (total <= kScanItems) {
+                    lo_first[lane] = (uint32_t)lo | ((uint32_t)first << 16);
+                    for (int t = 0; t < cnt; ++t) items[first + t] = (uint8_t)lane;
+                }
+                DIAG_MAX(9, cnt);   // longest candidate window among the lanes 0 of the workgroup's waves
+                if (lane == 0) __hip_atomic_store(&ctl[8 + pair], total + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                int ready;
+                BOUNDED_POLL((ready = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[8 + pair], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP))) == 0, poll_expired);
+                total = ready > 0 ? ready - 1 : 0;
+            }
+            if (total <= kScanItems) {
+                for (int base = 64 * member; base < total; base += 64 * 3) {
+                    const int k = base + lane;
+                    if (k < total) {
+                        const int e = (int)items[k];
+                        const uint32_t lf = lo_first[e];
+                        const int j = (int)(lf & 0xFFFFu) + (k - (int)(lf >> 16));
+                        const LdsF64 wp = lds_path + 5 * j;
+                        if (way_point_reached(P, wp[0], wp[1], wp[2], wp[3], wp[4], hand_pose[e], hand_pose[kBlock + e], hand_pose[2 * kBlock + e]))
+                            __hip_atomic_fetch_max(&res[e], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            } else {
+                // (a path so dense that the pair's windows hold more than kScanItems way points: a lane per env, every third
+                //  candidate per wave, as for paths in global memory)
+                const PathWindow win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
+                PathWindow part;
+                part.hi = min(win.hi, m - 1) - member;
+                part.lo = max(win.lo, q.target);
+                const int last = last_reached_from(P, lds_path, part, m, q.target, x, y, th, 3);
+                if (last >= 0) __hip_atomic_fetch_max(&res[lane], last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            DIAG_STAMP_U(4, 14);    // scorer of pair 0: scanned
+            DIAG_STAMP_U(8, 7);     // helper 1 of pair 0: scanned
+            DIAG_STAMP_U(12, 8);    // helper 2 of pair 0: scanned
+        } else {
         PathWindow win;
         if (SL->path.shared)
             win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
         else
             win = path_window(P, box, SL->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
-        const int m = my_len;
-        const double* gpath = a.hot.path_pts + (a.hot.path_shared ? 0 : g * (int64_t)a.hot.path_max_len * 5);
         DIAG_STAMP_U(4, 6);    // scorer: candidate window known
         if (PLAIN) {
-            // this member's share of the candidate window [max(lo, target), min(hi, m - 1)].  Way points in LDS: every
-            // third candidate (the ones near the target pass the cheap box test and cost ten times the others: contiguous
-            // thirds left the wave with the bottom third scanning 2 k cycles after the one with the top third was done);
-            // way points in memory: a contiguous third, counted from the top (four neighbours per round trip).
+            // way points in memory: this member's share of the candidate window [max(lo, target), min(hi, m - 1)] is a
+            // contiguous third, counted from the top (four neighbours per round trip)
             const int lo = max(win.lo, q.target), hi = min(win.hi, m - 1);
             int last;
-            if (lds_path) {
-                PathWindow part;
-                part.hi = hi - member;
-                part.lo = lo;
-                last = last_reached_from(P, lds_path, part, m, q.target, x, y, th, 3);
-            } else {
+            {
                 const int third = (max(hi - lo + 1, 0) + 2) / 3;
                 PathWindow part;
                 part.hi = hi - member * third;
@@ -1719,10 +1829,12 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             hand_score[kBlock + lane] = min_dist;
             hand_score[2 * kBlock + lane] = (double)target;
         }
+        }
     }
     // (3c) a lane whose episode may end this step -- time-out reached, or a pose the classification could not clear -- asks
     //      for its env's initial state now; the in-kernel reset at the end of the step then needs no memory round trip
-    if (mover && (a.flags & BCP_STEP_AUTO_RESET) && !a.hot.geom_of_env && active &&
+    //      (PLAIN configurations: with delay queues the movers have no registers to spare for it)
+    if (PLAIN && mover && (a.flags & BCP_STEP_AUTO_RESET) && !a.hot.geom_of_env && active &&
         (parkable || q.iter + 1 >= P.iteration_timeout))
         ahead = fetch_init_ahead(SL, i, a.hot.model == BCP_MODEL_TRICYCLE);
     // (4) movers park the undecided poses in LDS right away (one LDS atomic per wave hands out the slots)
@@ -1755,15 +1867,13 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     if (mover) {
         if (lane == 0) __hip_atomic_fetch_add(&ctl[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         const int scans = PLAIN ? 3 : 1;
-        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[4 + pair], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < scans)
-            __builtin_amdgcn_s_sleep(1);
+        BOUNDED_POLL(__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[4 + pair], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < scans, poll_expired);
     } else if (scanner && lane == 0) {
         __hip_atomic_fetch_add(&ctl[4 + pair], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // (everybody: the number of parked poses must be final before a wave draws tickets -- a ticket is consumed by the
     //  draw, so a wave that compared it with a stale count would drop a pose, and its owner would wait for ever)
-    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < kLocalPairs)
-        __builtin_amdgcn_s_sleep(1);
+    BOUNDED_POLL(__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < kLocalPairs, poll_expired);
     DIAG_STAMP(5);
     // (scalar: the ticket loop below must stay wave-uniform)
     const int n_parked = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -1776,7 +1886,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     if (mover) {
         if (PLAIN) {
             const __attribute__((address_space(3))) int32_t* found = (__attribute__((address_space(3))) int32_t*)hand_score;
-            const int last = max(max(found[lane], found[kBlock + lane]), found[2 * kBlock + lane]);
+            const int last = lds_path ? found[lane] : max(max(found[lane], found[kBlock + lane]), found[2 * kBlock + lane]);
             const int64_t g = slot_of(SL, i, q);
             const int m = my_len;
             sc.min_dist = q.min_dist;
@@ -1792,20 +1902,36 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             sc.target = (int)hand_score[2 * kBlock + lane];
         }
         DIAG_STAMP(6);    // mover: reward provider done
-        if (active && !park)
+        if (active && !park) {
+            if (!PLAIN) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) q.popped_pose[k] = fifo_stash[k * kLocalEnvs];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) q.popped_state[k] = fifo_stash[(3 + k) * kLocalEnvs];
+            }
             finalize_env_from<PLAIN>(a, SL, i, q, hit, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len, false, ahead);
+        }
     }
     DIAG_STAMP_W(8, 9);   // helper: past the second barrier
     const double vqx = lane < P.n_verts ? qv[2 * lane] : 0.0, vqy = lane < P.n_verts ? qv[2 * lane + 1] : 0.0;   // (row-by-row fallback)
     // (6) every wave settles parked poses, a ticket at a time: exact test, verdict into the record.
-    // (Control flow: ONE single-lane region per iteration -- lane 0 posts the verdict and draws the next ticket in the same
-    //  block -- and a scalar loop condition.  With the draw at the top of the body, i.e. two `if (lane == 0)` regions per
-    //  trip, hipcc 7.2 threaded lane 0's path across the back edge and split the loop in two; lanes 1..63 then span in the
-    //  inner one on ticket 0 for ever while lane 0 waited outside it.)
+    // (Control flow: a scalar loop condition and NO single-lane region around the draw.  With two `if (lane == 0)` regions
+    //  per trip hipcc 7.2 threaded lane 0's path across the back edge and split the loop in two; lanes 1..63 then span in
+    //  the inner one on ticket 0 for ever while lane 0 waited outside it.  Round 2 kept one such region per trip; round 3
+    //  draws with every lane, so no edit or compiler update can bring that shape back.)
     DIAG_STAMP(7);        // mover: decided envs finished
+    // (the draw has no single-lane region: every lane issues an LDS add -- lane 0 adds 1 to the ticket counter, the others add
+    //  0 to a word of their own in the wave's cell list, which changes nothing: 64 lanes on ONE word are 64 serialised
+    //  atomics, and 16 waves drawing at once cost the step 4 us that way -- and lane 0's returned value is the ticket)
+    __attribute__((address_space(3))) int* const ticket_word =
+        lane == 0 ? (__attribute__((address_space(3))) int*)&ctl[1] : (__attribute__((address_space(3))) int*)(cell_list + lane);
+#ifdef BCP_VAR_TICKET
     int ticket = 0;
     if (lane == 0) ticket = atomicAdd((int*)&ctl[1], 1);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
+#else
+    int ticket = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(ticket_word, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+#endif
     while (ticket < n_parked) {
         DIAG_STAMP_W(8, 10);   // helper: has a ticket
         __attribute__((address_space(3))) ParkedPose* e = rec + ticket;
@@ -1831,21 +1957,38 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         }
         DIAG_MAX(0, ((DIAG_NOW() - test_from) << 4) | (unsigned)how);   // the longest exact test of the workgroup, and its kind
         DIAG_STAMP_W(8, 11);   // helper: verdict
+        bool post = lane == 0;
+#ifdef BCP_DIAG
+        post = post && !(a.flags & kDiagWithholdVerdicts);
+#endif
+        if (post) __hip_atomic_store(&e->verdict, h ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef BCP_VAR_TICKET
         int next = 0;
-        if (lane == 0) {
-            __hip_atomic_store(&e->verdict, h ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            next = atomicAdd((int*)&ctl[1], 1);
-        }
+        if (lane == 0) next = atomicAdd((int*)&ctl[1], 1);
         ticket = __builtin_amdgcn_readfirstlane(next);
+#else
+        ticket = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(ticket_word, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+#endif
         DIAG_STAMP_W(8, 12);   // helper: verdict posted
     }
     // (7) movers: the envs they parked are finished by the lane that holds their state, as soon as the verdicts are in
     //     (every parked pose has been claimed by now -- by this wave or by one that is working on it)
     if (mover && __ballot(park)) {
         int verdict = park ? 0 : 1;
-        while (__ballot(verdict == 0)) {
-            if (verdict == 0) verdict = __hip_atomic_load(&my_rec->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __builtin_amdgcn_s_sleep(1);
+        {
+            int trips = 0;
+            while (__ballot(verdict == 0)) {
+                if (verdict == 0) verdict = __hip_atomic_load(&my_rec->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_s_sleep(1);
+                if (++trips > kPollLimit) {   // (a verdict that never comes: the env is finished as free, and the step says so)
+                    poll_expired = true;
+                    if (verdict == 0) {
+                        verdict = 1;
+                        q.err |= BCP_ERR_INTERNAL;
+                    }
+                    break;
+                }
+            }
         }
         // A pose that really collides is rolled back, and the reward provider runs for the OLD pose: the scan for its last
         // reached way point by the whole wave, a candidate per lane (one lane walking the window alone took ~5 k cycles, and
@@ -1872,6 +2015,12 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
                 sc.target = q.target;
                 sc.rew = reward_from_last(P, lds_path, my_len, last_hit, q.old.x, q.old.y, sc.min_dist, sc.target);
             }
+            if (!PLAIN) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) q.popped_pose[k] = fifo_stash[k * kLocalEnvs];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) q.popped_state[k] = fifo_stash[(3 + k) * kLocalEnvs];
+            }
             finalize_env_from<PLAIN>(a, SL, i, q, verdict == 2, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len, fits, ahead);
         }
     }
@@ -1880,6 +2029,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
 #ifdef BCP_DIAG
     if (tid == 0 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 16 + 15] = (unsigned long long)n_parked;
 #endif
+    if (poll_expired && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 4), 1ull);   // (bcp_expired_waits)
     if ((a.flags & kStepAdvances) && tid == (kLocalWaves - 1) * kBlock) {   // the last workgroup to get here moves the step counter on
         unsigned int* ticket = reinterpret_cast<unsigned int*>(a.tick + 3);
         if (atomicAdd(ticket, 1u) == gridDim.x - 1) {

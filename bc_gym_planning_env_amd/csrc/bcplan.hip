@@ -6,6 +6,7 @@
 // bcp_device.h, bcp_raster.h, bcp_coop.h), the egocentric observation in bcp_ego.h.
 // Compiled with -ffp-contract=off (numpy rounds every product and sum separately).  No CPU path exists here.
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 #include <cmath>
 #include <cstdarg>
@@ -54,7 +55,7 @@ struct bcp_handle {
     int device;
     int64_t env_id_base;
     uint64_t seed;
-    uint64_t* tick;           // owned, device: step counter (two views), noise seed, ticket -- see StepArgs::tick
+    uint64_t* tick;           // owned, device: step counter (two views), noise seed, ticket -- see StepArgs::tick; [4]: waits that gave up
     bool have_map, have_path, have_state, have_init;
     double resolution;
     uint32_t* bitmap;      // owned
@@ -106,7 +107,6 @@ struct bcp_handle {
     int32_t edt_in_lds;       // distance transform of maps that fit: the LDS-resident kernel (BCP_TUNE_EDT_LDS)
     int32_t last_step_form;   // 0 none yet, 1 single-kernel step, 2 two-kernel step (parking counters in use)
     int32_t fused;            // settle parked poses inside the step launch (step_local_kernel) instead of a second launch
-    int32_t local_lds_set[4]; // step_local_kernel variant has been given its dynamic LDS size (-> that size)
 };
 
 // number of entries of a non-shared map / path / initial-state array
@@ -929,7 +929,7 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->fused = 1;
     h->static_dirty = true;
     fill_dev_params(h);
-    if (hipMalloc((void**)&h->tick, 4 * sizeof(uint64_t)) != hipSuccess || hipMemset(h->tick, 0, 4 * sizeof(uint64_t)) != hipSuccess) {
+    if (hipMalloc((void**)&h->tick, 8 * sizeof(uint64_t)) != hipSuccess || hipMemset(h->tick, 0, 8 * sizeof(uint64_t)) != hipSuccess) {
         if (h->tick) (void)hipFree(h->tick);
         delete h;
         return fail(BCP_E_HIP, "bcp_create: cannot allocate device memory");
@@ -1482,10 +1482,19 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
                                       : (const void*)step_local_kernel<false, false>;
         const int64_t bitmap_words = (int64_t)S.map.rows * S.map.wpr;
         const size_t lds = local_step_lds_bytes(h->params.n_verts, S.lds_path_doubles,
-                                                (S.map.shared && bitmap_words <= kLocalMapWords) ? (int)bitmap_words : 0);
-        if (h->local_lds_set[variant] != (int32_t)lds) {
-            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            h->local_lds_set[variant] = (int32_t)lds;
+                                                (S.map.shared && bitmap_words <= kLocalMapWords) ? (int)bitmap_words : 0,
+                                                step_is_plain(h));
+        // The attribute belongs to the FUNCTION on a device, not to a handle: the largest size any handle of this process
+        // has asked for stays set (two live handles with different staging sizes would otherwise lower it under each other).
+        {
+            static std::mutex lds_mutex;
+            static int32_t lds_max[64][4];   // [device][variant], zero-initialised
+            std::lock_guard<std::mutex> lock(lds_mutex);
+            int32_t& cur = lds_max[h->device & 63][variant];
+            if ((int32_t)lds > cur) {
+                HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                cur = (int32_t)lds;
+            }
         }
         a.flags |= kStepAdvances;
         const dim3 grid((unsigned)((h->n + kLocalEnvs - 1) / kLocalEnvs)), block(kLocalWaves * kBlock);
@@ -1536,7 +1545,7 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
 // exist only in a -DBCP_DIAG build (tools/); kStepAdvances is internal and never accepted.
 #ifdef BCP_DIAG
 constexpr uint32_t kCallerFlags = BCP_STEP_AUTO_RESET | BCP_STEP_ACTIONS_F32 | kAblateNoCollision | kAblateNoReward |
-                                  kAblateNoCoop | kAblateNoPark | kAblateNoClassify;
+                                  kAblateNoCoop | kAblateNoPark | kAblateNoClassify | kDiagWithholdVerdicts;
 #else
 constexpr uint32_t kCallerFlags = BCP_STEP_AUTO_RESET | BCP_STEP_ACTIONS_F32;
 #endif
@@ -1561,6 +1570,17 @@ extern "C" int bcp_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, vo
     rc = launch_step(h, io, flags, (hipStream_t)stream);
     if (rc != BCP_OK) return rc;
     HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+extern "C" int bcp_expired_waits(bcp_handle* h, int64_t* count, void* stream)
+{
+    if (!h || !count) return fail(BCP_E_INVALID, "bcp_expired_waits: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    uint64_t v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, h->tick + 4, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    *count = (int64_t)v;
     return BCP_OK;
 }
 
@@ -1632,6 +1652,11 @@ extern "C" int bcp_time_step_kernels(bcp_handle* h, const bcp_step_io* io, uint3
     float full = 0, first = 0;
     rc = time_loop(h, io, flags, steps, s, false, &full);
     if (rc != BCP_OK) return rc;
+    if (bcp_step_form(h) != 2) {   // the step is ONE launch (step_local_kernel, step_kernel): nothing to split, and no second loop
+        kernel_ms[0] = full;
+        kernel_ms[1] = 0.0f;
+        return BCP_OK;
+    }
     rc = time_loop(h, io, flags, steps, s, true, &first);
     if (rc != BCP_OK) return rc;
     kernel_ms[0] = first;

@@ -56,7 +56,9 @@ enum {
 /* per-env error bits written to bcp_step_io.err (mirror of the reference's Python exceptions) */
 enum {
     BCP_ERR_ANGLE_JUMP = 1, /* path_velocity raises when |dtheta| >= pi, utilities/path_tools.py:319-322 */
-    BCP_ERR_TIME_ORDER = 2  /* path_velocity's `assert (dt > 0).all()`, utilities/path_tools.py:307 (bcp_path_velocity only) */
+    BCP_ERR_TIME_ORDER = 2, /* path_velocity's `assert (dt > 0).all()`, utilities/path_tools.py:307 (bcp_path_velocity only) */
+    BCP_ERR_INTERNAL = 4    /* no counterpart in the reference: a wait inside the step kernel ran into its iteration limit (a hand-off
+                               between wavefronts never arrived); the step finished, its results for this workgroup are unreliable */
 };
 
 /* bcp_step flags */
@@ -350,6 +352,14 @@ int bcp_refresh_mini_worlds(bcp_handle *h, const bcp_mini_world_params *p /*host
 int bcp_release_mini_worlds(bcp_handle *h, void *stream);
 
 /* ---- the on-device noise stream (introspection) --------------------------------------------------------------- */
+/* Health of the step kernel's internal hand-offs.  The single-launch step passes undecided poses between the wavefronts of a
+ * workgroup through LDS; every wait on such a hand-off is bounded (~10^7 cycles against the ~2 * 10^4 a step lasts).  A
+ * wait that runs into its limit gives up -- the step still finishes; an env whose verdict never arrived is finished as
+ * "free" with BCP_ERR_INTERNAL in `err` -- and is counted here.  *count = waits that gave up since bcp_create (host
+ * pointer; the call synchronises `stream`).  Anything but 0 means a defect of the library, never of the caller's data.
+ * No counterpart in the reference. */
+int bcp_expired_waits(bcp_handle *h, int64_t *count, void *stream);
+
 /* The standard normals a step draws when bcp_step_io.noise_z is NULL (the stand-in for np.random.normal of
  * robot_models/differential_drive.py:43-52): out double [n_steps][n_envs][3] = the three slots of envs first_env ..
  * first_env + n_envs - 1 of this handle at step counters first_step .. first_step + n_steps - 1, for the handle's seed
@@ -367,11 +377,11 @@ int bcp_step_form(bcp_handle *h);
  * returns the average kernel-launch duration in milliseconds (synchronises).  Used by bench.py for
  * roofline.achieved. */
 int bcp_time_steps(bcp_handle *h, const bcp_step_io *io, uint32_t flags, int32_t steps, void *stream, float *avg_ms);
-/* Per-kernel split of a step: kernel_ms[0] = average duration of kernel 1 (a loop of launches of kernel 1 alone
- * between two events), kernel_ms[1] = average full step minus kernel_ms[0], i.e. kernel 2 (step_pending_kernel) plus the
- * launch boundary (0 when the step runs as a single kernel).  Advances the envs by `steps` steps.  Coarse: the
- * kernel-1-only loop re-parks the same poses without settling them; profiles/ (rocprofv3 kernel trace) is the
- * reference for per-kernel durations. */
+/* Per-kernel split of a step.  Single-launch forms (bcp_step_form 0, 1, 3 -- the default is 3): kernel_ms[0] = the average
+ * step, kernel_ms[1] = 0; the envs advance by `steps` steps.  Two-launch form (2): kernel_ms[0] = average duration of
+ * kernel 1 (a second loop of `steps` launches of kernel 1 alone), kernel_ms[1] = average full step minus kernel_ms[0], i.e.
+ * step_pending_kernel plus the launch boundary.  Coarse: the kernel-1-only loop re-parks the same poses without settling
+ * them; profiles/ (rocprofv3 kernel trace) is the reference for per-kernel durations. */
 int bcp_time_step_kernels(bcp_handle *h, const bcp_step_io *io, uint32_t flags, int32_t steps, void *stream,
                           float *kernel_ms);
 

@@ -8,6 +8,8 @@ import pytest
 
 from util import GOLDEN
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 E_INVALID, E_STATE = -1, -4
@@ -108,3 +110,22 @@ def test_python_layer_raises_like_the_reference(torch_cuda):
         env.step(np.zeros((3, 2), dtype=np.float32))
     with pytest.raises(NotImplementedError):
         env.render()
+
+
+def test_a_wait_that_never_ends_gives_up(torch_cuda, launcher, tmp_path):
+    """The hand-offs inside step_local_kernel are waits on LDS words; every one of them is bounded.  A -DBCP_DIAG build
+    (compiled here, on the box) can withhold the verdicts of the parked poses: the movers' waits then run into their
+    limit, the step RETURNS (milliseconds, not a wedged GPU), the envs concerned are finished as free with
+    BCP_ERR_INTERNAL, bcp_expired_waits counts the waits and check_errors() raises."""
+    import json
+    import sys
+    from bc_gym_planning_env_amd import build
+    lib = str(tmp_path / "libbcplan_diag.so")
+    r = launcher.run([build.hipcc()] + build.FLAGS + ["-DBCP_DIAG", build.SRC, "-o", lib], timeout=400, cwd=ROOT)
+    assert r["rc"] == 0, r["err"][-3000:]
+    r = launcher.run([sys.executable, os.path.join(ROOT, "tests", "ranks", "withheld_verdicts.py"), lib], timeout=300, cwd=ROOT)
+    assert r["rc"] == 0, r["err"][-3000:]
+    got = json.loads([x for x in r["out"].splitlines() if x.startswith("{")][-1])
+    assert got["rc"] == 0 and got["seconds"] < 5.0
+    assert got["expired_before"] == 0 and got["expired_after"] > 0
+    assert got["envs_flagged"] > 0 and got["flagged_collided_now"] == 0 and got["check_errors_raised"]

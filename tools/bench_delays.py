@@ -1,5 +1,6 @@
-"""Step rate of the C3 geometry (65 536 envs, shared map) with delay queues and with the pure-pursuit reward provider --
-the configurations that run through the general single-kernel step."""
+"""Step rate of the C3 geometry (65 536 envs, shared map) with delay queues and with the pure-pursuit reward provider
+(step_local_kernel<*, PLAIN = false>), against the plain configuration and the general single-kernel step.
+The time of a step is measured as bench.py does it: a pool of 8 action batches, python loop, HIP events."""
 import os
 import sys
 
@@ -12,7 +13,7 @@ from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams  # noqa
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "g8_traj_mini_00.npz"))
 res = float(g["resolution"])
-for tag, kw in (("no delays, continuous reward (two-kernel step)", dict()),
+for tag, kw in (("no delays, continuous reward", dict()),
                 ("pose_delay 1, state_delay 1 (the runner scripts)", dict(pose_delay=1, state_delay=1)),
                 ("control 2, pose 1, state 3", dict(control_delay=2, pose_delay=1, state_delay=3)),
                 ("pure pursuit", dict(reward_provider_name="continuous_reward_pure_pursuit")),
@@ -28,6 +29,15 @@ for tag, kw in (("no delays, continuous reward (two-kernel step)", dict()),
     for k in range(1200):
         env.step(pool[k % 8])
     torch.cuda.synchronize()
-    ms = min(env.time_steps(pool[i % 8], 100) for i in range(3))
-    print("%-52s %.4f ms/step  %.3e env-steps/s" % (tag, ms, n / ms * 1e3), flush=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for rep in range(3):
+        e0.record()
+        for k in range(400):
+            env.step(pool[k % 8])
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 400)
+    env.check_errors()
+    print("%-52s %.4f ms/step  %.3e env-steps/s  (%s)" % (tag, best, n / best * 1e3, env.step_kernels()), flush=True)
     del env

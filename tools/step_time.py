@@ -16,5 +16,5 @@ if os.environ.get("BCP_FUSED") is not None:
     env.set_tuning(fused=int(os.environ["BCP_FUSED"]))
 ms = [env.time_steps(pool[0], 200) for _ in range(5)]
 k = env.time_step_kernels(pool[0], 200)
-print("%s n=%d: ms/step %s  min %.5f  (kernel-1-only loop %.5f, rest %.5f)  form: %s" % (
+print("%s n=%d: ms/step %s  min %.5f  (bcp_time_step_kernels: %.5f + %.5f)  form: %s" % (
     os.path.basename(_lib.LIB_PATH), n, " ".join("%.5f" % m for m in ms), min(ms), k[0], k[1], env.step_kernels()), flush=True)
