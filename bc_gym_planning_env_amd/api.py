@@ -47,10 +47,6 @@ class Action(object):
     """A motion primitive: command = (wheel_v, wheel_angle) for the tricycle, (v, w) for diff-drive."""
     command = attr.ib(type=np.ndarray)
 
-    @classmethod
-    def from_cmds(cls, wanted_linear_velocity_of_baselink, wanted_front_wheel_angle):
-        return cls(command=np.array([wanted_linear_velocity_of_baselink, wanted_front_wheel_angle]))
-
     def __eq__(self, other):
         return isinstance(other, Action) and not (self.command != other.command).any()
 
@@ -168,9 +164,6 @@ class TricycleRobotState(Serializable):
 
     def egocentric_state_numpy_array(self):
         return np.array([self.v, self.w, self.wheel_angle], dtype=np.float64)
-
-    def old_style(self):
-        return [self.wheel_angle, self.v, self.w, self.steering_motor_command]
 
     def get_robot_type_name(self):
         return self.robot_type_name

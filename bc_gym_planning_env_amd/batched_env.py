@@ -565,11 +565,12 @@ class BatchedPlanEnv(object):
             env.envs[i].set_state(State.deserialize(r['state']))
         return env
 
-    def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None, defer=None, edt_lds=None, fused=None):
+    def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None, defer=None, edt_lds=None, fused=None,
+                   ego_sparse=None):
         """Execution knobs of libbcplan (bcp_set_tuning); results never depend on them."""
         for key, val in ((_lib.TUNE_EXACT_MODE, exact_mode), (_lib.TUNE_DENSE_THRESHOLD, dense_threshold),
                          (_lib.TUNE_CULL, cull), (_lib.TUNE_DEFER, defer), (_lib.TUNE_EDT_LDS, edt_lds),
-                         (_lib.TUNE_FUSED, fused)):
+                         (_lib.TUNE_FUSED, fused), (_lib.TUNE_EGO_SPARSE, ego_sparse)):
             if val is not None:
                 _lib.check(self._lib.bcp_set_tuning(self._h, key, int(val)))
 
@@ -720,7 +721,6 @@ class BatchedPlanEnv(object):
         io = _lib.BcpStepIO()
         io.actions = a.data_ptr()
         flags = (_lib.STEP_ACTIONS_F32 if a.dtype == torch.float32 else 0) | (_lib.STEP_AUTO_RESET if self.auto_reset else 0)
-        flags |= getattr(self, "_debug_flags", 0)   # ablation switches of tools/ablate.py (timing experiments only)
         if noise_z is not None:
             io.noise_z = noise_z.data_ptr()
         io.reward, io.done = self.reward.data_ptr(), self.done.data_ptr()

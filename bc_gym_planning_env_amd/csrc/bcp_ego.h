@@ -731,6 +731,159 @@ __global__ void __launch_bounds__(256) ego_costmap_window_kernel(const EgoArgs a
     }
 }
 
+// ---- sparse costmaps: fill + patch ---------------------------------------------------------------------------------------
+// The costmaps this path meets are nearly empty (RandomMiniEnv: two walls one cell thick, ~120 cells of 33 489 non-zero) and
+// the border value of extract_egocentric_costmap is 0 (costmap_utils.py:27): an egocentric image is then ZEROS plus the few
+// pixels whose source cell is not.  INTER_NEAREST is an exact inverse map, so instead of asking every destination pixel for
+// its source cell (15 561 fixed-point evaluations and LDS reads per image, issue-bound at 46 % of the HBM write rate)
+//   1. the image is filled with zeros in 16-byte stores -- a plain memset, all the HBM traffic there is;
+//   2. every non-zero source cell (X, Y) is mapped FORWARD to the image with the inverse of the dst -> src matrix, and the
+//      3 x 3 pixels around that position are tested with cv::warpAffine's own 22.10 formula: a pixel whose source cell is
+//      (X, Y) gets the cell's value.  A rotation has scale 1: the pixels whose source coordinate rounds to (X, Y) lie within
+//      0.5 (|cos| + |sin|) + 2^-9 <= 0.71 px of the forward image of the cell centre in each axis, hence within the 3 x 3
+//      block around its rounding -- the test is exact, the neighbourhood only has to contain the candidates.
+// ~120 cells x 9 candidates = ~1 100 evaluations per image instead of 15 561.  Lists of the non-zero cells are built per map
+// entry (ego_cells_kernel); an entry with more than `cap` of them is drawn pixel by pixel (ego_image_slow), and the host
+// routes whole calls whose maps are dense -- or whose border value is not 0 -- to the sampling kernels above.
+constexpr int kEgoCellCap = 512;   // cells per map entry a list holds (a RandomMiniEnv world: <= 2 x 183)
+
+// list[entry][k] = value << 24 | row << 12 | column of the k-th non-zero cell inside the entry's valid region (any order);
+// counts[entry] = how many there are (may exceed `cap`: the list then holds the first `cap` found); *max_count = running
+// maximum over the entries built so far.  One workgroup per entry.
+__global__ void __launch_bounds__(256) ego_cells_kernel(const uint8_t* __restrict__ data, EntrySelect sel, int rows, int cols,
+                                                        const int32_t* __restrict__ valid_rows,
+                                                        const int32_t* __restrict__ valid_cols, int cap,
+                                                        uint32_t* __restrict__ cells, int32_t* __restrict__ counts,
+                                                        int32_t* __restrict__ max_count)
+{
+    __shared__ int n_found;
+    const int64_t total = sel.size();
+    for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {
+        const int64_t m = sel.entry(it);
+        const int vr = valid_rows ? valid_rows[m] : rows, vc = valid_cols ? valid_cols[m] : cols;
+        if (threadIdx.x == 0) n_found = 0;
+        __syncthreads();
+        const uint8_t* src = data + m * (int64_t)rows * cols;
+        const int cells_total = rows * cols;
+        for (int base = 4 * (int)threadIdx.x; base < cells_total; base += 4 * 256) {
+            uint32_t four = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (base + j < cells_total) four |= (uint32_t)src[base + j] << (8 * j);
+            if (four == 0) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t v = (four >> (8 * j)) & 255u;
+                if (v == 0) continue;
+                const int idx = base + j, r = idx / cols, c = idx - r * cols;
+                if (r >= vr || c >= vc) continue;
+                const int at = atomicAdd(&n_found, 1);
+                if (at < cap) cells[m * cap + at] = (v << 24) | ((uint32_t)r << 12) | (uint32_t)c;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            counts[m] = n_found;
+            atomicMax(max_count, n_found);
+        }
+        __syncthreads();
+    }
+}
+
+// one image, pixel by pixel from global memory (entries whose list overflowed: rare, correctness only)
+__device__ __forceinline__ void ego_image_slow(const EgoArgs& a, const EgoImage& I, const uint8_t* __restrict__ src,
+                                               uint8_t* __restrict__ image, int lane)
+{
+    const int P = a.drows * a.dcols;
+    for (int p = lane; p < P; p += 64) {
+        const int y = p / a.dcols, x = p - y * a.dcols;
+        const int X = (sat_int((I.m1 * y + I.m2) * 1024) + 512 + sat_int(I.m0 * x * 1024)) >> 10;
+        const int Y = (sat_int((I.m4 * y + I.m5) * 1024) + 512 + sat_int(I.m3 * x * 1024)) >> 10;
+        uint8_t v = (uint8_t)a.border;
+        if ((unsigned)X < (unsigned)I.vc && (unsigned)Y < (unsigned)I.vr) v = src[(int64_t)Y * a.cols + X];
+        image[p] = v;
+    }
+}
+
+typedef uint32_t EgoU32x4 __attribute__((ext_vector_type(4)));
+
+// One wavefront per image (border value 0, cell lists built): zero fill, then the patches.  No LDS.
+__global__ void __launch_bounds__(64 * kEgoWaves) ego_sparse_kernel(const EgoArgs a, const uint32_t* __restrict__ cells,
+                                                                     const int32_t* __restrict__ counts, int cap)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const int64_t P = (int64_t)a.drows * a.dcols;
+    const int64_t first = (int64_t)blockIdx.x * waves + wave, stride = (int64_t)gridDim.x * waves;
+    for (int64_t base = first; base < a.n_images; base += 64 * stride) {
+        EgoXform T;
+        memset(&T, 0, sizeof(T));
+        const int64_t mine = base + lane * stride;   // lane l: transform of the wave's l-th image of this batch
+        if (mine < a.n_images) T = ego_transform(a, mine);
+        const int64_t left = (a.n_images - base + stride - 1) / stride;
+        const int count = (int)(left < 64 ? left : 64);
+        for (int k = 0; k < count; ++k) {            // the wave's images, one at a time
+            const int64_t img = base + k * stride;
+            const EgoImage I = ego_broadcast(T, k);
+            uint8_t* const image = a.out + img * P;
+            const int n_cells = counts[I.g];
+            if (n_cells > cap) {
+                ego_image_slow(a, I, a.data + I.g * a.map_stride, image, lane);
+                continue;
+            }
+            // ---- 1. zeros: bytes up to the first 16-byte boundary, aligned 16-byte stores, the tail
+            {
+                const int head = (int)((16u - (uint32_t)(uintptr_t)image) & 15u);
+                const int64_t body = (P - head) >> 4;           // whole 16-byte pieces
+                const int tail = (int)(P - head - (body << 4));
+                if (lane < head) image[lane] = 0;
+                EgoU32x4* const q = reinterpret_cast<EgoU32x4*>(image + head);
+                const EgoU32x4 zero = {0u, 0u, 0u, 0u};
+                for (int64_t c = lane; c < body; c += 64) q[c] = zero;   // (non-temporal stores: 7 % slower)
+                if (lane < tail) image[head + (body << 4) + lane] = 0;
+            }
+            if (n_cells == 0) continue;
+            // (the patches below must land after the zeros: same wave, same addresses -- wait for the fill to be done.
+            //  Measured alternatives, both slower than this plain form (0.203 ms per 65 536 images): all the fills of a
+            //  batch of 64 images first, one wait, then all the patches 0.32 ms -- the waves then fill and patch in step
+            //  and stores never overlap arithmetic --; a two-stage pipeline with s_waitcnt vmcnt(16) 0.27 ms.)
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            // ---- 2. forward map of the source cells: the inverse of the (dst -> src) matrix
+            const double det = I.m0 * I.m4 - I.m1 * I.m3;
+            const double id = det != 0.0 ? 1.0 / det : 0.0;
+            const double f0 = I.m4 * id, f1 = -I.m1 * id, f3 = -I.m3 * id, f4 = I.m0 * id;
+            const double f2 = -(f0 * I.m2 + f1 * I.m5), f5 = -(f3 * I.m2 + f4 * I.m5);
+            const uint32_t* const list = cells + I.g * (int64_t)cap;
+            for (int c0 = 0; c0 < n_cells; c0 += 64) {
+                if (c0 + lane >= n_cells) continue;
+                const uint32_t cell = list[c0 + lane];
+                const int sx = (int)(cell & 0xFFFu), sy = (int)((cell >> 12) & 0xFFFu);
+                const uint8_t v = (uint8_t)(cell >> 24);
+                const double fx = f0 * sx + f1 * sy + f2, fy = f3 * sx + f4 * sy + f5;
+                if (!(fx > -2.0 && fx < (double)a.dcols + 1.0 && fy > -2.0 && fy < (double)a.drows + 1.0)) continue;
+                const int xc = (int)rint(fx), yc = (int)rint(fy);
+                int cx[3], cy[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {   // cv::hal::warpAffine's adelta / bdelta of the three candidate columns
+                    cx[j] = sat_int(I.m0 * (xc - 1 + j) * 1024);
+                    cy[j] = sat_int(I.m3 * (xc - 1 + j) * 1024);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int y = yc - 1 + r;
+                    if ((unsigned)y >= (unsigned)a.drows) continue;
+                    const int rx = sat_int((I.m1 * y + I.m2) * 1024) + 512, ry = sat_int((I.m4 * y + I.m5) * 1024) + 512;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int x = xc - 1 + j;
+                        if ((unsigned)x < (unsigned)a.dcols && ((rx + cx[j]) >> 10) == sx && ((ry + cy[j]) >> 10) == sy)
+                            image[(int64_t)y * a.dcols + x] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- grouping images by map entry: count -> exclusive scan -> scatter ------------------------------------------
 __global__ void ego_bin_count_kernel(const int32_t* __restrict__ geom_of_env, int64_t n_envs, int64_t n_images,
                                      int32_t* __restrict__ bin_count, int32_t* __restrict__ rank)

@@ -93,6 +93,14 @@ struct bcp_handle {
     int64_t ego_bins_cap;
     int32_t* ego_order;       // owned: [2][images] rank within the bin / images grouped by map entry
     int64_t ego_order_cap;
+    // sparse egocentric views (ego_sparse_kernel): per map entry the list of its non-zero cells
+    uint32_t* ego_cells;      // owned: [entries][kEgoCellCap]
+    int32_t* ego_cell_counts; // owned: [entries] + [1] running maximum
+    int64_t ego_cells_entries;
+    bool ego_cells_built;     // the lists describe the current maps (rebuilt entry by entry when a pool is refreshed)
+    bool ego_cells_refused;   // allocation failed once: the sampling kernels serve this handle
+    int32_t ego_cells_max;    // host copy of the maximum count, -1 = not fetched since the last (re)build
+    int32_t ego_sparse;       // BCP_TUNE_EGO_SPARSE
     const uint8_t* map_data;  // caller-owned raw costmap(s) as given to bcp_set_costmaps (egocentric views read them)
     const int32_t* map_valid_rows;
     const int32_t* map_valid_cols;
@@ -927,6 +935,8 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->cull_enabled = 1;
     h->defer = 1;
     h->fused = 1;
+    h->ego_sparse = 1;
+    h->ego_cells_max = -1;
     h->static_dirty = true;
     fill_dev_params(h);
     if (hipMalloc((void**)&h->tick, 8 * sizeof(uint64_t)) != hipSuccess || hipMemset(h->tick, 0, 8 * sizeof(uint64_t)) != hipSuccess) {
@@ -956,6 +966,8 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->dev_static) (void)hipFree(h->dev_static);
     if (h->ego_bins) (void)hipFree(h->ego_bins);
     if (h->ego_order) (void)hipFree(h->ego_order);
+    if (h->ego_cells) (void)hipFree(h->ego_cells);
+    if (h->ego_cell_counts) (void)hipFree(h->ego_cell_counts);
     if (h->ring) (void)hipFree(h->ring);
     delete h;
     return BCP_OK;
@@ -1015,6 +1027,9 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
         case BCP_TUNE_EDT_LDS:
             h->edt_in_lds = value ? 1 : 0;
             return BCP_OK;
+        case BCP_TUNE_EGO_SPARSE:
+            h->ego_sparse = value ? 1 : 0;
+            return BCP_OK;
         case BCP_TUNE_FUSED:
             h->fused = value ? 1 : 0;
             return BCP_OK;
@@ -1029,11 +1044,26 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
 
 // Derived map data (1-bit lethal mask, distance field) and path data (cos/sin columns, bounding boxes, bucket index)
 // of the selected entries; `max_entries` bounds sel.size() and only sizes the grids.
+static void launch_ego_cells(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
+{
+    const MapDesc& m = h->map;
+    hipLaunchKernelGGL(ego_cells_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(max_entries, 8192))), dim3(256), 0, s,
+                       h->map_data, sel, m.rows, m.cols, h->map_valid_rows, h->map_valid_cols, kEgoCellCap, h->ego_cells,
+                       h->ego_cell_counts, h->ego_cell_counts + h->ego_cells_entries);
+    h->ego_cells_max = -1;
+}
+
 static void launch_pack_bitmap(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
 {
     const MapDesc& m = h->map;
     hipLaunchKernelGGL(pack_bitmap_kernel, dim3(stride_grid(max_entries * m.rows * m.wpr, 256, sel.list != nullptr)), dim3(256), 0, s, h->map_data,
                        h->bitmap, sel, m.rows, m.cols, m.wpr, h->map_valid_rows, h->map_valid_cols);
+    // the cell lists of the sparse egocentric views follow the maps: all of them are rebuilt lazily after a re-bind
+    // (sel.list == nullptr), the re-sampled entries of a pool refresh right here, in stream order
+    if (h->ego_cells_built) {
+        if (sel.list) launch_ego_cells(h, sel, max_entries, s);
+        else h->ego_cells_built = false;
+    }
 }
 
 static void launch_near_tiles(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
@@ -1897,6 +1927,49 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
     cus = std::max(cus, 1);
     const dim3 block(256);
+    // Sparse maps and a zero border (extract_egocentric_costmap's default): zero fill + one patch per non-zero source cell
+    // (ego_sparse_kernel).  Decided per call from the lists of non-zero cells: they are built on the first such call after
+    // the maps were (re)bound -- one pass over the maps and one read-back of the largest count -- and kept up to date by the
+    // pool refresh.  Dense maps (any entry with more than kEgoCellCap non-zero cells) keep the sampling kernels below.
+    if (border_value == 0 && a.rows <= 4095 && a.cols <= 4095 && !h->ego_cells_refused && h->ego_sparse) {
+        const int64_t entries = a.shared ? 1 : n_slots(h);
+        if (h->ego_cells_entries != entries || !h->ego_cells) {
+            if (h->ego_cells) (void)hipFree(h->ego_cells);
+            if (h->ego_cell_counts) (void)hipFree(h->ego_cell_counts);
+            h->ego_cells = nullptr;
+            h->ego_cell_counts = nullptr;
+            h->ego_cells_built = false;
+            if (hipMalloc((void**)&h->ego_cells, (size_t)entries * kEgoCellCap * sizeof(uint32_t)) != hipSuccess ||
+                hipMalloc((void**)&h->ego_cell_counts, (size_t)(entries + 1) * sizeof(int32_t)) != hipSuccess) {
+                (void)hipGetLastError();
+                if (h->ego_cells) (void)hipFree(h->ego_cells);
+                h->ego_cells = nullptr;
+                h->ego_cell_counts = nullptr;
+                h->ego_cells_refused = true;   // (no room for the lists: not an error, the sampling kernels take over)
+            } else {
+                h->ego_cells_entries = entries;
+            }
+        }
+        if (h->ego_cells && !h->ego_cells_built) {
+            HIP_TRY(hipMemsetAsync(h->ego_cell_counts + entries, 0, sizeof(int32_t), st));
+            const EntrySelect all = {nullptr, nullptr, entries};
+            launch_ego_cells(h, all, entries, st);
+            h->ego_cells_built = true;
+        }
+        if (h->ego_cells && h->ego_cells_max < 0) {
+            HIP_TRY(hipMemcpyAsync(&h->ego_cells_max, h->ego_cell_counts + entries, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (h->ego_cells && h->ego_cells_max >= 0 && h->ego_cells_max <= kEgoCellCap) {
+            const dim3 wide(64 * kEgoWaves);
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ego_sparse_kernel, 64 * kEgoWaves, 0));
+            const dim3 grid((unsigned)std::min<int64_t>((n + kEgoWaves - 1) / kEgoWaves, (int64_t)std::max(per_cu, 1) * cus));
+            hipLaunchKernelGGL(ego_sparse_kernel, grid, wide, 0, st, a, h->ego_cells, h->ego_cell_counts, kEgoCellCap);
+            HIP_TRY(hipGetLastError());
+            return BCP_OK;
+        }
+    }
     if (!a.shared && map_bytes + 4 * row_bytes <= 150 * 1024 && n < ((int64_t)1 << 31)) {
         // private / pooled maps that fit LDS: group the images by map entry, then one workgroup per entry at a time
         const int64_t n_bins = n_slots(h);

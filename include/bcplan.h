@@ -159,9 +159,11 @@ int bcp_seed(bcp_handle *h, uint64_t seed);
  *   BCP_TUNE_EDT_LDS          0 = build distance fields with the two-pass global-memory kernels even where a map fits
  *                             into LDS (takes effect at the next bcp_set_costmaps)
  *   BCP_TUNE_FUSED            0 = settle the parked poses in a second launch (step_fast_pair_kernel + step_pending_kernel)
- *                             instead of inside the step launch itself (step_local_kernel, the default) */
+ *                             instead of inside the step launch itself (step_local_kernel, the default)
+ *   BCP_TUNE_EGO_SPARSE       0 = egocentric views always sample the costmap pixel by pixel; 1 (default) = sparse maps with
+ *                             border value 0 are drawn as a zero fill plus one patch per non-zero source cell */
 enum { BCP_TUNE_EXACT_MODE = 0, BCP_TUNE_DENSE_THRESHOLD = 1, BCP_TUNE_CULL = 2, BCP_TUNE_DEFER = 3, BCP_TUNE_EDT_LDS = 4,
-       BCP_TUNE_FUSED = 5 };
+       BCP_TUNE_FUSED = 5, BCP_TUNE_EGO_SPARSE = 6 };
 int bcp_set_tuning(bcp_handle *h, int32_t key, int32_t value);
 
 /* ---- static per-episode inputs ------------------------------------------------------------------------ */

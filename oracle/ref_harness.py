@@ -11,8 +11,8 @@ Everything else that then runs is the reference's own code.  Consequently golden
 `cv2.fillPoly` (get_pixel_footprint / pose_collides / full PlanEnv.step) pin the *rest* of the arithmetic exactly,
 while the fill itself stays pinned only by the reference's known-answer tests (see bcp_oracle.h header).
 
-Only oracle/gen_golden.py and the container-only tests (tests/test_oracle_vs_reference.py) use this module; they
-skip when /root/reference is absent.
+Only oracle/gen_golden.py uses this module (in the build container, where /root/reference exists); the committed
+fixtures under tests/golden/ are what travels.
 """
 import os
 import sys

@@ -185,3 +185,84 @@ def test_g12_colored_ego_observation(torch_cuda):
     vec = obs['goal'].cpu().numpy()
     assert vec.shape == (n, 5, 1) and vec.dtype == np.float64
     np.testing.assert_allclose(vec[:, :, 0], g["goal"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["shared", "private"])
+def test_sparse_maps_fill_and_patch_vs_oracle(torch_cuda, oracle, kind):
+    """Sparse costmaps with border value 0 take the fill-and-patch kernel (ego_sparse_kernel): a zero fill plus one patch
+    per non-zero source cell.  Random poses far in and out of the map, several windows, maps with thin walls, isolated
+    cells, cells on the map's edges and arbitrary non-zero values -- against the oracle, and against the sampling kernels
+    (BCP_TUNE_EGO_SPARSE = 0) bit for bit.  A map with more non-zero cells than a list holds routes the call to the
+    sampling kernels (same images)."""
+    torch = torch_cuda
+    import ctypes as C
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams, _lib
+    rng = np.random.RandomState(21)
+    n = 192
+    res = 0.05
+
+    def sparse_map(shape, cells):
+        m = np.zeros(shape, dtype=np.uint8)
+        m[rng.randint(0, shape[0], cells), rng.randint(0, shape[1], cells)] = rng.randint(1, 256, cells)
+        m[shape[0] // 3, 5:shape[1] - 5] = 254            # a wall one cell thick
+        m[7:shape[0] - 9, shape[1] // 2] = 254
+        m[0, 0] = m[-1, -1] = m[0, -1] = m[-1, 0] = 200    # the corners
+        m[0, 3:9] = 17                                     # on the edges
+        m[5:11, -1] = 18
+        return m
+
+    shapes = [(90, 70)] if kind == "shared" else [(90, 70), (64, 101), (183, 183)]
+    maps = [sparse_map(s, 60) for s in shapes]
+    orgs = [rng.uniform(-2, 0, 2) for _ in shapes]
+    path = np.array([[0., 0., 0.], [1., 0., 0.], [2., 0., 0.]])
+    params = EnvParams(resolution=res, refine_path=False)
+    if kind == "shared":
+        env = BatchedPlanEnv(CostMap2D(maps[0], res, orgs[0]), path, params, n_envs=n)
+    else:
+        env = BatchedPlanEnv([CostMap2D(maps[i % 3], res, orgs[i % 3]) for i in range(n)], [path] * n, params, n_envs=n)
+    poses = np.stack([rng.uniform(-3, 7, n), rng.uniform(-3, 7, n), rng.uniform(-7, 7, n)], axis=1)
+    poses[0] = (0., 0., 0.)
+    poses[1] = (1.0, 1.0, np.pi)
+    poses[2] = (2.0, 1.5, np.pi / 2)
+    poses[3] = (2.0, 1.5, np.pi / 4)
+    poses[4] = (1e4, -1e4, 0.3)      # nowhere near the map
+    pt = torch.from_numpy(poses).cuda()
+    f64p = C.POINTER(C.c_double)
+
+    def draw(o, s, border):
+        shape = (C.c_int32 * 2)()
+        _lib.check(env._lib.bcp_egocentric_shape(env._h, s.ctypes.data_as(f64p) if s is not None else None, shape))
+        out = torch.full((n, shape[0], shape[1]), 99, dtype=torch.uint8, device="cuda")
+        _lib.check(env._lib.bcp_egocentric_costmaps(env._h, pt.data_ptr(), n, o.ctypes.data_as(f64p) if o is not None else None,
+                                                    s.ctypes.data_as(f64p) if s is not None else None, border,
+                                                    out.data_ptr(), None))
+        return out.cpu().numpy()
+
+    nonzero = 0
+    for org, size in (((-0.5, -2.0), (3.5, 4.0)), ((-1.0, -1.0), (2.0, 2.0)), ((-3.0, -0.7), (6.05, 1.45)), ((-0.1, -0.15), (0.3, 0.25))):
+        o, s = np.array(org, dtype=np.float64), np.array(size, dtype=np.float64)
+        env.set_tuning(ego_sparse=1)
+        got = draw(o, s, 0)
+        env.set_tuning(ego_sparse=0)
+        sampled = draw(o, s, 0)
+        assert (got == sampled).all()
+        for i in range(n):
+            k = 0 if kind == "shared" else i % 3
+            ref = oracle.extract_egocentric(maps[k], orgs[k], res, poses[i], o, s, 0)
+            assert ref.shape == got[i].shape and (ref == got[i]).all(), (org, size, i, int((ref != got[i]).sum()))
+        nonzero += int((got != 0).sum())
+    assert nonzero > 2000
+    # a dense map: more non-zero cells than a list holds -> the sampling kernels, same answers
+    env.set_tuning(ego_sparse=1)
+    dense = rng.randint(0, 256, shapes[0]).astype(np.uint8)
+    if kind == "shared":
+        env2 = BatchedPlanEnv(CostMap2D(dense, res, orgs[0]), path, params, n_envs=n)
+        o, s = np.array((-0.5, -2.0)), np.array((3.5, 4.0))
+        shape = (C.c_int32 * 2)()
+        _lib.check(env2._lib.bcp_egocentric_shape(env2._h, s.ctypes.data_as(f64p), shape))
+        out = torch.zeros((n, shape[0], shape[1]), dtype=torch.uint8, device="cuda")
+        _lib.check(env2._lib.bcp_egocentric_costmaps(env2._h, pt.data_ptr(), n, o.ctypes.data_as(f64p), s.ctypes.data_as(f64p), 0,
+                                                     out.data_ptr(), None))
+        got = out.cpu().numpy()
+        for i in range(0, n, 7):
+            assert (oracle.extract_egocentric(dense, orgs[0], res, poses[i], o, s, 0) == got[i]).all()

@@ -96,7 +96,7 @@ def test_api_types_mirror_reference_semantics():
     assert p.reward_provider_params == RewardParams(1.0, np.pi / 2, 0.0)
     with pytest.raises(Exception):
         p.dt = 1.0  # frozen, like the reference
-    a = Action.from_cmds(0.3, -0.2)
+    a = Action(command=np.array([0.3, -0.2]))
     assert a == Action(command=np.array([0.3, -0.2])) and a != Action(command=np.array([0.3, 0.2]))
     cm = CostMap2D(np.zeros((4, 5), np.uint8), 0.03, np.array([1., 2.]))
     assert not cm.get_origin().flags.writeable and cm == cm.copy()

@@ -7,6 +7,8 @@ sys.path.insert(0, '.')
 from bc_gym_planning_env_amd import _lib
 _lib.LIB_PATH = os.path.join('tools', 'libbcplan_diag.so')   # -DBCP_DIAG build: the shipping library rejects these flags
 import bench
+sys.path.insert(0, 'tools')
+from diag_flags import time_steps_with_flags
 rng = np.random.RandomState(0)
 if "c4" in sys.argv[1:]:   # BASELINE configs[3] instead of the metric workload
     env = bench.make_c4_env(65536, 0)
@@ -26,6 +28,5 @@ st = env.get_state()
 for name, fl in [('full', 0), ('no_park', 1 << 21), ('no_classify', 1 << 22), ('no_collision', 1 << 16),
                  ('no_reward', 1 << 17), ('neither', 3 << 16), ('no_exact_test', 1 << 19)]:
     env.set_state(st)
-    env._debug_flags = fl
-    ms = [env.time_steps(pool[i % 16], 20) for i in range(5)]
+    ms = [time_steps_with_flags(env, pool[i % 16], 20, fl) for i in range(5)]
     print(name, ['%.4f' % m for m in ms], flush=True)

@@ -24,6 +24,8 @@ sys.path.insert(0, '.')
 from bc_gym_planning_env_amd import _lib
 _lib.LIB_PATH = os.path.join('tools', 'libbcplan_diag.so')
 import bench
+sys.path.insert(0, 'tools')
+from diag_flags import time_steps_with_flags
 n = 65536
 rng = np.random.RandomState(1234)
 if "pool" in sys.argv[1:]:   # one private world per env (tools/pmc_pool_run.py)
@@ -40,8 +42,7 @@ else:
 st = env.get_state()
 for name, fl in PHASES:
     env.set_state(st)
-    env._debug_flags = fl
     for k in range(40):
-        env.time_steps(pool[k % 16], 1)   # (the timing entry point: the one that passes the ablation flags on)
+        time_steps_with_flags(env, pool[k % 16], 1, fl)   # (the library's timing loop: it takes the ablation flags)
     torch.cuda.synchronize()
 print("done")

@@ -1,5 +1,7 @@
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
+from diag_flags import time_steps_with_flags
 from bc_gym_planning_env_amd import mini_env
 n = 65536
 pool = mini_env.sample_pool(None, list(range(1024)), 4)
@@ -14,6 +16,5 @@ st = env.get_state()
 print("ambiguous/park stats: collided_now mean %.5f" % float(env.collided_now.float().mean()))
 for name, fl in [('full', 0), ('no_park', 1 << 21), ('no_classify', 1 << 22), ('no_collision', 1 << 16), ('no_reward', 1 << 17), ('neither', 3 << 16)]:
     env.set_state(st)
-    env._debug_flags = fl
-    ms = [env.time_steps(acts[i % 8], 20) for i in range(4)]
+    ms = [time_steps_with_flags(env, acts[i % 8], 20, fl) for i in range(4)]
     print(name, ['%.4f' % m for m in ms], flush=True)
