@@ -34,6 +34,8 @@ struct MapDesc {
 
 struct PathDesc {
     const double* pts;   // [len][5] = x, y, theta, cos(theta), sin(theta); shared or [N][max_len][5]
+    const float* pre;    // private paths: [N][max_len][4] = x, y, cos(theta), sin(theta) in float32 -- the prefilter record of
+                         // the way-point scan (16 bytes: four way points per 64-byte sector); nullptr for a shared path
     const double* bbox;  // [kBoxDoubles] per path: xmin, xmax, ymin, ymax of the way points, the bucket grid x0, 1/wx, y0,
                          // 1/wy, then (private paths) the costmap origin and the path length of the entry -- see kBoxOrigin
     const int16_t* index; // [2 axes][kPathBuckets][2] = first / last way point index that can be reached from a bucket
@@ -74,6 +76,7 @@ struct StepHot {
     int64_t env_id_base;
     int32_t* geom_of_env;
     const double* path_pts;
+    const float* path_pre;
     const double* path_bbox;
     const int16_t* path_index;
     const uint32_t* map_bits;
@@ -91,7 +94,7 @@ struct StepHot {
     struct Pending* pending;
 };
 constexpr int kHotStateWords = 11 * 2;                                   // x .. collided
-constexpr int kHotPrologueWords = (9 * 8 + 17 * 4) / 4;                 // n .. pending_cap
+constexpr int kHotPrologueWords = (10 * 8 + 17 * 4) / 4;                // n .. pending_cap
 static_assert(offsetof(DevState, collided) == 10 * 8 && offsetof(StepHot, st) == 0, "x .. collided lead DevState");
 static_assert(offsetof(StepHot, pending_cap) + 4 - offsetof(StepHot, n) == kHotPrologueWords * 4, "the prologue block of StepHot");
 
@@ -212,7 +215,8 @@ __global__ void pack_bitmap_kernel(const uint8_t* __restrict__ data, uint32_t* _
 }
 
 // path [.,3] -> [.,5] with cos/sin of the heading (utilities/path_tools.py:405)
-__global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restrict__ out, EntrySelect sel, int max_len)
+__global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restrict__ out, float* __restrict__ pre,
+                                 EntrySelect sel, int max_len)
 {
     const int64_t total = sel.size() * max_len;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
@@ -221,8 +225,15 @@ __global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restr
         out[5 * i + 0] = xyt[3 * i + 0];
         out[5 * i + 1] = xyt[3 * i + 1];
         out[5 * i + 2] = th;
-        out[5 * i + 3] = cos(th);
-        out[5 * i + 4] = sin(th);
+        const double c = cos(th), sn = sin(th);
+        out[5 * i + 3] = c;
+        out[5 * i + 4] = sn;
+        if (pre) {   // (private paths: the float32 prefilter record, last_reached_prefiltered)
+            pre[4 * i + 0] = (float)xyt[3 * i + 0];
+            pre[4 * i + 1] = (float)xyt[3 * i + 1];
+            pre[4 * i + 2] = (float)c;
+            pre[4 * i + 3] = (float)sn;
+        }
     }
 }
 
@@ -416,6 +427,41 @@ __device__ __forceinline__ int coop_last_reached(const DevParams& P, LdsF64 path
         }
         const uint64_t mask = __ballot(ok);
         if (mask) return top - ((int)__ffsll((unsigned long long)mask) - 1);
+    }
+    return -1;
+}
+
+// way points in global memory with the float32 prefilter record of private paths (PathDesc::pre: x, y, cos, sin, 16 bytes):
+// four candidates per trip cost four 16-byte loads out of one or two 64-byte sectors instead of twenty 8-byte loads out
+// of three, and float32 arithmetic; only a candidate the prefilter cannot rule out fetches its float64 record for the
+// exact test.  The prefilter rejects on position and on the "not behind the way point" condition with a guard `g` that
+// covers everything float32 can get wrong on coordinates up to `reach` in magnitude (conversion of both points 2^-24
+// relative each, the difference, two products and a sum: < 5e-7 (reach + sp); g = 2e-6 (reach + 1)), so whatever it
+// rejects fails the float64 test too -- the result is the exact scan's, bit for bit.
+__device__ __forceinline__ int last_reached_prefiltered(const DevParams& P, const double* __restrict__ path,
+                                                        const float* __restrict__ pre, PathWindow w, int m, int target,
+                                                        double x, double y, double th, double reach)
+{
+    if (target > m - 1) return -1;
+    const int lo = max(w.lo, target);
+    const int hi = min(w.hi, m - 1);
+    const float g = 2e-6f * ((float)reach + 1.0f);
+    const float xf = (float)x, yf = (float)y, spg = (float)P.sp + g, par_min = (float)P.par_thr - g;
+    const float q_max = spg * spg * 1.000001f;
+    for (int j = hi; j >= lo; j -= 4) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = as_global(reinterpret_cast<const f32x4*>(pre))[max(j - u, lo)];   // (below lo: a repeat of lo)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j - u < lo) break;
+            const float dx = p[u].x - xf, dy = p[u].y - yf;
+            const float par = p[u].z * (xf - p[u].x) + p[u].w * (yf - p[u].y);
+            if (fabsf(dx) > spg || fabsf(dy) > spg || dx * dx + dy * dy > q_max || par < par_min) continue;
+            const double* s = path + 5 * (j - u);
+            if (way_point_reached(P, s[0], s[1], s[2], s[3], s[4], x, y, th)) return j - u;
+        }
     }
     return -1;
 }
@@ -1807,7 +1853,14 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
                 PathWindow part;
                 part.hi = hi - member * third;
                 part.lo = max(lo, part.hi - third + 1);
-                last = last_reached_from(P, gpath, part, m, q.target, x, y, th);
+                if (a.hot.path_pre) {
+                    // (private paths: float32 prefilter records; `reach` = largest coordinate magnitude of this path's box)
+                    const double reach = fmax(fmax(fabs(box[0]), fabs(box[1])), fmax(fabs(box[2]), fabs(box[3]))) + P.sp;
+                    last = last_reached_prefiltered(P, gpath, a.hot.path_pre + g * (int64_t)a.hot.path_max_len * 4, part, m,
+                                                    q.target, x, y, th, reach);
+                } else {
+                    last = last_reached_from(P, gpath, part, m, q.target, x, y, th);
+                }
             }
             ((__attribute__((address_space(3))) int32_t*)hand_score)[member * kBlock + lane] = last;
             DIAG_STAMP_U(8, 7);     // helper 1 of pair 0: scanned

@@ -62,6 +62,8 @@ struct bcp_handle {
     size_t bitmap_bytes;
     double* path5;         // owned
     size_t path5_bytes;
+    float* path_pre;       // owned: [paths][max_len][4] float32 {x, y, cos, sin}: the prefilter record of private paths
+    size_t path_pre_bytes;
     double* path_bbox;     // owned
     size_t path_bbox_bytes;
     int16_t* path_index;   // owned
@@ -954,6 +956,7 @@ extern "C" int bcp_destroy(bcp_handle* h)
     (void)hipSetDevice(h->device);
     if (h->bitmap) (void)hipFree(h->bitmap);
     if (h->path5) (void)hipFree(h->path5);
+    if (h->path_pre) (void)hipFree(h->path_pre);
     if (h->path_bbox) (void)hipFree(h->path_bbox);
     if (h->path_index) (void)hipFree(h->path_index);
     if (h->edt) (void)hipFree(h->edt);
@@ -1110,7 +1113,7 @@ static void launch_path_data(bcp_handle* h, EntrySelect sel, int64_t max_entries
 {
     const PathDesc& p = h->path;
     hipLaunchKernelGGL(path_trig_kernel, dim3(stride_grid(max_entries * p.max_len, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src, h->path5,
-                       sel, p.max_len);
+                       p.shared ? nullptr : h->path_pre, sel, p.max_len);
     hipLaunchKernelGGL(path_bbox_kernel, dim3(stride_grid(max_entries, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src, p.lens, p.max_len,
                        sel, h->dev.sp_prune, h->path_bbox);
     hipLaunchKernelGGL(path_index_kernel, dim3(stride_grid(max_entries * 2 * kPathBuckets, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src,
@@ -1295,6 +1298,14 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
         HIP_TRY(hipMalloc((void**)&h->path5, bytes));
         h->path5_bytes = bytes;
     }
+    const size_t pre_bytes = shared ? 0 : (size_t)total * 4 * sizeof(float);
+    if (pre_bytes > h->path_pre_bytes) {
+        if (h->path_pre) HIP_TRY(hipFree(h->path_pre));
+        h->path_pre = nullptr;
+        h->path_pre_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&h->path_pre, pre_bytes));
+        h->path_pre_bytes = pre_bytes;
+    }
     const int64_t n_paths = shared ? 1 : n_slots(h);
     const size_t bb_bytes = (size_t)n_paths * kBoxDoubles * sizeof(double);
     if (bb_bytes > h->path_bbox_bytes) {
@@ -1314,6 +1325,7 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
     }
     if (max_len > 32766) return fail(BCP_E_INVALID, "bcp_set_paths: paths longer than 32766 way points are not supported");
     h->path.pts = h->path5;
+    h->path.pre = shared ? nullptr : h->path_pre;
     h->path.bbox = h->path_bbox;
     h->path.index = h->path_index;
     h->path.lens = shared ? nullptr : lens;
@@ -1458,6 +1470,7 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     hot.n = S.n;
     hot.geom_of_env = S.geom_of_env;
     hot.path_pts = S.path.pts;
+    hot.path_pre = S.path.pre;
     hot.path_bbox = S.path.bbox;
     hot.path_index = S.path.index;
     hot.pending = S.pending;

@@ -36,6 +36,27 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 bytes_out = wrap.images.numel()
 print("observation only: %.4f ms  -> %.1f GB/s written (%d B per env)" % (ms, bytes_out / ms / 1e6, bytes_out // n), flush=True)
+# the same with the sampling kernels (BCP_TUNE_EGO_SPARSE = 0: what round 2 ran), and a plain device fill of the same bytes
+env.set_tuning(ego_sparse=0)
+for k in range(3):
+    wrap.observation()
+e0.record()
+for k in range(reps):
+    wrap.observation()
+e1.record()
+torch.cuda.synchronize()
+ms_dense = e0.elapsed_time(e1) / reps
+env.set_tuning(ego_sparse=1)
+for k in range(3):
+    wrap.images.zero_()
+e0.record()
+for k in range(reps):
+    wrap.images.zero_()
+e1.record()
+torch.cuda.synchronize()
+ms_fill = e0.elapsed_time(e1) / reps
+print("  sampling kernels (ego_sparse = 0): %.4f ms -> %.1f GB/s;  torch zero_() of the same buffer: %.4f ms -> %.1f GB/s" % (
+    ms_dense, bytes_out / ms_dense / 1e6, ms_fill, bytes_out / ms_fill / 1e6), flush=True)
 e0.record()
 for k in range(reps):
     wrap.step(acts[k % 8])
