@@ -11,6 +11,10 @@
 
 #include "bcp_coop.h"   // bcast_i / bcast_d
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "bcp_ego.h is written for gfx950 (MI355X): lds_byte_shifted_16 relies on d16 loads writing the whole register (SRAM-ECC targets), and the sampling kernels on 160 KB of LDS per workgroup"
+#endif
+
 namespace bcp {
 
 extern __shared__ __attribute__((aligned(16))) uint32_t ego_lds[];

@@ -1425,11 +1425,7 @@ static_assert(kStaticChunks <= 128, "*S is staged by the last two waves");
 // `expired`; the wave carries on with what it has and reports BCP_ERR_INTERNAL at the end.  (hipcc 7.2 has turned two
 // shapes of exactly these loops into endless spins, DESIGN.md "Compiler notes": a miscompile must fail a test, not wedge the GPU.)
 constexpr int kPollLimit = 1 << 16;
-#ifdef BCP_VAR_UNBOUNDED
-#define BOUNDED_POLL(cond, expired) do { while (cond) __builtin_amdgcn_s_sleep(1); } while (0)
-#else
 #define BOUNDED_POLL(cond, expired) do { int trips_ = 0; while (cond) { __builtin_amdgcn_s_sleep(1); if (++trips_ > kPollLimit) { (expired) = true; break; } } } while (0)
-#endif
 constexpr uint32_t kDiagWithholdVerdicts = 1u << 23;   // -DBCP_DIAG builds: parked poses are tested but their verdicts never posted
 
 template <bool WIDE, bool PLAIN>
@@ -1437,21 +1433,16 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
 {
     KernArgs a = *(const __attribute__((address_space(4))) StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     DIAG_STAMP_WAVES(512);    // every wave: first instruction
-#ifdef BCP_PRIO
-    // static issue priority by role: the four waves of a SIMD (mover, scorer, helper 1, helper 2 of one pair) compete for its
-    // issue slots, and the mover's chain is the workgroup's critical path
-#if BCP_PRIO == 1
-    if (threadIdx.x < 256) __builtin_amdgcn_s_setprio(3);
-#elif BCP_PRIO == 2
-    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(3);
-#endif
-#endif
-    // The prologue is ONE memory round trip: everything a wave asks for first -- the mover's state and action, a scanner's
-    // target index, the old heading of the helper that takes its cos / sin, every wave's share of the staging data -- is
-    // addressed from the launch arguments alone (StepHot) and issued back to back before anything is waited for; the
-    // parameter block *S (scalar loads that miss at a kernel start) is asked for behind them and is in by the time the
-    // vector loads land.  (Round 2 staged array by array -- load, wait, LDS store -- and only then issued the state loads:
-    // five dependent round trips, 4.1 k cycles until the state had landed; tools/diag_local.py.)
+    // (static issue priorities by role -- s_setprio 3 for the movers, or for everybody else -- change nothing: +-0.5 %)
+    // The prologue is ONE memory round trip.  Everything a wave asks for first -- the mover's state, action and robot
+    // constants, a scanner's target index, the old heading of the helper that takes its cos / sin, every wave's share of the
+    // staging data (footprint, shared path + index, lethal bitmap, the parameter block *S) -- is addressed from the launch
+    // arguments alone (StepHot, fetched together: fetch_words / pin_words) and issued back to back before anything is waited
+    // for; what was loaded is stored to LDS only after the wave has done what it can do without it.  Nothing before barrier 0
+    // reads *S through the scalar cache: those fetches take 1.3 - 2.2 k cycles at a kernel start, and a wave that waits for
+    // one waits for all of them.  (Round 2 staged array by array -- load, wait, LDS store -- fetched each launch argument
+    // where it was first used (~450 cycles per first touch, nine in a row) and only then issued the state loads: 4.1 k
+    // cycles until a mover's state had landed, 5.1 k to barrier 0; tools/diag_local.py.)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool mover = wave < kLocalPairs, scorer = wave >= kLocalPairs && wave < 2 * kLocalPairs;
     const int pair = wave & (kLocalPairs - 1);
@@ -1978,13 +1969,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     //  atomics, and 16 waves drawing at once cost the step 4 us that way -- and lane 0's returned value is the ticket)
     __attribute__((address_space(3))) int* const ticket_word =
         lane == 0 ? (__attribute__((address_space(3))) int*)&ctl[1] : (__attribute__((address_space(3))) int*)(cell_list + lane);
-#ifdef BCP_VAR_TICKET
-    int ticket = 0;
-    if (lane == 0) ticket = atomicAdd((int*)&ctl[1], 1);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-#else
     int ticket = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(ticket_word, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-#endif
     while (ticket < n_parked) {
         DIAG_STAMP_W(8, 10);   // helper: has a ticket
         __attribute__((address_space(3))) ParkedPose* e = rec + ticket;
@@ -2015,13 +2000,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         post = post && !(a.flags & kDiagWithholdVerdicts);
 #endif
         if (post) __hip_atomic_store(&e->verdict, h ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef BCP_VAR_TICKET
-        int next = 0;
-        if (lane == 0) next = atomicAdd((int*)&ctl[1], 1);
-        ticket = __builtin_amdgcn_readfirstlane(next);
-#else
         ticket = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(ticket_word, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-#endif
         DIAG_STAMP_W(8, 12);   // helper: verdict posted
     }
     // (7) movers: the envs they parked are finished by the lane that holds their state, as soon as the verdicts are in

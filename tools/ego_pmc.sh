@@ -17,7 +17,7 @@ f = glob.glob("gpurun_out/ego_pmc_$i/**/*counter_collection.csv", recursive=True
 acc = collections.defaultdict(lambda: [0, 0.0])
 for fn in f:
     for r in csv.DictReader(open(fn)):
-        if "ego_costmap" in r["Kernel_Name"]:
+        if "ego_costmap" in r["Kernel_Name"] or "ego_sparse" in r["Kernel_Name"]:
             a = acc[r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
@@ -35,7 +35,7 @@ for line in open("gpurun_out/ego_pmc_summary.txt"):
         vals[m.group(1)] = float(m.group(2))
 avg_ns = None
 for r in csv.DictReader(open("gpurun_out/ego_kernel_stats.csv")):
-    if "ego_costmap" in r["Name"]:
+    if "ego_costmap" in r["Name"] or "ego_sparse" in r["Name"]:
         avg_ns, name = float(r["AverageNs"]), r["Name"]
 n, px = 65536, 133 * 117
 out = {"source": "rocprofv3 --kernel-trace --pmc <set> (one run per set) -- python3 tools/ego_prof.py; MI355X; kernel %s, %d images of 133 x 117 px per launch (C3 batch at steady state)" % (name, n),
