@@ -280,6 +280,25 @@ __device__ __forceinline__ int robot_step_end(const Params& P, Robot& r, RobotDr
     return err;
 }
 
+// robot_step_end in two parts: the new pose first -- what the other waves of step_local_kernel wait for -- then the
+// measured velocities (path_velocity: a square root and two divisions that nobody else needs)
+template <typename Params>
+__device__ __forceinline__ Pose robot_step_pose(const Params& P, const Robot& r, RobotDrive d, const double z[3], int& drawn)
+{
+    return d.noisy ? kinematic_step_noise(r.p, d.v, d.w, P.dt, P.alpha, z, drawn) : kinematic_step(r.p, d.v, d.w, P.dt);
+}
+
+template <typename Params>
+__device__ __forceinline__ int robot_step_measure(const Params& P, Robot& r, Pose np_, KnownHeading old_heading = no_known_heading())
+{
+    double mv, mw;
+    const int err = path_velocity(r.p, np_, P.dt, mv, mw, old_heading);
+    r.p = np_;
+    r.v = mv;
+    r.w = mw;
+    return err;
+}
+
 __device__ __forceinline__ int robot_step(const DevParams& P, Robot& r, double cmd0, double cmd1, const double z[3],
                                           int& drawn, KnownHeading old_heading = no_known_heading())
 {

@@ -761,23 +761,11 @@ struct Pending {
     double popped_pose[3], popped_state[7];
 };
 
-// An env's initial state, fetched ahead of time for a lane that may well end its episode this step (time-out reached,
-// pose not yet cleared of a collision): the in-kernel reset then finds it in registers instead of paying a memory round
-// trip at the very end of the step.
+// An env's initial state (entry k of the initial-state arrays), all loads in flight together
 struct InitAhead {
     double x, y, th, v, w, steer, wheel, min_dist;
     int32_t target, iter, collided;
-    bool have;
 };
-
-__device__ __forceinline__ InitAhead no_init_ahead()
-{
-    InitAhead p;
-    p.x = p.y = p.th = p.v = p.w = p.steer = p.wheel = p.min_dist = 0.0;
-    p.target = p.iter = p.collided = 0;
-    p.have = false;
-    return p;
-}
 
 template <typename SP>
 __device__ __forceinline__ InitAhead fetch_init_ahead(SP S, int64_t k, bool tri)
@@ -794,7 +782,6 @@ __device__ __forceinline__ InitAhead fetch_init_ahead(SP S, int64_t k, bool tri)
     p.target = as_global(S->init.target_idx)[k];
     p.iter = as_global(S->init.cur_iter)[k];
     p.collided = (int32_t)as_global(S->init.collided)[k];
-    p.have = true;
     return p;
 }
 
@@ -829,8 +816,7 @@ __device__ __forceinline__ int64_t slot_of(SP S, int64_t i, const Pending& q)
 template <bool PLAIN, typename A, typename SP>
 __device__ __forceinline__ void finalize_env_from(const A& a, SP S, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
                                              const PathWindow* free_window = nullptr, bool have_score = false,
-                                             ScoredFree score = ScoredFree(), int known_len = -1, bool score_fits_hit = false,
-                                             InitAhead ahead = no_init_ahead())
+                                             ScoredFree score = ScoredFree(), int known_len = -1, bool score_fits_hit = false)
 {   // (the score travels by value: a pointer to a local made the compiler keep it in scratch memory;
     //  known_len >= 0: the caller already holds the length of this env's path;
     //  score_fits_hit: `score` was computed for the rolled-back pose of a colliding env -- continuous provider only)
@@ -912,7 +898,7 @@ __device__ __forceinline__ void finalize_env_from(const A& a, SP S, int64_t i, P
             k = S->next_geom ? as_global(S->next_geom)[g] : g;
             as_global(S->geom_of_env)[i] = (int32_t)k;
         }
-        if (!ahead.have) ahead = fetch_init_ahead(S, k, tri);   // (fetched ahead only without a geometry pool: entry = env)
+        const InitAhead ahead = fetch_init_ahead(S, k, tri);
         r.p.x = ahead.x;
         r.p.y = ahead.y;
         r.p.th = ahead.th;
@@ -1690,6 +1676,9 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     const int map_rows = hot_map_rows, map_cols = hot_map_cols;
     const int my_len = hot_path_shared ? hot_max_len : (int)own_len;   // way points of this env's path
     // (7) mover: the second half of the robot model; the pose the reward provider will see goes to the scanning waves
+    Pose new_pose;
+    new_pose.x = new_pose.y = new_pose.th = 0.0;
+    double heading_c0 = 0.0, heading_s0 = 0.0;
     if (mover) {
         if (noise_by_waves) {
             q.z[0] = hand_score[lane];
@@ -1702,19 +1691,29 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         old_heading.s0 = hand_pose[kBlock + lane];
         old_heading.known = true;
         if (!PLAIN) drive = robot_step_begin(P, r, cmd0, cmd1);
-        q.err = robot_step_end(P, r, drive, q.z, q.drawn, old_heading);
+        // the new pose goes out as soon as it exists; the measured velocities (path_velocity: a square root, two divisions)
+        // are the mover's own business, behind barrier 1
+        new_pose = robot_step_pose(P, r, drive, q.z, q.drawn);
+        heading_c0 = old_heading.c0;
+        heading_s0 = old_heading.s0;
         const bool delayed = !PLAIN && P.pose_delay > 0 && q.iter + 1 > 1;
-        hand_pose[lane] = delayed ? fifo_stash[0] : r.p.x;
-        hand_pose[kBlock + lane] = delayed ? fifo_stash[kLocalEnvs] : r.p.y;
-        hand_pose[2 * kBlock + lane] = delayed ? fifo_stash[2 * kLocalEnvs] : r.p.th;
+        hand_pose[lane] = delayed ? fifo_stash[0] : new_pose.x;
+        hand_pose[kBlock + lane] = delayed ? fifo_stash[kLocalEnvs] : new_pose.y;
+        hand_pose[2 * kBlock + lane] = delayed ? fifo_stash[2 * kLocalEnvs] : new_pose.th;
         DIAG_STAMP(2);
     }
     DIAG_STAMP_WAVES(1536);
     __syncthreads();
     DIAG_STAMP(3);
-    bool hit = false, park = false, parkable = false;
+    if (mover) {
+        KnownHeading old_heading;
+        old_heading.c0 = heading_c0;
+        old_heading.s0 = heading_s0;
+        old_heading.known = true;
+        q.err = robot_step_measure(P, r, new_pose, old_heading);
+    }
+    bool hit = false, park = false;
     bool poll_expired = false;   // (wave-uniform) one of the bounded waits below gave up
-    InitAhead ahead = no_init_ahead();
     if (mover) {
         // (3a) collision: distance-field classification; an undecided env is parked below
         // (its parameters are read from the LDS copy of *S here, where they are used: held from barrier 0 on they cost
@@ -1745,7 +1744,6 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         }
         if (!active) cls = kFree;
         DIAG_STAMP_U(0, 5);    // mover: classified
-        parkable = cls == kAmbiguous;
         if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
             park = true;
             q.c = c;
@@ -1767,7 +1765,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             // a few have ten: with a lane per env the waves ran as many trips as their unluckiest lane (four) for an average
             // of less than one useful candidate per lane and trip.  The scorer looks up every env's window, numbers the
             // candidates (prefix sum over the wave), writes the list -- item k -> env -- and releases it; then every wave
-            // takes the items k = 64 * (3 r + member) + lane, tests way point lo(env) + (k - first(env)) against the env's
+            // takes its share of the items (64 per wave and round), tests way point lo(env) + (k - first(env)) against the env's
             // pose and keeps the largest reached index per env with an LDS maximum.  (`hand_score` is free by now: the noise
             // it carried was read behind barrier 0.)
             __attribute__((address_space(3))) int32_t* res = (__attribute__((address_space(3))) int32_t*)hand_score;        // [64]
@@ -1803,7 +1801,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
                 total = ready > 0 ? ready - 1 : 0;
             }
             if (total <= kScanItems) {
-                for (int base = 64 * member; base < total; base += 64 * 3) {
+                // (the scorer, who has just made the list, takes the LAST share of every round: 64 * (3 r + 2) ...)
+                for (int base = 64 * ((member + 2) % 3); base < total; base += 64 * 3) {
                     const int k = base + lane;
                     if (k < total) {
                         const int e = (int)items[k];
@@ -1875,12 +1874,10 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         }
         }
     }
-    // (3c) a lane whose episode may end this step -- time-out reached, or a pose the classification could not clear -- asks
-    //      for its env's initial state now; the in-kernel reset at the end of the step then needs no memory round trip
-    //      (PLAIN configurations: with delay queues the movers have no registers to spare for it)
-    if (PLAIN && mover && (a.flags & BCP_STEP_AUTO_RESET) && !a.hot.geom_of_env && active &&
-        (parkable || q.iter + 1 >= P.iteration_timeout))
-        ahead = fetch_init_ahead(SL, i, a.hot.model == BCP_MODEL_TRICYCLE);
+    // (An env that ends its episode this step reloads its initial state in finalize_env_from, a dependent round trip at
+    //  the end of the step.  Fetching it ahead for the lanes that may end -- time-out reached, pose not cleared -- was
+    //  measured in round 3: the ~60 instructions it adds to every mover cost more than the round trip they hide,
+    //  12.24 against 12.00 us per step.)
     // (4) movers park the undecided poses in LDS right away (one LDS atomic per wave hands out the slots)
     __attribute__((address_space(3))) ParkedPose* my_rec = rec;
     if (mover) {
@@ -1953,7 +1950,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
 #pragma unroll
                 for (int k = 0; k < 7; ++k) q.popped_state[k] = fifo_stash[(3 + k) * kLocalEnvs];
             }
-            finalize_env_from<PLAIN>(a, SL, i, q, hit, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len, false, ahead);
+            finalize_env_from<PLAIN>(a, SL, i, q, hit, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len);
         }
     }
     DIAG_STAMP_W(8, 9);   // helper: past the second barrier
@@ -2053,7 +2050,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
 #pragma unroll
                 for (int k = 0; k < 7; ++k) q.popped_state[k] = fifo_stash[(3 + k) * kLocalEnvs];
             }
-            finalize_env_from<PLAIN>(a, SL, i, q, verdict == 2, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len, fits, ahead);
+            finalize_env_from<PLAIN>(a, SL, i, q, verdict == 2, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len, fits);
         }
     }
     DIAG_STAMP(13);            // mover: out of tickets
