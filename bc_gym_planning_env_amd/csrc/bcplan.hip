@@ -103,6 +103,8 @@ struct bcp_handle {
     bool ego_cells_refused;   // allocation failed once: the sampling kernels serve this handle
     int32_t ego_cells_max;    // host copy of the maximum count, -1 = not fetched since the last (re)build
     int32_t ego_sparse;       // BCP_TUNE_EGO_SPARSE
+    hipStream_t side_stream;  // owned: the CU-masked stream of bcp_side_stream (nullptr: not created)
+    int32_t side_share;       // ... and the share of the CUs it was created with
     const uint8_t* map_data;  // caller-owned raw costmap(s) as given to bcp_set_costmaps (egocentric views read them)
     const int32_t* map_valid_rows;
     const int32_t* map_valid_cols;
@@ -969,6 +971,7 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->dev_static) (void)hipFree(h->dev_static);
     if (h->ego_bins) (void)hipFree(h->ego_bins);
     if (h->ego_order) (void)hipFree(h->ego_order);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->ego_cells) (void)hipFree(h->ego_cells);
     if (h->ego_cell_counts) (void)hipFree(h->ego_cell_counts);
     if (h->ring) (void)hipFree(h->ring);
@@ -1616,6 +1619,42 @@ extern "C" int bcp_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, vo
     return BCP_OK;
 }
 
+extern "C" int bcp_side_stream(bcp_handle* h, int32_t cu_percent, void** stream)
+{
+    if (!h || !stream) return fail(BCP_E_INVALID, "bcp_side_stream: null argument");
+    if (cu_percent < 1 || cu_percent > 100) return fail(BCP_E_INVALID, "bcp_side_stream: cu_percent must be 1 .. 100");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->side_stream && h->side_share != cu_percent) {
+        HIP_TRY(hipStreamSynchronize(h->side_stream));
+        HIP_TRY(hipStreamDestroy(h->side_stream));
+        h->side_stream = nullptr;
+    }
+    if (!h->side_stream) {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+        // one bit per CU; the enabled ones are spread evenly (every k-th bit, whatever order the driver numbers the CUs of
+        // the shader engines and XCDs in, every one of them keeps the same share)
+        const int words = (cus + 31) / 32;
+        std::vector<uint32_t> mask((size_t)std::max(words, 1), 0u);
+        int enabled = 0;
+        for (int c = 0; c < cus; ++c)
+            if ((int64_t)(c + 1) * cu_percent / 100 > (int64_t)c * cu_percent / 100) {
+                mask[(size_t)c / 32] |= 1u << (c % 32);
+                ++enabled;
+            }
+        if (enabled == 0) mask[0] |= 1u;
+        hipStream_t s = nullptr;
+        if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(BCP_E_HIP, "bcp_side_stream: the runtime refused a CU-masked stream");
+        }
+        h->side_stream = s;
+        h->side_share = cu_percent;
+    }
+    *stream = (void*)h->side_stream;
+    return BCP_OK;
+}
+
 extern "C" int bcp_expired_waits(bcp_handle* h, int64_t* count, void* stream)
 {
     if (!h || !count) return fail(BCP_E_INVALID, "bcp_expired_waits: null argument");
@@ -1947,7 +1986,8 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
     if (border_value == 0 && a.rows <= 4095 && a.cols <= 4095 && !h->ego_cells_refused && h->ego_sparse) {
         const int64_t entries = a.shared ? 1 : n_slots(h);
         if (h->ego_cells_entries != entries || !h->ego_cells) {
-            if (h->ego_cells) (void)hipFree(h->ego_cells);
+            if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->ego_cells) (void)hipFree(h->ego_cells);
             if (h->ego_cell_counts) (void)hipFree(h->ego_cell_counts);
             h->ego_cells = nullptr;
             h->ego_cell_counts = nullptr;
@@ -1955,7 +1995,8 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
             if (hipMalloc((void**)&h->ego_cells, (size_t)entries * kEgoCellCap * sizeof(uint32_t)) != hipSuccess ||
                 hipMalloc((void**)&h->ego_cell_counts, (size_t)(entries + 1) * sizeof(int32_t)) != hipSuccess) {
                 (void)hipGetLastError();
-                if (h->ego_cells) (void)hipFree(h->ego_cells);
+                if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->ego_cells) (void)hipFree(h->ego_cells);
                 h->ego_cells = nullptr;
                 h->ego_cell_counts = nullptr;
                 h->ego_cells_refused = true;   // (no room for the lists: not an error, the sampling kernels take over)

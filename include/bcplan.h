@@ -354,6 +354,15 @@ int bcp_refresh_mini_worlds(bcp_handle *h, const bcp_mini_world_params *p /*host
 int bcp_release_mini_worlds(bcp_handle *h, void *stream);
 
 /* ---- the on-device noise stream (introspection) --------------------------------------------------------------- */
+/* A stream of the handle that may only use `cu_percent` % of the device's compute units, spread evenly over the chip
+ * (hipExtStreamCreateWithCUMask).  For work that runs BESIDE the steps: the single-launch step wants whole compute units
+ * (one 1024-thread workgroup each), and behind a kernel of small long-running workgroups on an ordinary side stream -- the
+ * world sampler of bcp_refresh_mini_worlds -- a step launch can wait until that kernel has drained (measured: 18 ms).  On a
+ * masked stream such a kernel leaves the other compute units to the steps.  The stream belongs to the handle (destroyed
+ * with it; asking for another share replaces it after a synchronisation).  BCP_E_HIP when the runtime refuses: use an
+ * ordinary stream.  No counterpart in the reference. */
+int bcp_side_stream(bcp_handle *h, int32_t cu_percent, void **stream);
+
 /* Health of the step kernel's internal hand-offs.  The single-launch step passes undecided poses between the wavefronts of a
  * workgroup through LDS; every wait on such a hand-off is bounded (~10^7 cycles against the ~2 * 10^4 a step lasts).  A
  * wait that runs into its limit gives up -- the step still finishes; an env whose verdict never arrived is finished as

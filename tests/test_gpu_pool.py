@@ -311,7 +311,7 @@ def _check_ring_entries(env, deep, world_of_env, generated):
     assert torch.equal(near, env.distance_field(0, env.n_envs * E)[0] < t_out)
 
 
-@pytest.mark.parametrize("overlap,E", [(False, 3), (True, 5)], ids=["in-order", "side-stream"])
+@pytest.mark.parametrize("overlap,E", [(False, 3), (True, 5), ("masked", 5)], ids=["in-order", "side-stream", "cu-masked-side-stream"])
 def test_endless_pool_follows_the_streams(torch_cuda, overlap, E):
     """BatchedRandomMiniEnv(endless=True) + refresh(): every env walks through the worlds of its own RandomState
     stream in order, never an old one again; re-sampled entries (costmap, path, initial state, and the handle's
@@ -321,6 +321,9 @@ def test_endless_pool_follows_the_streams(torch_cuda, overlap, E):
     from bc_gym_planning_env_amd import mini_env
     n, K = 96, 40
     params, env, deep = _endless_setup(mini_env, n, E, K, timeout=12)
+    if overlap == "masked":   # the refresh on a stream that may only use half of the compute units (bcp_side_stream)
+        env.side_cu_percent = 50
+        overlap = True
     ref = mini_env.BatchedRandomMiniEnv(n, params, pool=deep, auto_reset=True, seed=9)
     world = np.ones(n, dtype=np.int64)          # both constructors end with the reset() that moves on to world 1
     generated = np.full(n, E, dtype=np.int64)   # worlds planned so far ...

@@ -1,5 +1,6 @@
 """Endless geometry pool (BatchedRandomMiniEnv(endless=True)): step rate with refresh() every R steps, and what one
-refresh costs.  Usage: python tools/bench_endless.py [n_envs] [episodes] [refresh_every] [steps]"""
+refresh costs.  Usage: python tools/bench_endless.py [n_envs] [episodes] [refresh_every] [steps] [side_cu_percent]
+(side_cu_percent: share of the compute units the overlapped refresh may use, bcp_side_stream; 100 = an ordinary stream)"""
 import os
 import sys
 import time
@@ -14,11 +15,13 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 episodes = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 every = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
+share = int(sys.argv[5]) if len(sys.argv) > 5 else 100
 
 t0 = time.time()
 env = mini_env.BatchedRandomMiniEnv(n, episodes=episodes, endless=True, auto_reset=True, seed=1)
+env.side_cu_percent = share
 torch.cuda.synchronize()
-print("setup: %d envs x %d entries in %.2f s" % (n, episodes, time.time() - t0), flush=True)
+print("setup: %d envs x %d entries in %.2f s; overlapped refresh on %d %% of the compute units" % (n, episodes, time.time() - t0, share), flush=True)
 g = torch.Generator(device="cuda").manual_seed(0)
 acts = [torch.rand(n, 2, device="cuda", generator=g, dtype=torch.float64) * torch.tensor([1.0, 1.0], device="cuda",
         dtype=torch.float64) - torch.tensor([0.0, 0.5], device="cuda", dtype=torch.float64) for _ in range(16)]
