@@ -1419,7 +1419,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
 {
     KernArgs a = *(const __attribute__((address_space(4))) StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     DIAG_STAMP_WAVES(512);    // every wave: first instruction
-    // (static issue priorities by role -- s_setprio 3 for the movers, or for everybody else -- change nothing: +-0.5 %)
+    // (static issue priorities by role, s_setprio -- the movers above everybody else, or everybody else above the movers
+    //  until barrier 0, or behind barrier 1 -- change nothing: +-0.5 % in every form tried)
     // The prologue is ONE memory round trip.  Everything a wave asks for first -- the mover's state, action and robot
     // constants, a scanner's target index, the old heading of the helper that takes its cos / sin, every wave's share of the
     // staging data (footprint, shared path + index, lethal bitmap, the parameter block *S) -- is addressed from the launch
