@@ -358,7 +358,10 @@ int bcp_release_mini_worlds(bcp_handle *h, void *stream);
  * (hipExtStreamCreateWithCUMask).  For work that runs BESIDE the steps: the single-launch step wants whole compute units
  * (one 1024-thread workgroup each), and behind a kernel of small long-running workgroups on an ordinary side stream -- the
  * world sampler of bcp_refresh_mini_worlds -- a step launch can wait until that kernel has drained (measured: 18 ms).  On a
- * masked stream such a kernel leaves the other compute units to the steps.  The stream belongs to the handle (destroyed
+ * masked stream such a kernel leaves the other compute units to the steps.  Measured in round 3: with 50 %
+ * the endless pool ran SLOWER (0.078 against 0.064 ms per step) -- the refresh takes twice as long and the steps' own
+ * workgroups still land on the masked units too -- so the Python layer defaults to an ordinary stream; the entry point is
+ * kept for callers whose side work is lighter.  The stream belongs to the handle (destroyed
  * with it; asking for another share replaces it after a synchronisation).  BCP_E_HIP when the runtime refuses: use an
  * ordinary stream.  No counterpart in the reference. */
 int bcp_side_stream(bcp_handle *h, int32_t cu_percent, void **stream);
