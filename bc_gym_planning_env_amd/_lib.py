@@ -12,7 +12,7 @@ MODEL_TRICYCLE, MODEL_DIFFDRIVE = 0, 1
 REWARD_CONTINUOUS, REWARD_PURE_PURSUIT = 0, 1
 STEP_AUTO_RESET, STEP_ACTIONS_F32 = 1, 2
 ERR_ANGLE_JUMP, ERR_TIME_ORDER, ERR_INTERNAL = 1, 2, 4
-TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL, TUNE_DEFER, TUNE_EDT_LDS, TUNE_FUSED, TUNE_EGO_SPARSE = 0, 1, 2, 3, 4, 5, 6
+TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL, TUNE_DEFER, TUNE_EDT_LDS, TUNE_FUSED, TUNE_EGO_SPARSE, TUNE_NEAR_DILATE = 0, 1, 2, 3, 4, 5, 6, 7
 E_NO_DEVICE = -2
 
 _f64p = C.POINTER(C.c_double)

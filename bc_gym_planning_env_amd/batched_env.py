@@ -566,11 +566,12 @@ class BatchedPlanEnv(object):
         return env
 
     def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None, defer=None, edt_lds=None, fused=None,
-                   ego_sparse=None):
+                   ego_sparse=None, near_dilate=None):
         """Execution knobs of libbcplan (bcp_set_tuning); results never depend on them."""
         for key, val in ((_lib.TUNE_EXACT_MODE, exact_mode), (_lib.TUNE_DENSE_THRESHOLD, dense_threshold),
                          (_lib.TUNE_CULL, cull), (_lib.TUNE_DEFER, defer), (_lib.TUNE_EDT_LDS, edt_lds),
-                         (_lib.TUNE_FUSED, fused), (_lib.TUNE_EGO_SPARSE, ego_sparse)):
+                         (_lib.TUNE_FUSED, fused), (_lib.TUNE_EGO_SPARSE, ego_sparse),
+                         (_lib.TUNE_NEAR_DILATE, near_dilate)):
             if val is not None:
                 _lib.check(self._lib.bcp_set_tuning(self._h, key, int(val)))
 
@@ -583,9 +584,10 @@ class BatchedPlanEnv(object):
         _lib.check(self._lib.bcp_get_distance_field(self._h, int(first), int(count), out.data_ptr(), shape, self._stream()))
         return out, int(shape[2]), int(shape[3])
 
-    def near_field(self, first=0, count=1):
+    def near_field(self, first=0, count=1, raw=False):
         """The 1-bit form of the distance fields the step's outer test reads (bcp_get_near_field), unpacked:
-        (bool device tensor [count, rows + 2 pad, cols + 2 pad] -- True where the field is < t_out --, t_out)."""
+        (bool device tensor [count, rows + 2 pad, cols + 2 pad] -- True where the field is < t_out --, t_out);
+        raw: the tile words themselves, int32 [count, tile rows, tile columns, 32]."""
         shape = (C.c_int32 * 3)()
         _lib.check(self._lib.bcp_get_near_field(self._h, 0, 0, None, shape, None))
         ty, tx, t_out = int(shape[0]), int(shape[1]), int(shape[2])
@@ -595,6 +597,8 @@ class BatchedPlanEnv(object):
         _lib.check(self._lib.bcp_get_distance_field(self._h, 0, 0, None, dshape, None))
         bits = (words.unsqueeze(-1) >> torch.arange(32, device=self.device, dtype=torch.int32)) & 1   # [count, ty, tx, 32 rows, 32 bits]
         cells = bits.permute(0, 1, 3, 2, 4).reshape(int(count), ty * 32, tx * 32)
+        if raw:
+            return words, t_out
         return cells[:, :dshape[0], :dshape[1]].bool(), t_out
 
     # ------------------------------------------------------------------ per-env lookups

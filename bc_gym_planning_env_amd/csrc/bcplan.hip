@@ -119,6 +119,12 @@ struct bcp_handle {
     int32_t edt_in_lds;       // distance transform of maps that fit: the LDS-resident kernel (BCP_TUNE_EDT_LDS)
     int32_t last_step_form;   // 0 none yet, 1 single-kernel step, 2 two-kernel step (parking counters in use)
     int32_t fused;            // settle parked poses inside the step launch (step_local_kernel) instead of a second launch
+    // near_dilate_kernel: 1-bit tiles without the uint8 field (pool refresh under the single-launch step)
+    int32_t near_dilate;      // BCP_TUNE_NEAR_DILATE: 0 never, 1 pool refreshes (default), 2 every build (after the field: tests)
+    uint8_t* edt_stale;       // owned: [entries] 1 = the entry's uint8 field does not describe its map (tiles do)
+    int32_t* edt_stale_list;  // owned: [entries] + [1] count, scratch of ensure_fields
+    int64_t edt_stale_cap;
+    bool edt_lazy;            // a refresh has left stale fields behind since the last full build
 };
 
 // number of entries of a non-shared map / path / initial-state array
@@ -561,6 +567,86 @@ __global__ void __launch_bounds__(256) edt_lds_kernel(const uint32_t* __restrict
     }
 }
 
+// The 1-bit tiles WITHOUT the distance field: bit (x, y) = "a lethal cell lies within dx^2 + dy^2 < t_out^2" is the lethal
+// mask dilated by a disc, and a disc is a stack of horizontal runs: with reach(w) = isqrt(t_out^2 - 1 - w^2),
+//     near(x, y) = OR over |w| < t_out of  V_|w|(x + w, y),     V_w(x, y) = OR over |dy| <= reach(w) of lethal(x, y + dy).
+// reach() grows as w shrinks, so one pass from w = t_out - 1 down to 0 ORs every row within reach into a 96-bit window
+// exactly once and shifts the window by +-w: ~250 integer instructions per 32-cell output word against ~1200 of the
+// distance transform + threshold (edt_lds_kernel + near_tiles_kernel), and no 16 KB uint8 field to write and read back.
+// The bits are those of near_tiles_kernel by construction (floor(sqrt(D2)) < t_out  <=>  D2 <= t_out^2 - 1; the transform's
+// windows are wider than t_out); tests/test_gpu_distance_field.py compares the two word for word.  What a pool refresh runs
+// while the steps only read the tiles (step_local_kernel); the uint8 field of such entries is marked stale (ensure_fields).
+// One workgroup per map; LDS: the padded lethal rows with a zero word either side and t_out - 1 zero rows above and below.
+__global__ void __launch_bounds__(256) near_dilate_kernel(const uint32_t* __restrict__ bits, EntrySelect sel, int rows, int cols,
+                                                          int wpr, int pad, int t_out, int W, int H, int tiles_x, int tiles_y,
+                                                          uint32_t* __restrict__ tiles, uint8_t* __restrict__ stale)
+{
+    const LdsU32 P = (LdsU32)lds_dyn;
+    const int tid = threadIdx.x;
+    const int margin = t_out - 1, pitch = tiles_x + 2, Ht = tiles_y * 32, Hp = Ht + 2 * margin;
+    const LdsU32 reach = P + Hp * pitch;   // [t_out]
+    for (int w = tid; w < t_out; w += 256) {
+        const int v = t_out * t_out - 1 - w * w;
+        int sq = (int)__builtin_amdgcn_sqrtf((float)v);   // v < 1024: the fix-ups make it exact
+        while (sq * sq > v) --sq;
+        while ((sq + 1) * (sq + 1) <= v) ++sq;
+        reach[w] = (uint32_t)sq;
+    }
+    const int64_t n_sel = sel.size(), per = (int64_t)tiles_x * tiles_y * 32;
+    for (int64_t k = blockIdx.x; k < n_sel; k += gridDim.x) {
+        const int64_t m = sel.entry(k);
+        const uint32_t* mb = bits + m * (int64_t)rows * wpr;
+        __syncthreads();   // the previous map's words are no longer read
+        // P[yp][1 + kx] bit b = lethal(column 32 kx + b - pad, row yp - margin - pad); zero outside the map
+        for (int i = tid; i < Hp * pitch; i += 256) {
+            const int yp = i / pitch, kp = i - yp * pitch;
+            const int r = yp - margin - pad, start = 32 * (kp - 1) - pad;
+            uint32_t word = 0;
+            if (r >= 0 && r < rows && kp >= 1 && kp <= tiles_x) {
+                const int w0 = start >> 5, sh = start & 31;   // (arithmetic shift: floor for negative starts)
+                const uint32_t lo = (w0 >= 0 && w0 < wpr) ? mb[r * wpr + w0] : 0u;
+                const uint32_t hi = (w0 + 1 >= 0 && w0 + 1 < wpr) ? mb[r * wpr + w0 + 1] : 0u;
+                word = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+                const int left = cols + pad - 32 * (kp - 1);   // columns >= cols are not part of the map
+                word = left >= 32 ? word : (left > 0 ? word & ((1u << left) - 1u) : 0u);
+            }
+            P[i] = word;
+        }
+        __syncthreads();
+        for (int i = tid; i < Ht * tiles_x; i += 256) {
+            const int y = i / tiles_x, kx = i - y * tiles_x;
+            const LdsU32 centre = P + (y + margin) * pitch + kx;   // words kx - 1, kx, kx + 1 of row y
+            uint32_t a = 0, b = 0, c = 0, word = 0;
+            int in = -1;
+            for (int w = t_out - 1; w >= 0; --w) {
+                const int need = (int)reach[w];
+                while (in < need) {
+                    ++in;
+                    const LdsU32 up = centre - in * pitch, dn = centre + in * pitch;
+                    a |= up[0] | dn[0];
+                    b |= up[1] | dn[1];
+                    c |= up[2] | dn[2];
+                }
+                word |= w ? (b << w) | (a >> (32 - w)) | (b >> w) | (c << (32 - w)) : b;
+            }
+            const int left = W - 32 * kx;   // near_tiles_kernel leaves cells outside the padded field clear
+            word = (y < H) ? (left >= 32 ? word : (left > 0 ? word & ((1u << left) - 1u) : 0u)) : 0u;
+            tiles[m * per + ((int64_t)(y >> 5) * tiles_x + kx) * 32 + (y & 31)] = word;
+        }
+        if (stale && tid == 0) stale[m] = 1;
+    }
+}
+
+// entries whose uint8 distance field is stale (near_dilate_kernel ran for them) -> a list for edt_lds_kernel & co.
+__global__ void stale_fields_list_kernel(uint8_t* __restrict__ stale, int64_t n, int32_t* __restrict__ list, int32_t* __restrict__ count)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        if (stale[e]) {
+            stale[e] = 0;
+            list[atomicAdd(count, 1)] = (int32_t)e;
+        }
+}
+
 __global__ void normalize_angle_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -930,6 +1016,7 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->params = *params;
     h->n = n_envs;
     h->edt_in_lds = 1;
+    h->near_dilate = 1;
     h->device = device;
     h->env_id_base = env_id_base;
     h->seed = 0;
@@ -964,6 +1051,8 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->edt) (void)hipFree(h->edt);
     if (h->edt_col) (void)hipFree(h->edt_col);
     if (h->near) (void)hipFree(h->near);
+    if (h->edt_stale) (void)hipFree(h->edt_stale);
+    if (h->edt_stale_list) (void)hipFree(h->edt_stale_list);
     if (h->pending) (void)hipFree(h->pending);
     if (h->tick) (void)hipFree(h->tick);
     if (h->pending_count) (void)hipFree(h->pending_count);
@@ -1033,6 +1122,10 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
         case BCP_TUNE_EDT_LDS:
             h->edt_in_lds = value ? 1 : 0;
             return BCP_OK;
+        case BCP_TUNE_NEAR_DILATE:
+            if (value < 0 || value > 2) return fail(BCP_E_INVALID, "bcp_set_tuning: BCP_TUNE_NEAR_DILATE takes 0, 1 or 2");
+            h->near_dilate = value;
+            return BCP_OK;
         case BCP_TUNE_EGO_SPARSE:
             h->ego_sparse = value ? 1 : 0;
             return BCP_OK;
@@ -1081,7 +1174,27 @@ static void launch_near_tiles(bcp_handle* h, EntrySelect sel, int64_t max_entrie
                        h->edt, sel, C.width, C.height, C.near_tx, tiles_y, C.t_out, h->near);
 }
 
-static void launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
+// near_dilate_kernel serves these maps: radius within a word, rows + margins in LDS
+static size_t near_dilate_lds(const bcp_handle* h)
+{
+    const CullDesc& C = h->cull;
+    if (!C.near || C.t_out < 1 || C.t_out > 32 || C.pad < C.t_out - 1) return 0;
+    const int tiles_y = C.near_words / (32 * C.near_tx);
+    const size_t bytes = ((size_t)(tiles_y * 32 + 2 * (C.t_out - 1)) * (C.near_tx + 2) + C.t_out) * sizeof(uint32_t);
+    return bytes <= 64 * 1024 ? bytes : 0;
+}
+
+static void launch_near_dilate(bcp_handle* h, EntrySelect sel, int64_t max_entries, uint8_t* stale, hipStream_t s)
+{
+    const MapDesc& m = h->map;
+    const CullDesc& C = h->cull;
+    const size_t lds = near_dilate_lds(h);
+    const int64_t blocks = std::min<int64_t>(max_entries, sel.list ? 4096 : 16384);
+    hipLaunchKernelGGL(near_dilate_kernel, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), lds, s, h->bitmap, sel, m.rows,
+                       m.cols, m.wpr, C.pad, C.t_out, C.width, C.height, C.near_tx, C.near_words / (32 * C.near_tx), h->near, stale);
+}
+
+static void launch_edt(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
 {
     const MapDesc& m = h->map;
     const CullDesc& C = h->cull;
@@ -1094,14 +1207,46 @@ static void launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_en
         const int64_t blocks = std::min<int64_t>(max_entries, sel.list ? 2048 : 16384);
         hipLaunchKernelGGL(edt_lds_kernel, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), lds, s, h->bitmap, sel,
                            m.rows, m.cols, m.wpr, C.pad, C.clamp, h->edt);
-        launch_near_tiles(h, sel, max_entries, s);
         return;
     }
     hipLaunchKernelGGL(edt_columns_kernel, dim3(stride_grid(max_entries * C.width, 64, sel.list != nullptr)), dim3(64), 0, s, h->bitmap, sel, m.rows,
                        m.cols, m.wpr, C.pad, C.clamp, h->edt_col);
     hipLaunchKernelGGL(edt_rows_kernel, dim3(stride_grid(max_entries * C.width * C.height, 256, sel.list != nullptr)), dim3(256), 0, s, h->edt_col,
                        sel, C.width, C.height, C.clamp, h->edt);
+}
+
+// Distance field + tiles of the selected entries.  `tiles_only`: the caller's consumers read nothing but the tiles (a pool
+// refresh under the single-launch step) -- when near_dilate_kernel can serve the maps, the uint8 field is left stale and
+// marked so; ensure_fields() brings it up to date for whoever asks for it later.
+static int launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s, bool tiles_only = false)
+{
+    if (tiles_only && h->near_dilate >= 1 && near_dilate_lds(h) && h->edt_stale && h->edt_stale_cap >= n_slots(h)) {
+        launch_near_dilate(h, sel, max_entries, h->edt_stale, s);
+        h->edt_lazy = true;
+        return BCP_OK;
+    }
+    launch_edt(h, sel, max_entries, s);
     launch_near_tiles(h, sel, max_entries, s);
+    if (h->near_dilate == 2 && near_dilate_lds(h)) launch_near_dilate(h, sel, max_entries, nullptr, s);
+    return BCP_OK;
+}
+
+// Before anything reads the uint8 field (two-launch and single-kernel step forms, bcp_pose_collides,
+// bcp_get_distance_field): the transform of the entries a tiles-only refresh has left stale, on the reader's stream.  An
+// entry is marked at the end of its refresh, in the refresh's stream order, so a refresh still running on another stream
+// is simply picked up by the next call; the flag of the handle stays up for as long as such refreshes may be in flight.
+static int ensure_fields(bcp_handle* h, hipStream_t s)
+{
+    if (!h->edt_lazy || !h->cull.edt || !h->edt_stale) return BCP_OK;
+    const int64_t entries = h->edt_stale_cap;
+    int32_t* count = h->edt_stale_list + entries;
+    HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(stale_fields_list_kernel, dim3(stride_grid(entries, 256)), dim3(256), 0, s, h->edt_stale, entries,
+                       h->edt_stale_list, count);
+    const EntrySelect sel = {h->edt_stale_list, count, entries};
+    launch_edt(h, sel, entries, s);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
 }
 
 // origin and length into the path records of private paths (kBoxOrigin, kBoxLen): needs both the costmaps and the paths
@@ -1217,7 +1362,20 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
         C.clamp = clamp;
         C.env_stride = shared ? 0 : (int64_t)W * H;
         C.on = C.t_out <= clamp ? 1 : 0;
-        launch_distance_field(h, all_maps, n_maps, s);
+        // the stale marks of tiles-only refreshes (launch_distance_field): every field is rebuilt below, so none is stale
+        h->edt_lazy = false;
+        if (!shared && n_maps > h->edt_stale_cap) {
+            if (h->edt_stale) HIP_TRY(hipFree(h->edt_stale));
+            if (h->edt_stale_list) HIP_TRY(hipFree(h->edt_stale_list));
+            h->edt_stale = nullptr;
+            h->edt_stale_list = nullptr;
+            h->edt_stale_cap = 0;
+            HIP_TRY(hipMalloc((void**)&h->edt_stale, (size_t)n_maps));
+            HIP_TRY(hipMalloc((void**)&h->edt_stale_list, (size_t)(n_maps + 1) * sizeof(int32_t)));
+            h->edt_stale_cap = n_maps;
+        }
+        if (h->edt_stale) HIP_TRY(hipMemsetAsync(h->edt_stale, 0, (size_t)h->edt_stale_cap, s));
+        { const int rc = launch_distance_field(h, all_maps, n_maps, s); if (rc != BCP_OK) return rc; }
         HIP_TRY(hipGetLastError());
         if (!h->pending) {
             const int64_t blocks = (h->n + kBlock - 1) / kBlock;
@@ -1259,6 +1417,7 @@ extern "C" int bcp_get_distance_field(bcp_handle* h, int64_t first_entry, int64_
     if (first_entry < 0 || n_entries <= 0 || first_entry + n_entries > n_maps)
         return fail(BCP_E_INVALID, "bcp_get_distance_field: entries out of range");
     HIP_TRY(hipSetDevice(h->device));
+    { const int rc = ensure_fields(h, (hipStream_t)stream); if (rc != BCP_OK) return rc; }
     const size_t per = (size_t)C.width * C.height;
     HIP_TRY(hipMemcpyAsync(out, h->edt + first_entry * per, n_entries * per, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return BCP_OK;
@@ -1459,6 +1618,10 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     // (an explicit BCP_TUNE_DENSE_THRESHOLD asks for poses to be settled inside the stepping wave: the two-launch form has that path)
     const bool fused = S.pending && h->fused && h->adaptive;
     const int32_t form = fused ? 3 : (S.pending ? 2 : 1);
+    if (!fused && h->edt_lazy) {   // these forms read the uint8 field
+        const int rc = ensure_fields(h, s);
+        if (rc != BCP_OK) return rc;
+    }
     if (form != h->last_step_form) {
         if (form == 2 && h->last_step_form != 0) {
             const int rc = rearm_parking(h, s);
@@ -1764,6 +1927,7 @@ static int pose_collides_launch(bcp_handle* h, const double* poses, int64_t n, u
     if (!h || !poses || !out || n <= 0) return fail(BCP_E_INVALID, "%s: bad argument", who);
     if (!h->have_map) return fail(BCP_E_STATE, "%s: costmaps not set", who);
     HIP_TRY(hipSetDevice(h->device));
+    { const int rc = ensure_fields(h, (hipStream_t)stream); if (rc != BCP_OK) return rc; }
     const int blocks = (int)((n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(pose_collides_kernel, dim3(blocks), dim3(kBlock),
                        collision_lds_bytes(h->params.n_verts, h->map.in_lds, h->map.rows, h->map.wpr),
@@ -2263,7 +2427,12 @@ extern "C" int bcp_refresh_mini_worlds(bcp_handle* h, const bcp_mini_world_param
                        (int)(h->params.reward_provider == BCP_REWARD_PURE_PURSUIT), (int)h->path.max_len, paths, lens, init,
                        path_status);
     launch_pack_bitmap(h, sel, G, s);
-    if (h->cull.edt) launch_distance_field(h, sel, G, s);
+    if (h->cull.edt) {
+        // under the single-launch step nothing reads the uint8 fields: tiles only, the fields follow on demand
+        const bool tiles_only = h->pending && h->fused && h->adaptive && h->cull.on;
+        const int rc2 = launch_distance_field(h, sel, G, s, tiles_only);
+        if (rc2 != BCP_OK) return rc2;
+    }
     launch_path_data(h, sel, G, s);
     hipLaunchKernelGGL(pool_initial_state_kernel, dim3(stride_grid(G, 256, true)), dim3(256), 0, s, sel, paths,
                        (int)h->path.max_len, init, h->init);

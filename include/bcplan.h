@@ -161,9 +161,15 @@ int bcp_seed(bcp_handle *h, uint64_t seed);
  *   BCP_TUNE_FUSED            0 = settle the parked poses in a second launch (step_fast_pair_kernel + step_pending_kernel)
  *                             instead of inside the step launch itself (step_local_kernel, the default)
  *   BCP_TUNE_EGO_SPARSE       0 = egocentric views always sample the costmap pixel by pixel; 1 (default) = sparse maps with
- *                             border value 0 are drawn as a zero fill plus one patch per non-zero source cell */
+ *                             border value 0 are drawn as a zero fill plus one patch per non-zero source cell
+ *   BCP_TUNE_NEAR_DILATE      how the 1-bit tiles of the distance field (bcp_get_near_field) are made: 0 = always by
+ *                             thresholding the uint8 field; 1 (default) = a pool refresh (bcp_refresh_mini_worlds) under the
+ *                             single-launch step dilates the lethal mask by the sample disc instead and leaves the uint8
+ *                             fields of those entries to be computed when something asks for them (the other step forms,
+ *                             bcp_pose_collides, bcp_get_distance_field); 2 = bcp_set_costmaps also overwrites its
+ *                             thresholded tiles with dilated ones (tests: the two must agree bit for bit) */
 enum { BCP_TUNE_EXACT_MODE = 0, BCP_TUNE_DENSE_THRESHOLD = 1, BCP_TUNE_CULL = 2, BCP_TUNE_DEFER = 3, BCP_TUNE_EDT_LDS = 4,
-       BCP_TUNE_FUSED = 5, BCP_TUNE_EGO_SPARSE = 6 };
+       BCP_TUNE_FUSED = 5, BCP_TUNE_EGO_SPARSE = 6, BCP_TUNE_NEAR_DILATE = 7 };
 int bcp_set_tuning(bcp_handle *h, int32_t key, int32_t value);
 
 /* ---- static per-episode inputs ------------------------------------------------------------------------ */

@@ -335,6 +335,10 @@ def test_endless_pool_follows_the_streams(torch_cuda, overlap, E):
     for t in range(150):
         a = env.action_space.sample_batch(n, rng)
         a[:, 0] *= 3.0
+        if t in (90, 120) and E == 5:
+            # the refreshes so far only made the 1-bit tiles of the re-sampled worlds (near_dilate_kernel: nothing else is read
+            # under the single-launch step); the two-launch form reads the uint8 fields -- they are brought up to date on demand
+            env.set_tuning(fused=0 if t == 90 else 1)
         env.step(a, noise_z_out=z)
         ref.step(a, noise_z=z)
         for name in ("reward", "done", "collided_now"):
@@ -434,3 +438,32 @@ def test_distance_fields_lds_kernel_vs_two_pass_vs_scipy(torch_cuda):
         free = np.pad(dense[k] != 254, pad, constant_values=True)
         want = np.minimum(np.floor(ndimage.distance_transform_edt(free) + 1e-9), clamp).astype(np.uint8)
         assert (fast[k] == want).all(), k
+
+
+@pytest.mark.parametrize("density", [0.0005, 0.02, 0.5])
+def test_near_tiles_by_dilation_vs_thresholded_field(torch_cuda, density):
+    """near_dilate_kernel (what a pool refresh runs under the single-launch step: the lethal mask dilated by the sample
+    disc, no uint8 field) writes the very words near_tiles_kernel gets by thresholding the distance field -- padding bits
+    and rows included --, on sampled worlds and on random maps with lethal cells in the corners and along the edges"""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import mini_env
+    pool = mini_env.sample_pool_device(None, list(range(3, 11)), 2, keep_on_device=True)
+    env = mini_env.BatchedRandomMiniEnv(16, pool=pool)
+    g_n = len(pool)
+    rng = np.random.RandomState(int(density * 1e4))
+    maps = pool.maps.cpu().numpy().copy()
+    half = g_n // 2
+    maps[half:] = np.where(rng.rand(g_n - half, *maps.shape[1:]) < density, 254, 0).astype(np.uint8)
+    maps[half:, 0, 0] = maps[half:, -1, -1] = maps[half, 0, -1] = maps[half, -1, 0] = 254
+    maps[half + 1, :, 0] = maps[half + 1, 0, :] = 254
+    maps[half + 2, :, -1] = maps[half + 2, -1, :] = 254
+    dmap = torch.from_numpy(maps).cuda()
+    env.set_tuning(near_dilate=0)
+    env.set_costmap_tensors(dmap, env._keep["origins"], env.resolution)
+    want, t_out = env.near_field(0, g_n, raw=True)
+    cells = env.near_field(0, g_n)[0]
+    assert torch.equal(cells, env.distance_field(0, g_n)[0] < t_out) and bool(cells.any()) and not bool(cells.all())
+    env.set_tuning(near_dilate=2)
+    env.set_costmap_tensors(dmap, env._keep["origins"], env.resolution)
+    got, t2 = env.near_field(0, g_n, raw=True)
+    assert t2 == t_out and torch.equal(got, want)

@@ -1,6 +1,7 @@
 """Endless geometry pool (BatchedRandomMiniEnv(endless=True)): step rate with refresh() every R steps, and what one
-refresh costs.  Usage: python tools/bench_endless.py [n_envs] [episodes] [refresh_every] [steps] [side_cu_percent]
-(side_cu_percent: share of the compute units the overlapped refresh may use, bcp_side_stream; 100 = an ordinary stream)"""
+refresh costs.  Usage: python tools/bench_endless.py [n_envs] [episodes] [refresh_every] [steps] [side_cu_percent] [near_dilate]
+(side_cu_percent: share of the compute units the overlapped refresh may use, bcp_side_stream; 100 = an ordinary stream;
+near_dilate: BCP_TUNE_NEAR_DILATE, 0 = every refresh computes the uint8 distance fields, 1 = tiles by dilation only)"""
 import os
 import sys
 import time
@@ -16,12 +17,14 @@ episodes = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 every = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
 share = int(sys.argv[5]) if len(sys.argv) > 5 else 100
+near_dilate = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 
 t0 = time.time()
 env = mini_env.BatchedRandomMiniEnv(n, episodes=episodes, endless=True, auto_reset=True, seed=1)
 env.side_cu_percent = share
+env.set_tuning(near_dilate=near_dilate)
 torch.cuda.synchronize()
-print("setup: %d envs x %d entries in %.2f s; overlapped refresh on %d %% of the compute units" % (n, episodes, time.time() - t0, share), flush=True)
+print("setup: %d envs x %d entries in %.2f s; overlapped refresh on %d %% of the compute units; near_dilate %d" % (n, episodes, time.time() - t0, share, near_dilate), flush=True)
 g = torch.Generator(device="cuda").manual_seed(0)
 acts = [torch.rand(n, 2, device="cuda", generator=g, dtype=torch.float64) * torch.tensor([1.0, 1.0], device="cuda",
         dtype=torch.float64) - torch.tensor([0.0, 0.5], device="cuda", dtype=torch.float64) for _ in range(16)]
