@@ -541,7 +541,8 @@ __device__ __forceinline__ int row_max(int v)
 
 template <bool WIDE, typename WordPtr>
 __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 qverts, double c, double s, int px, int py,
-                                                    WordPtr words, int rows, int cols, int wpr, LdsU32 list)
+                                                    WordPtr words, int rows, int cols, int wpr, LdsU32 list,
+                                                    [[maybe_unused]] unsigned long long* phase = nullptr)
 {
     constexpr int NW = WIDE ? 8 : 3;
     const int K = P.n_verts;
@@ -586,6 +587,9 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 q
     //      of the cells does not matter, so a lane just reserves room for its row's cells with one LDS atomic)
     CoopCollisionSink<NW, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
     sink.extent(umin, umax);
+#ifdef BCP_DIAG
+    if (phase) phase[0] = __builtin_amdgcn_s_memtime();   // the edges are set up
+#endif
     if (lane == 0) list[kSparseCap] = 0;
     wave_lds_sync();
     const int n_chunks = (vmax - vmin) / 64 + 1;
@@ -612,6 +616,10 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 q
     }
     wave_lds_sync();
     int total = bcast_i((int)list[kSparseCap], 0);
+#ifdef BCP_DIAG
+    if (phase) phase[1] = __builtin_amdgcn_s_memtime();   // the lethal cells are listed
+    if (phase) phase[2] = (unsigned long long)total;
+#endif
     if (total > kSparseCap) return kSparseTooMany;
     // A long list (the median is 3 cells) sets the pace of its whole workgroup -- and the slowest workgroup that of the
     // step: drop the cells that lie outside the footprint's own bounding box (robot frame, 2 px of slack for vertex

@@ -799,6 +799,10 @@ struct ParkedPose {
     int32_t env_lo, env_hi;  // env index (private maps: the map entry)
     int32_t geom;            // geometry-pool entry
     int32_t verdict;         // 0 = pending, 1 = free, 2 = collides
+    // private paths: what the reward provider returns for the rolled-back pose, should the verdict be "collides" -- worked
+    // out by the env's mover while the scanners are still busy (step_local_kernel), valid when spec_ok != 0
+    double spec_rew, spec_min;
+    int32_t spec_target, spec_ok;
 };
 
 // entry of the non-shared map / path arrays that env i uses
@@ -1898,6 +1902,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
                 my_rec->env_hi = q.env_hi;
                 my_rec->geom = q.geom;
                 my_rec->verdict = 0;
+                my_rec->spec_ok = 0;
             }
         }
     }
@@ -1908,6 +1913,29 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     // poses while the slowest scan of the workgroup is still running (release adds / acquire polls, workgroup scope).
     if (mover) {
         if (lane == 0) __hip_atomic_fetch_add(&ctl[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // Private paths: a parked pose that turns out to collide is rolled back, and the reward provider then runs for
+        // the OLD pose -- window lookup, way-point scan, distance to the target: five to ten dependent round trips to
+        // memory by one lane at the very end of the step, with the rest of the workgroup idle (C4: the workgroups that
+        // end last all hold such an env).  The mover has nothing to do until its pair's scans are in, so it works that
+        // reward out now for every pose it parked; the verdict then only picks between two finished results.
+        if (PLAIN && !lds_path && !hot_path_shared && a.hot.path_pre && park && !(a.flags & kAblateNoReward)) {
+            const int64_t g = slot_of(SL, i, q);
+            const GlobalPtr<const double> bx = as_global(L.hot.path_bbox) + g * kBoxDoubles;
+            double obox[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) obox[k] = bx[k];
+            const PathWindow ow = path_window(P, obox, SL->path.index + g * (int64_t)(4 * kPathBuckets), q.old.x, q.old.y);
+            const double* opath = SL->path.pts + g * (int64_t)SL->path.max_len * 5;
+            const double reach = fmax(fmax(fabs(obox[0]), fabs(obox[1])), fmax(fabs(obox[2]), fabs(obox[3]))) + P.sp;
+            const int olast = last_reached_prefiltered(P, opath, a.hot.path_pre + g * (int64_t)a.hot.path_max_len * 4, ow, my_len,
+                                                       q.target, q.old.x, q.old.y, q.old.th, reach);
+            double omin = q.min_dist;
+            int otarget = q.target;
+            my_rec->spec_rew = reward_from_last(P, opath, my_len, olast, q.old.x, q.old.y, omin, otarget);
+            my_rec->spec_min = omin;
+            my_rec->spec_target = otarget;
+            my_rec->spec_ok = 1;
+        }
         const int scans = PLAIN ? 3 : 1;
         BOUNDED_POLL(__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[4 + pair], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < scans, poll_expired);
     } else if (scanner && lane == 0) {
@@ -1981,11 +2009,25 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         [[maybe_unused]] int how = 0;
         if (!(a.flags & kAblateNoCoop)) {
             // the lethal cells under the image tested one by one; a map too dense for that is rasterised row by row
+#ifdef BCP_DIAG
+            unsigned long long phase[3] = {test_from, test_from, 0};
+            unsigned long long* const phases = phase;
+#else
+            unsigned long long* const phases = nullptr;
+#endif
             const int verdict = map_words
                 ? coop_collides_sparse<WIDE>(P, (LdsF64)qv, c, s, px, py, (LdsWords)lds_map, a.hot.map_rows, a.hot.map_cols,
-                                             a.hot.map_wpr, cell_list)
+                                             a.hot.map_wpr, cell_list, phases)
                 : coop_collides_sparse<WIDE>(P, (LdsF64)qv, c, s, px, py, as_global(words), a.hot.map_rows, a.hot.map_cols,
-                                             a.hot.map_wpr, cell_list);
+                                             a.hot.map_wpr, cell_list, phases);
+#ifdef BCP_DIAG
+            // wave 8's test: cycles for the edge set-up, for listing the cells, for the rest, and the list's length
+            if (threadIdx.x == 8 * 64 && blockIdx.x < 2048) {
+                const unsigned long long now = DIAG_NOW();
+                g_diag[(2048 + blockIdx.x) * 16 + 13] = ((phase[0] - test_from) << 40) | ((phase[1] - phase[0]) << 20) | (now - phase[1]);
+                g_diag[(2048 + blockIdx.x) * 16 + 15] = phase[2];
+            }
+#endif
             h = verdict == kSparseHit;
             if (verdict == kSparseTooMany)
                 h = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr);
@@ -2039,11 +2081,16 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             }
         }
         if (park) {
-            const bool fits = hit_score && verdict == 2;
+            bool fits = hit_score && verdict == 2;
             if (fits) {
                 sc.min_dist = q.min_dist;
                 sc.target = q.target;
                 sc.rew = reward_from_last(P, lds_path, my_len, last_hit, q.old.x, q.old.y, sc.min_dist, sc.target);
+            } else if (PLAIN && verdict == 2 && my_rec->spec_ok) {   // (private path: worked out ahead, see above)
+                sc.rew = my_rec->spec_rew;
+                sc.min_dist = my_rec->spec_min;
+                sc.target = my_rec->spec_target;
+                fits = true;
             }
             if (!PLAIN) {
 #pragma unroll

@@ -2,6 +2,9 @@
 C2 4096 envs diff-drive shared 64x64;  C4 65536 envs AisleTurn, private 256x256 costmaps + private paths."""
 import sys, os, time, numpy as np, torch
 sys.path.insert(0, '.')
+from bc_gym_planning_env_amd import _lib
+if os.environ.get('BCP_LIB'):   # A/B of kernel variants: another build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ['BCP_LIB'])
 from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
 G = os.path.join('tests', 'golden')
 

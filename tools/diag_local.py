@@ -70,6 +70,13 @@ for k in (0, 1, 2):
     if sel.any():
         print("  longest test of a workgroup, kind %d: %3d workgroups, median %6d  max %6d cycles; those workgroups end after median %6d max %6d" % (
             k, sel.sum(), np.median(dur[sel]), dur[sel].max(), np.median(endw[sel]), endw[sel].max()))
+# wave 8's (last) exact test by phase: edge set-up | listing the lethal cells under the image | filter + cell tests
+ph = upper[had, 13]
+if had.any():
+    setup, listing, rest, cells = ph >> 40, (ph >> 20) & 0xFFFFF, ph & 0xFFFFF, upper[had, 15]
+    print("  exact test of helper wave 8 by phase (cycles): edge set-up median %d p90 %d | cell list median %d p90 %d | filter + tests median %d p90 %d ; cells listed median %d p90 %d max %d" % (
+        np.median(setup), np.percentile(setup, 90), np.median(listing), np.percentile(listing, 90), np.median(rest), np.percentile(rest, 90),
+        np.median(cells), np.percentile(cells, 90), cells.max()))
 # the ten workgroups that end last: where did they lose the time?
 order = np.argsort(-endw)[:10]
 print("  latest workgroups: parked | robot model done, barrier 1, parked, scans in, reward done, decided done, out | longest test (kind)")
