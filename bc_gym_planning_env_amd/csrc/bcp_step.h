@@ -88,15 +88,22 @@ struct StepHot {
     int32_t dynamic_model, model_front_column_pid;
     int32_t noise_slot0;       // alpha1 > 0 or alpha2 > 0: the noise model can consume slot 0 (differential_drive.py:62)
     int32_t pending_cap;
+    // (copies of StepArgs::flags / actions / noise_z / tick: with them here everything step_local_kernel's prologue fetches
+    //  lies in the first five 64-byte lines of the launch arguments instead of being spread over seven -- a cold argument
+    //  fetch costs ~160 cycles per further line, at the very start of every wave)
+    uint32_t io_flags;
+    const void* io_actions;
+    const double* io_noise_z;
+    uint64_t* io_tick;
     // ---- used later in a step
     const uint32_t* near;
     int64_t map_env_stride;
     struct Pending* pending;
 };
 constexpr int kHotStateWords = 11 * 2;                                   // x .. collided
-constexpr int kHotPrologueWords = (10 * 8 + 17 * 4) / 4;                // n .. pending_cap
+constexpr int kHotPrologueWords = (10 * 8 + 18 * 4 + 3 * 8) / 4;        // n .. io_tick
 static_assert(offsetof(DevState, collided) == 10 * 8 && offsetof(StepHot, st) == 0, "x .. collided lead DevState");
-static_assert(offsetof(StepHot, pending_cap) + 4 - offsetof(StepHot, n) == kHotPrologueWords * 4, "the prologue block of StepHot");
+static_assert(offsetof(StepHot, io_tick) + 8 - offsetof(StepHot, n) == kHotPrologueWords * 4, "the prologue block of StepHot");
 
 constexpr int kShards = 64;  // a wave parks into shard (block index % kShards)
 
@@ -1127,6 +1134,7 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
     const LdsF64 lds_path = a.hot.lds_path_doubles ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
     __attribute__((address_space(3))) double* hand_pose = qv + nq + a.hot.lds_path_doubles;
     __attribute__((address_space(3))) double* hand_score = hand_pose + 3 * kBlock;
+    __attribute__((address_space(3))) double* hand_heading = hand_pose + 6 * kBlock;
     __attribute__((address_space(3))) double* lds_box = hand_score + 3 * kBlock;                    // [8]
     __attribute__((address_space(3))) uint32_t* lds_index = (__attribute__((address_space(3))) uint32_t*)(lds_box + 8);  // [128]
     if (!mover && a.hot.path_shared) {
@@ -1346,6 +1354,7 @@ typedef const __attribute__((address_space(4))) StepArgs& KernArgs;   // the lau
                                                                       // demand instead of ~500 bytes pinned in SGPRs
 
 constexpr int kScanItems = 1024;       // candidates of a pair's 64 envs that the flat scan list holds (bytes of LDS)
+constexpr int kHandDoubles = 8;   // per pair and env: pose [3], score / noise [3], cos / sin of the old heading [2]
 constexpr int kLocalMapWords = 4096;   // a shared lethal bitmap of up to 16 KB is staged in LDS for the exact tests
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1353,7 +1362,7 @@ constexpr int kStaticChunks = (int)((sizeof(StepStatic) + 15) / 16);   // *S in 
 
 static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles, int staged_map_words, bool plain = true)
 {
-    size_t bytes = ((size_t)2 * n_verts + lds_path_doubles + (size_t)kLocalPairs * 6 * kBlock + 8) * sizeof(double);
+    size_t bytes = ((size_t)2 * n_verts + lds_path_doubles + (size_t)kLocalPairs * kHandDoubles * kBlock + 8) * sizeof(double);
     bytes += 2 * kBlock * sizeof(uint32_t);          // bucket index of the shared path
     bytes += 16 * sizeof(int32_t);                   // parked count, ticket counter, movers parked, -, scans done per pair [4], scan lists ready per pair [4], - [4]
     bytes = (bytes + 15) & ~(size_t)15;
@@ -1441,24 +1450,18 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     PrologueArgs L;
     {
         constexpr int kStateWords = PLAIN ? kHotStateWords : (int)(sizeof(DevState) / 4);
-        uint32_t w_st[kStateWords], w_hot[kHotPrologueWords], w_io[4], w_tick[2], w_flags[1];
+        uint32_t w_st[kStateWords], w_hot[kHotPrologueWords];
         fetch_words(&a.hot.st, w_st);
         fetch_words(&a.hot.n, w_hot);
-        fetch_words(&a.actions, w_io);          // actions, noise_z
-        fetch_words(&a.tick, w_tick);
-        fetch_words(&a.flags, w_flags);
         pin_words(w_st);
         pin_words(w_hot);
-        pin_words(w_io);
-        pin_words(w_tick);
-        pin_words(w_flags);
         __builtin_memset(&L.hot, 0, sizeof(L.hot));
         __builtin_memcpy(&L.hot.st, w_st, sizeof(w_st));
         __builtin_memcpy(&L.hot.n, w_hot, sizeof(w_hot));
-        __builtin_memcpy(&L.actions, &w_io[0], 8);
-        __builtin_memcpy(&L.noise_z, &w_io[2], 8);
-        __builtin_memcpy(&L.tick, w_tick, 8);
-        L.flags = w_flags[0];
+        L.actions = L.hot.io_actions;
+        L.noise_z = L.hot.io_noise_z;
+        L.tick = L.hot.io_tick;
+        L.flags = L.hot.io_flags;
         L.S = a.S;   // (not pinned: a pointer that went through the asm is no longer known to be uniform, nor global)
     }
     const int hot_n_verts = L.hot.n_verts, hot_npath = L.hot.lds_path_doubles, hot_path_shared = L.hot.path_shared;
@@ -1477,12 +1480,13 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     const int nq = 2 * hot_n_verts;
     const int npath = hot_npath;
     const LdsF64 lds_path = npath ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
-    __attribute__((address_space(3))) double* hand_pose = qv + nq + npath + pair * 6 * kBlock;
+    __attribute__((address_space(3))) double* hand_pose = qv + nq + npath + pair * kHandDoubles * kBlock;
     __attribute__((address_space(3))) double* hand_score = hand_pose + 3 * kBlock;
-    __attribute__((address_space(3))) double* lds_box = qv + nq + npath + kLocalPairs * 6 * kBlock;   // [8]
+    __attribute__((address_space(3))) double* hand_heading = hand_pose + 6 * kBlock;
+    __attribute__((address_space(3))) double* lds_box = qv + nq + npath + kLocalPairs * kHandDoubles * kBlock;   // [8]
     __attribute__((address_space(3))) uint32_t* lds_index = (__attribute__((address_space(3))) uint32_t*)(lds_box + 8);  // [128]
     __attribute__((address_space(3))) int32_t* ctl = (__attribute__((address_space(3))) int32_t*)(lds_index + 2 * kBlock);   // [16]
-    const uint32_t rec_off = (uint32_t)((((size_t)(nq + npath + kLocalPairs * 6 * kBlock + 8) * sizeof(double) +
+    const uint32_t rec_off = (uint32_t)((((size_t)(nq + npath + kLocalPairs * kHandDoubles * kBlock + 8) * sizeof(double) +
                                           2 * kBlock * sizeof(uint32_t) + 16 * sizeof(int32_t)) + 15) & ~(size_t)15);
     __attribute__((address_space(3))) ParkedPose* rec =
         (__attribute__((address_space(3))) ParkedPose*)((__attribute__((address_space(3))) char*)lds_dyn + rec_off);
@@ -1567,30 +1571,14 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
 #pragma unroll
         for (int u = 0; u < 7; ++u) rc[u] = pc[u];
     }
-    // (2) every wave's share of the staging data, into registers: footprint vertices, the shared path with its bounding
-    //     box and bucket index, the shared lethal bitmap (<= 4 words per thread), the parameter block *S (16 bytes per thread
-    //     of the last two waves)
-    //     (with delay queues a mover already holds ten more values in flight: it fetches its share of the staging data
-    //      behind the first half of the robot model instead -- a second round trip for it, but no register spills)
-    const bool stage_early = PLAIN || !mover;
+    // (2) the parameter block *S (16 bytes per thread of the last two waves) is the only staging data anybody needs before
+    //     barrier 1: the mover's second half reads its parameters from the LDS copy.  Footprint vertices, the shared path with
+    //     its bounding box and bucket index and the shared lethal bitmap are first read behind barrier 1, so the waves that
+    //     idle between the barriers fetch and store them there (below) -- a prologue that also addressed and issued ~8 staging
+    //     loads per thread kept the SIMDs busy for 1 - 2 k cycles before the movers' own loads were even issued.
+    //     (issued FIRST by those two waves it was measured slower, 11.75 against 11.70 us: it then competes with the movers' loads)
     u32x4 st_static = {0u, 0u, 0u, 0u};
     if (tid >= 896 && tid < 896 + kStaticChunks) st_static = as_global(reinterpret_cast<const u32x4*>(a.S))[tid - 896];
-    double st_q = 0.0, st_path = 0.0, st_box = 0.0;
-    uint32_t st_index = 0;
-    uint32_t st_map[kLocalMapWords / (kLocalWaves * kBlock)] = {};
-    if (stage_early) {
-        if (tid < nq) st_q = as_global(L.hot.qverts)[tid];
-        if (tid < npath) st_path = as_global(L.hot.path_pts)[tid];
-        if (hot_path_shared) {
-            if (tid >= 512 && tid < 520) st_box = as_global(L.hot.path_bbox)[tid - 512];
-            if (tid >= 576 && tid < 576 + 128) st_index = as_global(reinterpret_cast<const uint32_t*>(L.hot.path_index))[tid - 576];
-        }
-#pragma unroll
-        for (int u = 0; u < kLocalMapWords / (kLocalWaves * kBlock); ++u) {
-            const int k = u * kLocalWaves * kBlock + tid;
-            if (k < map_words) st_map[u] = as_global(L.hot.map_bits)[k];
-        }
-    }
     DIAG_STAMP_U(0, 10);   // mover: own + staging loads issued
     DIAG_STAMP_U(4, 11);   // scorer: the same
     DIAG_STAMP_WAVES(1280);   // every wave: prologue loads issued
@@ -1599,6 +1587,9 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     // (5) what needs no pose.  The odometry noise of this step needs nothing but seed, env id and step counter: Philox +
     //     float64 Box-Muller.  Slots 1 and 2 -- the ones PlanEnv's noise model draws -- are the two halves of one pair
     //     (device_normals): the scorer draws them; slot 0, when the model can consume it at all, the pair's second helper;
+    //     (Splitting the pair -- radius on the scorer, direction on a helper, both running the Philox block -- was measured
+    //      in round 3: the second copy of the generator costs the SIMD more issue slots than the shorter chain wins,
+    //      11.87 - 12.0 against 11.72 us per step.)
     if (noise_by_waves && scorer) {
         double z1, z2;
         device_normals_12(seed, (uint64_t)(L.hot.env_id_base + i), step_counter, z1, z2);
@@ -1607,14 +1598,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         DIAG_STAMP_U(4, 1);   // scorer: noise drawn
     }
     if (noise_by_waves && member == 2) hand_score[lane] = L.hot.noise_slot0 ? device_normal_0(seed, (uint64_t)(L.hot.env_id_base + i), step_counter) : 0.0;
-    //     the first helper cos / sin of the OLD heading, which the robot model needs at its very end (path_velocity);
-    if (!mover && member == 1) {
-        double c0, s0;
-        cos_sin(old_angle, c0, s0);
-        hand_pose[lane] = c0;
-        hand_pose[kBlock + lane] = s0;
-        DIAG_STAMP_U(8, 2);   // helper: cos / sin of the old heading
-    }
+    //     (the first helper's cos / sin of the OLD heading is needed behind barrier 1 only: it follows barrier 0)
     //     the mover the first half of the robot model (_env_step, envs/base/env.py:442-461): front-wheel column, cos / sin
     //     of the new wheel angle, velocity model
     Robot& r = q.r;
@@ -1651,29 +1635,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             for (int k = 0; k < 7; ++k) fifo_stash[(3 + k) * kLocalEnvs] = q.popped_state[k];
         }
     }
-    // (6) staging data into LDS
-    if (!stage_early) {   // (movers of a configuration with delay queues: see (2); tid < 256)
-        if (tid < nq) st_q = as_global(a.hot.qverts)[tid];
-        if (tid < npath) st_path = as_global(a.hot.path_pts)[tid];
-#pragma unroll
-        for (int u = 0; u < kLocalMapWords / (kLocalWaves * kBlock); ++u) {
-            const int k = u * kLocalWaves * kBlock + tid;
-            if (k < map_words) st_map[u] = as_global(a.hot.map_bits)[k];
-        }
-    }
-    if (tid < nq) qv[tid] = st_q;
-    if (tid < npath) qv[nq + tid] = st_path;
-    for (int k = kLocalWaves * kBlock + tid; k < npath; k += kLocalWaves * kBlock) qv[nq + k] = as_global(L.hot.path_pts)[k];   // (long paths)
-    if (hot_path_shared) {
-        if (tid >= 512 && tid < 520) lds_box[tid - 512] = st_box;
-        if (tid >= 576 && tid < 576 + 128) lds_index[tid - 576] = st_index;
-    }
+    // (6) the parameter block into LDS
     if (tid >= 960 && tid < 976) ctl[tid - 960] = 0;
-#pragma unroll
-    for (int u = 0; u < kLocalMapWords / (kLocalWaves * kBlock); ++u) {
-        const int k = u * kLocalWaves * kBlock + tid;
-        if (k < map_words) lds_map[k] = st_map[u];   // (read after the barriers)
-    }
     if (tid >= 896 && tid < 896 + kStaticChunks) lds_static[tid - 896] = st_static;
     DIAG_STAMP_WAVES(1024);
     __syncthreads();   // barrier 0: noise, old heading and the parameter block are in LDS
@@ -1683,7 +1646,6 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     // (7) mover: the second half of the robot model; the pose the reward provider will see goes to the scanning waves
     Pose new_pose;
     new_pose.x = new_pose.y = new_pose.th = 0.0;
-    double heading_c0 = 0.0, heading_s0 = 0.0;
     if (mover) {
         if (noise_by_waves) {
             q.z[0] = hand_score[lane];
@@ -1691,29 +1653,64 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             q.z[2] = hand_score[2 * kBlock + lane];
         }
         DIAG_STAMP(1);   // (the compiler may move loads across this: indicative only)
-        KnownHeading old_heading;   // (from the helper wave, barrier 0)
-        old_heading.c0 = hand_pose[lane];
-        old_heading.s0 = hand_pose[kBlock + lane];
-        old_heading.known = true;
         if (!PLAIN) drive = robot_step_begin(P, r, cmd0, cmd1);
         // the new pose goes out as soon as it exists; the measured velocities (path_velocity: a square root, two divisions)
         // are the mover's own business, behind barrier 1
         new_pose = robot_step_pose(P, r, drive, q.z, q.drawn);
-        heading_c0 = old_heading.c0;
-        heading_s0 = old_heading.s0;
         const bool delayed = !PLAIN && P.pose_delay > 0 && q.iter + 1 > 1;
         hand_pose[lane] = delayed ? fifo_stash[0] : new_pose.x;
         hand_pose[kBlock + lane] = delayed ? fifo_stash[kLocalEnvs] : new_pose.y;
         hand_pose[2 * kBlock + lane] = delayed ? fifo_stash[2 * kLocalEnvs] : new_pose.th;
         DIAG_STAMP(2);
     }
+    // (7a) the first helper: cos / sin of the OLD heading, which the robot model needs at its very end (path_velocity, behind
+    //      barrier 1) -- before barrier 0 it made its wave the last one to arrive there
+    if (!mover && member == 1) {
+        double c0, s0;
+        cos_sin(old_angle, c0, s0);
+        hand_heading[lane] = c0;
+        hand_heading[kBlock + lane] = s0;
+        DIAG_STAMP_U(8, 2);   // helper: cos / sin of the old heading
+    }
+    // (7b) everybody else stages what is read behind barrier 1: loads first, all of them in flight together, then the stores
+    if (!mover) {
+        constexpr int kStagers = (kLocalWaves - kLocalPairs) * kBlock;            // 768 threads
+        constexpr int kMapPerStager = (kLocalMapWords + kStagers - 1) / kStagers;   // 6 words each
+        const int nm = tid - kLocalPairs * kBlock;
+        double st_q = 0.0, st_path = 0.0, st_box = 0.0;
+        uint32_t st_index = 0;
+        uint32_t st_map[kMapPerStager] = {};
+        if (nm < nq) st_q = as_global(L.hot.qverts)[nm];
+        if (nm < npath) st_path = as_global(L.hot.path_pts)[nm];
+        if (hot_path_shared) {
+            if (nm >= 256 && nm < 264) st_box = as_global(L.hot.path_bbox)[nm - 256];
+            if (nm >= 320 && nm < 320 + 128) st_index = as_global(reinterpret_cast<const uint32_t*>(L.hot.path_index))[nm - 320];
+        }
+#pragma unroll
+        for (int u = 0; u < kMapPerStager; ++u) {
+            const int k = u * kStagers + nm;
+            if (k < map_words) st_map[u] = as_global(L.hot.map_bits)[k];
+        }
+        if (nm < nq) qv[nm] = st_q;
+        if (nm < npath) qv[nq + nm] = st_path;
+        for (int k = kStagers + nm; k < npath; k += kStagers) qv[nq + k] = as_global(L.hot.path_pts)[k];   // (long paths)
+        if (hot_path_shared) {
+            if (nm >= 256 && nm < 264) lds_box[nm - 256] = st_box;
+            if (nm >= 320 && nm < 320 + 128) lds_index[nm - 320] = st_index;
+        }
+#pragma unroll
+        for (int u = 0; u < kMapPerStager; ++u) {
+            const int k = u * kStagers + nm;
+            if (k < map_words) lds_map[k] = st_map[u];
+        }
+    }
     DIAG_STAMP_WAVES(1536);
     __syncthreads();
     DIAG_STAMP(3);
     if (mover) {
-        KnownHeading old_heading;
-        old_heading.c0 = heading_c0;
-        old_heading.s0 = heading_s0;
+        KnownHeading old_heading;   // (from the first helper wave, barrier 1)
+        old_heading.c0 = hand_heading[lane];
+        old_heading.s0 = hand_heading[kBlock + lane];
         old_heading.known = true;
         q.err = robot_step_measure(P, r, new_pose, old_heading);
     }

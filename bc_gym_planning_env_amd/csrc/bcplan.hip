@@ -1706,6 +1706,10 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
             }
         }
         a.flags |= kStepAdvances;
+        hot.io_flags = a.flags;   // (the prologue's copies, next to the rest of what it fetches)
+        hot.io_actions = a.actions;
+        hot.io_noise_z = a.noise_z;
+        hot.io_tick = a.tick;
         const dim3 grid((unsigned)((h->n + kLocalEnvs - 1) / kLocalEnvs)), block(kLocalWaves * kBlock);
         switch (variant) {
             case 3: hipLaunchKernelGGL((step_local_kernel<true, true>), grid, block, lds, s, a); break;
