@@ -1590,6 +1590,11 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     //     (Splitting the pair -- radius on the scorer, direction on a helper, both running the Philox block -- was measured
     //      in round 3: the second copy of the generator costs the SIMD more issue slots than the shorter chain wins,
     //      11.87 - 12.0 against 11.72 us per step.)
+    //     (So was drawing the NEXT step's pair at the end of a step, when the scorers idle, and fetching it here with a key
+    //      {seed, step, env base}: the noise is then ready 0.9 k cycles earlier, but the ten extra loads in the scorers'
+    //      prologue hold up everybody's own loads -- the movers reached barrier 0 0.4 k cycles LATER; 11.7 against 11.56 us.
+    //      And fetching the scanners' target index / path box and the helper's old heading behind barrier 0 instead of
+    //      here: 11.63 against 11.51 us.)
     if (noise_by_waves && scorer) {
         double z1, z2;
         device_normals_12(seed, (uint64_t)(L.hot.env_id_base + i), step_counter, z1, z2);

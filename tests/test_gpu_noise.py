@@ -91,3 +91,11 @@ def test_step_consumes_the_stream_it_reports(torch_cuda):
         assert torch.equal(zout[used], out[t][used])
         drawn += int(used.sum())
     assert drawn > 6 * n   # (slot 0 is never drawn with PlanEnv's alphas; slots 1 and 2 are once the robot moves)
+    # a new seed restarts the stream, and so does the same seed again
+    for seed in (78, 78):
+        env.seed(seed)
+        _lib.check(env._lib.bcp_device_normals(env._h, 0, n, 0, 3, out.data_ptr(), None))
+        for t in range(3):
+            env.step(env.action_space.sample_batch(n, rng), noise_z_out=zout)
+            used = ~torch.isnan(zout)
+            assert torch.equal(zout[used], out[t][used]), (seed, t)
