@@ -320,7 +320,7 @@ def aux_measurements(env, pool, n):
     out["egocentric_observation"] = {
         "what": "EgocentricCostmap.observation for every env: %d x %d px uint8 + goal_n_state (envs/egocentric.py:102-160)"
                 % wrap.image_shape,
-        "kernel": "ego_costmap_kernel", "ms_per_call": ms, "bytes_written_per_call": img_bytes,
+        "kernel": "ego_sparse_kernel (zero fill + one patch per non-zero source cell; ego_costmap_kernel for maps that do not qualify)", "ms_per_call": ms, "bytes_written_per_call": img_bytes,
         "roofline": {"bound": "hbm", "achieved": img_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": img_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "step_plus_observation_ms": ms_both, "env_steps_per_s_with_observation": n / (ms_both * 1e-3)}
