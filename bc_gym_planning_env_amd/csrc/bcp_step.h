@@ -7,6 +7,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <type_traits>
 
 #include "bcp_device.h"
 #include "bcp_raster.h"
@@ -396,22 +397,25 @@ __device__ __forceinline__ int last_reached_from(const DevParams& P, PathPtr pat
 
 // way points in global memory (private / pooled paths, cold after the kernel boundary): four candidates are fetched
 // together, so the scan pays one memory round trip per four way points instead of one each
+// (TRIP candidates per round trip: four hold 40 vector registers while they are in flight -- where the caller is short of
+//  registers, the finishing code of the configurations with delay queues, two)
+template <int TRIP = 4>
 __device__ __forceinline__ int last_reached_from(const DevParams& P, const double* __restrict__ path, PathWindow w, int m,
                                                  int target, double x, double y, double th)
 {
     if (target > m - 1) return -1;
     const int lo = max(w.lo, target);
     const int hi = min(w.hi, m - 1);
-    for (int j = hi; j >= lo; j -= 4) {
-        double v[4][5];
+    for (int j = hi; j >= lo; j -= TRIP) {
+        double v[TRIP][5];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < TRIP; ++u) {
             const double* s = path + 5 * max(j - u, lo);   // (below lo: a harmless repeat of way point lo)
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[u][k] = s[k];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < TRIP; ++u)
             if (j - u >= lo && way_point_reached(P, v[u][0], v[u][1], v[u][2], v[u][3], v[u][4], x, y, th)) return j - u;
     }
     return -1;
@@ -473,12 +477,14 @@ __device__ __forceinline__ int last_reached_prefiltered(const DevParams& P, cons
     return -1;
 }
 
-template <typename PathPtr>
+template <int TRIP = 4, typename PathPtr>
 __device__ __forceinline__ double reward_step(const DevParams& P, PathPtr path, PathWindow w, int m, double x, double y,
                                               double th, double& min_dist, int& target)
 {
     if (target > m - 1) return 0.0;
-    const int last = last_reached_from(P, path, w, m, target, x, y, th);
+    int last;
+    if constexpr (std::is_same<PathPtr, const double*>::value) last = last_reached_from<TRIP>(P, path, w, m, target, x, y, th);
+    else last = last_reached_from(P, path, w, m, target, x, y, th);
     if (last >= 0) {
         target = last + 1;
         if (!(target > m - 1)) {
@@ -884,7 +890,7 @@ __device__ __forceinline__ void finalize_env_from(const A& a, SP S, int64_t i, P
             if (lds_path && S->path.shared)  // way points staged in LDS by the step kernel
                 rew = reward_step(P, lds_path, w, m, seen[0], seen[1], seen[2], min_dist, target);
             else
-                rew = reward_step(P, pts, w, m, seen[0], seen[1], seen[2], min_dist, target);
+                rew = reward_step<PLAIN ? 4 : 2>(P, pts, w, m, seen[0], seen[1], seen[2], min_dist, target);
         }
         goal = target > m - 1;
     }
