@@ -465,16 +465,20 @@ def run_rank(args):
     # than MIN_REGION_MS is no instrument -- at the driver's --steps 20 it lasts 0.3 ms and one host synchronisation is
     # 9 % of it -- so the timed region repeats the block `reps` times back to back; `steps` stays what was asked for,
     # ms_per_step and value are per step.  Every rank uses the same `reps` (MAX of the probes).
+    # (the probe's first block only fills the launch queue -- timed from a standing start it reads up to 20 % slow, and
+    #  the region then ends before MIN_REGION_MS --, its second block is the one that is timed; 10 % on top)
     probe = max(1, min(args.steps, 32))
     barrier()
-    ev0.record(stream)
     for k in range(probe):
         one_step(k0 + k)
+    ev0.record(stream)
+    for k in range(probe):
+        one_step(k0 + probe + k)
     ev1.record(stream)
-    k0 += probe
+    k0 += 2 * probe
     drain()
     probe_ms = max_over_ranks(ev0.elapsed_time(ev1) / probe)
-    reps = args.reps if args.reps > 0 else int(min(8192, max(1, np.ceil(MIN_REGION_MS / max(probe_ms * args.steps, 1e-6)))))
+    reps = args.reps if args.reps > 0 else int(min(8192, max(1, np.ceil(1.1 * MIN_REGION_MS / max(probe_ms * args.steps, 1e-6)))))
     k0 = (k0 + gather_every - 1) // gather_every * gather_every   # (the ring starts the region at row 0)
     total = reps * args.steps
 
