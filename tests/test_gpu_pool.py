@@ -458,12 +458,18 @@ def test_near_tiles_by_dilation_vs_thresholded_field(torch_cuda, density):
     maps[half + 1, :, 0] = maps[half + 1, 0, :] = 254
     maps[half + 2, :, -1] = maps[half + 2, -1, :] = 254
     dmap = torch.from_numpy(maps).cuda()
-    env.set_tuning(near_dilate=0)
-    env.set_costmap_tensors(dmap, env._keep["origins"], env.resolution)
-    want, t_out = env.near_field(0, g_n, raw=True)
-    cells = env.near_field(0, g_n)[0]
-    assert torch.equal(cells, env.distance_field(0, g_n)[0] < t_out) and bool(cells.any()) and not bool(cells.all())
-    env.set_tuning(near_dilate=2)
-    env.set_costmap_tensors(dmap, env._keep["origins"], env.resolution)
-    got, t2 = env.near_field(0, g_n, raw=True)
-    assert t2 == t_out and torch.equal(got, want)
+    radii, base_res = set(), env.resolution
+    for scale in (1.0, 4.0, 0.6, 0.45):   # the same cells read at other resolutions: other radii of the sample disc (t_out)
+        res = base_res * scale
+        env.set_tuning(near_dilate=0)
+        env.set_costmap_tensors(dmap, env._keep["origins"], res)
+        want, t_out = env.near_field(0, g_n, raw=True)
+        cells = env.near_field(0, g_n)[0]
+        assert torch.equal(cells, env.distance_field(0, g_n)[0] < t_out) and bool(cells.any())
+        assert density > 0.1 or not bool(cells.all())
+        env.set_tuning(near_dilate=2)
+        env.set_costmap_tensors(dmap, env._keep["origins"], res)
+        got, t2 = env.near_field(0, g_n, raw=True)
+        assert t2 == t_out and torch.equal(got, want), (scale, t_out)
+        radii.add(t_out)
+    assert len(radii) >= 3 and min(radii) <= 10 and max(radii) >= 24, radii
