@@ -1140,7 +1140,6 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
     const LdsF64 lds_path = a.hot.lds_path_doubles ? (LdsF64)(qv + nq) : (LdsF64) nullptr;
     __attribute__((address_space(3))) double* hand_pose = qv + nq + a.hot.lds_path_doubles;
     __attribute__((address_space(3))) double* hand_score = hand_pose + 3 * kBlock;
-    __attribute__((address_space(3))) double* hand_heading = hand_pose + 6 * kBlock;
     __attribute__((address_space(3))) double* lds_box = hand_score + 3 * kBlock;                    // [8]
     __attribute__((address_space(3))) uint32_t* lds_index = (__attribute__((address_space(3))) uint32_t*)(lds_box + 8);  // [128]
     if (!mover && a.hot.path_shared) {
