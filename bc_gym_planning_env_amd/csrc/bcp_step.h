@@ -1814,6 +1814,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             }
             if (total <= kScanItems) {
                 // (the scorer, who has just made the list, takes the LAST share of every round: 64 * (3 r + 2) ...)
+                // (the scorer taking the FIRST share -- on the metric workload the only one that is not empty -- straight after
+                //  building the list: 11.64 against 11.54 us, round 3)
                 for (int base = 64 * ((member + 2) % 3); base < total; base += 64 * 3) {
                     const int k = base + lane;
                     if (k < total) {
