@@ -13,7 +13,7 @@ Workload (BASELINE.json configs[2], "C3"): 65 536 replicas per GPU of the Random
 183x183 uint8 costmap, shared refined path), tricycle dynamic model with PlanEnv's odometry noise drawn on the
 device (Philox4x32-10), float32 actions ~ U(action_space) pre-staged in HBM, reset-on-done inside the kernel.
 A "step" is one pass of the hot path over all envs of the rank.  With N > 1 ranks the env index space is sharded in
-contiguous blocks (weak scaling); the done masks go into a device-side ring that is all-gathered every 8 steps.
+contiguous blocks (weak scaling); the done masks go into a device-side ring that is all-gathered once per 128-step rollout.
 
 Timed region: barrier + synchronize, then `reps` x `--steps` steps back to back, then every rank drains ITS OWN stream
 and gathers and stops its clock (the closing barrier comes after and is not timed); `reps` is chosen so that the region
@@ -36,6 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 65536
+GATHER_EVERY = 128        # multi-GPU: the done masks of this many steps travel in one all-gather (see run_rank): one
+                          # rollout of the reference's PPO runner (StepEnvRoller number_of_steps=128, scripts/rl_runners/ppo_runner.py:69)
 MIN_REGION_MS = 50.0     # the timed region lasts at least this long (see run_rank: reps)
 # ALGORITHMIC bytes per env-step (DESIGN.md "Bytes"): SoA state in + out (7 f64 robot + min_dist f64 +
 # target_idx i32 + current_iter i32 + robot_collided u8 = 73 B each way) + action 2 x f32 + reward f64 + done u8.
@@ -402,10 +404,14 @@ def run_rank(args):
     env, g = make_env(n, device, env_id_base=rank * n, seed=2024)
     sharded = dist.is_initialized()     # world > 1, or a forced group at world size 1 (BCP_DIST_FORCE=1)
     backend = dist.get_backend() if sharded else None
-    # Multi-GPU: the only cross-rank traffic is the done mask.  Every rank writes its mask of step k into row k % 8 of a
-    # ring (the step kernel stores it there directly) and the ring is all-gathered every 8 steps, asynchronously
-    # (the gather of one block of 8 steps overlaps the kernels of the next): 1/8 collective per step.
-    gather_every = 8
+    # Multi-GPU: the only cross-rank traffic is the done mask.  Every rank writes its mask of step k into row k % R of a
+    # ring (the step kernel stores it there directly) and the ring is all-gathered every R steps, asynchronously (the
+    # gather of one block overlaps the kernels of the next).  R = 128: the consumer the reference itself has, its PPO
+    # runner, collects 128 steps per rollout before it looks at anything (ppo_runner.py:69).  One gather costs ~31 us of
+    # launch work on the host and of stream time whatever it carries (measured with the RCCL branch forced at world size 1:
+    # R = 8 15.4 us per step, 32 12.6, 128 11.9, no group at all 11.55), so a short ring would measure the collective's
+    # launch, not the step.  The rows of an unfinished block are gathered at the end of the timed region, inside it.
+    gather_every = max(1, int(args.gather_every))
     ring = torch.zeros(gather_every, n, dtype=torch.uint8, device=torch.device("cuda", device)) if sharded else None
     gather = bdist.DoneGather(gather_every * n, torch.device("cuda", device)) if sharded else None
     if sharded:
@@ -491,6 +497,8 @@ def run_rank(args):
     ev0.record(stream)
     for k in range(total):
         one_step(k0 + k)
+    if gather is not None and total % gather_every:   # (the rows of the last, unfinished block)
+        gather.launch(ring.view(-1))
     ev1.record(stream)
     drain()
     elapsed_local = time.perf_counter() - t0
@@ -538,8 +546,8 @@ def run_rank(args):
                                    "odometry noise (on-device Philox), shared 183x183 costmap, reset on done, steady-state episode phases" % n,
                        "envs_total": total_envs, "envs_per_gpu": n, "actions": "float32 U(action_space), pre-staged",
                        "sharding": ("env blocks per rank, done masks ring-buffered on the device and all-gathered (%s) every "
-                                    "8 steps, overlapped with the next steps"
-                                    % ("RCCL" if backend == "nccl" else "gloo through the host: REHEARSAL transport, not a scaling number"))
+                                    "%d steps, overlapped with the next steps"
+                                    % ("RCCL" if backend == "nccl" else "gloo through the host: REHEARSAL transport, not a scaling number", gather_every))
                        if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -576,6 +584,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--reps", type=int, default=0, help="repeat the block of --steps steps this many times inside the "
                     "timed region (default: as many as make the region last %.0f ms)" % MIN_REGION_MS)
+    ap.add_argument("--gather-every", type=int, default=GATHER_EVERY, help="multi-GPU: steps between two all-gathers of the done-mask ring")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the informational legs (observation, pools, C2 / C4)")
     args = ap.parse_args()

@@ -1,6 +1,6 @@
 """One rank of the CPU rehearsal of bench.py's launcher at the world size the driver uses (8): started by
 bench.spawn_ranks (RANK / WORLD_SIZE / MASTER_* in the environment), rendezvous over gloo, then the done-mask ring of
-bench.py -- a mask per step into row k % 8, the ring all-gathered every 8 steps, results one launch late -- with masks
+bench.py -- a mask per step into row k % R, the ring all-gathered every R steps (R = 8 here, 128 in bench.py), results one launch late -- with masks
 derived from the GLOBAL env index so that every rank can check what it gathered.  No GPU, no env: plumbing only.
 Rank 0 prints one JSON line."""
 import json
