@@ -91,6 +91,8 @@ SYMBOLS = {
     "bcp_path_velocity": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcp_pixel_footprint": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int32, C.c_void_p,
                                       C.c_void_p]),
+    "bcp_pack_mask_bits": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bcp_unpack_mask_bits": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "bcp_normalize_angle": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "bcp_world_to_pixel": (C.c_int, [_H, C.c_void_p, C.c_int64, _f64p, C.c_double, C.c_void_p, C.c_void_p]),
     "bcp_egocentric_shape": (C.c_int, [_H, _f64p, _i32p]),

@@ -1975,6 +1975,49 @@ extern "C" int bcp_pixel_footprint(bcp_handle* h, const double* angles, int64_t 
     return BCP_OK;
 }
 
+// done masks as bits: word w, bit b = mask[32 w + b] != 0 (a sharded job sends its masks over xGMI in this form)
+__global__ void pack_mask_bits_kernel(const uint8_t* __restrict__ mask, int64_t n, uint32_t* __restrict__ bits)
+{
+    const int64_t words = (n + 31) / 32;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t word = 0;
+        if (32 * w + 32 <= n && ((uintptr_t)(mask + 32 * w) & 15) == 0) {
+            const uint4* src = reinterpret_cast<const uint4*>(mask + 32 * w);
+            const uint4 lo = src[0], hi = src[1];
+            const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) word |= (uint32_t)(((q[k] >> (8 * j)) & 255u) != 0) << (4 * k + j);
+        } else {
+            for (int b = 0; b < 32 && 32 * w + b < n; ++b) word |= (uint32_t)(mask[32 * w + b] != 0) << b;
+        }
+        bits[w] = word;
+    }
+}
+
+__global__ void unpack_mask_bits_kernel(const uint32_t* __restrict__ bits, int64_t n, uint8_t* __restrict__ mask)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        mask[i] = (uint8_t)((bits[i >> 5] >> (i & 31)) & 1u);
+}
+
+extern "C" int bcp_pack_mask_bits(const uint8_t* mask, int64_t n, uint32_t* bits, void* stream)
+{
+    if (!mask || !bits || n <= 0) return fail(BCP_E_INVALID, "bcp_pack_mask_bits: bad argument");
+    hipLaunchKernelGGL(pack_mask_bits_kernel, dim3(stride_grid((n + 31) / 32, 256)), dim3(256), 0, (hipStream_t)stream, mask, n, bits);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
+extern "C" int bcp_unpack_mask_bits(const uint32_t* bits, int64_t n, uint8_t* mask, void* stream)
+{
+    if (!mask || !bits || n <= 0) return fail(BCP_E_INVALID, "bcp_unpack_mask_bits: bad argument");
+    hipLaunchKernelGGL(unpack_mask_bits_kernel, dim3(stride_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, bits, n, mask);
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
+}
+
 extern "C" int bcp_normalize_angle(bcp_handle* h, const double* in, double* out, int64_t n, void* stream)
 {
     if (!h || !in || !out || n <= 0) return fail(BCP_E_INVALID, "bcp_normalize_angle: bad argument");

@@ -68,21 +68,65 @@ def local_device(local_rank):
     return local_rank % max(1, torch.cuda.device_count())
 
 
+def _native(t):
+    """libbcplan for device tensors (bcp_pack_mask_bits / bcp_unpack_mask_bits: one pass); tensor arithmetic on the CPU"""
+    if not t.is_cuda:
+        return None
+    from . import _lib
+    return _lib.load()
+
+
+def pack_mask_bits(mask, out=None):
+    """uint8 mask [8 k] (non-zero = set) -> uint8 [k]: bit b of byte j = mask[8 j + b] (include/bcplan.h: bcp_pack_mask_bits)."""
+    lib = _native(mask)
+    if lib is not None and mask.numel() % 32 == 0 and mask.is_contiguous():
+        from . import _lib
+        if out is None:
+            out = torch.empty(mask.numel() // 8, dtype=torch.uint8, device=mask.device)
+        _lib.check(lib.bcp_pack_mask_bits(mask.data_ptr(), mask.numel(), out.data_ptr(),
+                                          torch.cuda.current_stream(mask.device).cuda_stream))
+        return out
+    w = (1 << torch.arange(8, device=mask.device, dtype=torch.int32)).to(torch.uint8)
+    bits = ((mask.view(-1, 8) != 0).to(torch.uint8) * w).sum(dim=1, dtype=torch.uint8)
+    return bits if out is None else out.copy_(bits)
+
+
+def unpack_mask_bits(bits):
+    """inverse of pack_mask_bits: uint8 [k] -> uint8 mask [8 k] of zeros and ones"""
+    lib = _native(bits)
+    if lib is not None and bits.numel() % 4 == 0 and bits.is_contiguous():
+        from . import _lib
+        out = torch.empty(bits.numel() * 8, dtype=torch.uint8, device=bits.device)
+        _lib.check(lib.bcp_unpack_mask_bits(bits.data_ptr(), out.numel(), out.data_ptr(),
+                                            torch.cuda.current_stream(bits.device).cuda_stream))
+        return out
+    sh = torch.arange(8, device=bits.device, dtype=torch.uint8)
+    return ((bits.view(-1, 1) >> sh) & 1).reshape(-1)
+
+
 class DoneGather(object):
     """All-gather of the per-rank done mask into the global mask [world_size * n_local] (uint8).
 
-    Equal shard sizes are required (all_gather_into_tensor); pad the last shard if the batch does not divide."""
+    Equal shard sizes are required (all_gather_into_tensor); pad the last shard if the batch does not divide.
+    `packed` (pipelined form only): the mask crosses the links as one BIT per env -- pack_mask_bits before the collective,
+    result() unpacks on request -- an eighth of the bytes for an RCCL kernel that shares the compute units with the steps
+    (n_local must be a multiple of 8)."""
 
-    def __init__(self, n_local, device, group=None):
+    def __init__(self, n_local, device, group=None, packed=False):
         self.group = group
         # with a process group every gather is a collective, also at world size 1 (init_from_env(force=True));
         # without one there is nothing to gather from
         self.collective = dist.is_initialized()
         self.world = dist.get_world_size(group) if self.collective else 1
         self.n_local = int(n_local)
-        self.out = torch.zeros(self.world * self.n_local, dtype=torch.uint8, device=device)
+        self.packed = bool(packed)
+        if self.packed and self.n_local % 8:
+            raise ValueError("DoneGather(packed=True) needs a multiple of 8 envs per rank, got %d" % self.n_local)
+        self.out = torch.zeros(self.world * (self.n_local // 8 if self.packed else self.n_local), dtype=torch.uint8, device=device)
 
     def __call__(self, done_local, async_op=False):
+        if self.packed:
+            raise ValueError("DoneGather(packed=True) is the pipelined form: launch() / result()")
         if not self.collective:
             self.out.copy_(done_local)
             return None if async_op else self.out
@@ -101,7 +145,8 @@ class DoneGather(object):
         one of two staging buffers (the step kernel overwrites `done_local` next step), then all-gathered
         asynchronously; the result of THIS call is what `result()` returns after the next `launch()` / `flush()`."""
         if not hasattr(self, "_stage"):
-            self._stage = [torch.empty_like(done_local) for _ in range(2)]
+            self._stage = [torch.empty(self.n_local // 8 if self.packed else self.n_local, dtype=torch.uint8, device=done_local.device)
+                           for _ in range(2)]
             self._outs = [self.out, torch.empty_like(self.out)]
             self._work = [None, None]
             self._k = 0
@@ -109,7 +154,10 @@ class DoneGather(object):
         if self._work[k] is not None:  # buffer k was used two launches ago: its gather must have completed
             self._work[k].wait()
             self._work[k] = None
-        self._stage[k].copy_(done_local)
+        if self.packed:
+            pack_mask_bits(done_local, out=self._stage[k])
+        else:
+            self._stage[k].copy_(done_local)
         if not self.collective:
             self._outs[k].copy_(self._stage[k])
         elif self.out.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -122,13 +170,14 @@ class DoneGather(object):
         self._k = 1 - k
         return k
 
-    def result(self):
-        """Global done mask of the most recent launch() (waits for its gather)."""
+    def result(self, unpack=True):
+        """Global done mask of the most recent launch() (waits for its gather).  packed: a uint8 mask of zeros and ones
+        [world_size * n_local], or with unpack=False the gathered bits as they arrived (pack_mask_bits per rank)."""
         k = self._last
         if self._work[k] is not None:
             self._work[k].wait()
             self._work[k] = None
-        return self._outs[k]
+        return unpack_mask_bits(self._outs[k]) if (self.packed and unpack) else self._outs[k]
 
     def flush(self):
         for k in range(2):

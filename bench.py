@@ -413,7 +413,7 @@ def run_rank(args):
     # launch, not the step.  The rows of an unfinished block are gathered at the end of the timed region, inside it.
     gather_every = max(1, int(args.gather_every))
     ring = torch.zeros(gather_every, n, dtype=torch.uint8, device=torch.device("cuda", device)) if sharded else None
-    gather = bdist.DoneGather(gather_every * n, torch.device("cuda", device)) if sharded else None
+    gather = bdist.DoneGather(gather_every * n, torch.device("cuda", device), packed=True) if sharded else None   # (one bit per env on the links)
     if sharded:
         # the first collectives run here, untimed (communicator set-up)
         gather.launch(ring.view(-1))
@@ -545,7 +545,7 @@ def run_rank(args):
             "config": {"workload": "C3: RandomMiniEnv seed-0 geometry, %d envs/GPU, tricycle dynamic model + PlanEnv "
                                    "odometry noise (on-device Philox), shared 183x183 costmap, reset on done, steady-state episode phases" % n,
                        "envs_total": total_envs, "envs_per_gpu": n, "actions": "float32 U(action_space), pre-staged",
-                       "sharding": ("env blocks per rank, done masks ring-buffered on the device and all-gathered (%s) every "
+                       "sharding": ("env blocks per rank, done masks ring-buffered on the device and all-gathered as bits (%s) every "
                                     "%d steps, overlapped with the next steps"
                                     % ("RCCL" if backend == "nccl" else "gloo through the host: REHEARSAL transport, not a scaling number", gather_every))
                        if sharded else "single GPU"},

@@ -271,6 +271,15 @@ int bcp_path_velocity(bcp_handle *h, const double *path_txyth, int64_t n_rows, d
  * image of angle i occupies the top-left shape_hw[i] = {2*half_y+1, 2*half_x+1} corner. */
 int bcp_pixel_footprint(bcp_handle *h, const double *angles, int64_t n, double resolution, uint8_t *masks,
                         int32_t side, int32_t *shape_hw, void *stream);
+/* Done masks as bits, for a job sharded over several GPUs (bc_gym_planning_env_amd/distributed.py: DoneGather(packed=True),
+ * bench.py): the only data that crosses GPUs is each rank's done mask, and it crosses as one bit per env --
+ * bits[w] bit b = (mask[32 w + b] != 0), n envs -> (n + 31) / 32 words -- an eighth of the bytes an RCCL all-gather has to
+ * move while it shares the compute units with the steps.  Device pointers of the current device, asynchronous on `stream`,
+ * no handle.  bcp_unpack_mask_bits writes zeros and ones.  No counterpart in the reference (its envs are independent objects,
+ * envs/base/env.py; its only vectorised call site, scripts/rl_runners/ppo_runner.py:35-36, runs them in one process). */
+int bcp_pack_mask_bits(const uint8_t *mask, int64_t n, uint32_t *bits, void *stream);
+int bcp_unpack_mask_bits(const uint32_t *bits, int64_t n, uint8_t *mask, void *stream);
+
 /* normalize_angle_impl (coordinate_transformations.py:17-36) */
 int bcp_normalize_angle(bcp_handle *h, const double *in, double *out, int64_t n, void *stream);
 /* world_to_pixel_impl (coordinate_transformations.py:169-205): xy [n,2] -> int64 [n,2]; origin host double[2] */

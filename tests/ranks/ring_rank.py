@@ -27,7 +27,7 @@ def main():
     assert (first, count) == (rank * n_local, n_local)
     every = 8
     ring = torch.zeros(every, n_local, dtype=torch.uint8)
-    gather = bdist.DoneGather(every * n_local, torch.device("cpu"))
+    gather = bdist.DoneGather(every * n_local, torch.device("cpu"), packed=True)   # (as bench.py: one bit per env on the wire)
     checked = 0
     for k in range(steps):
         ring[k % every].copy_(mask_of(first, count, k, torch))

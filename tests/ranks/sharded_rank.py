@@ -46,7 +46,7 @@ def main():
     every = 4
     ring = torch.zeros(every, count, dtype=torch.uint8, device=dev)
     per_step = bdist.DoneGather(count, dev)
-    ring_gather = bdist.DoneGather(every * count, dev)
+    ring_gather = bdist.DoneGather(every * count, dev, packed=True)   # (as bench.py: one bit per env on the wire)
     got_step, got_ring = [], []
     for k in range(steps):
         a = torch.from_numpy(acts[k, first:first + count]).to(dev)

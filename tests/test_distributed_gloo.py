@@ -47,6 +47,17 @@ def _worker(rank, world, port, n_total, out_dir):
         buf.zero_()  # the caller may overwrite its mask right away (the step kernel does)
         assert torch.equal(gather.result(), base ^ (step & 1)), (rank, step)
     gather.flush()
+    # ... and with one BIT per env on the wire (what bench.py's ring sends): the same masks come back, as zeros and ones,
+    # or as the gathered bits themselves
+    packed = bdist.DoneGather(count, torch.device("cpu"), packed=True)
+    for step in range(4):
+        buf = (done_local ^ (step & 1)) * (3 if step == 2 else 1)   # (any non-zero byte is "done")
+        packed.launch(buf)
+        buf.zero_()
+        assert torch.equal(packed.result(), base ^ (step & 1)), (rank, step)
+        bits = packed.result(unpack=False)
+        assert bits.numel() == n_total // 8 and torch.equal(bits, bdist.pack_mask_bits(base ^ (step & 1)))
+    packed.flush()
     np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([first, count]))
     dist.barrier()
     dist.destroy_process_group()

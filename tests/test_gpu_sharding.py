@@ -159,6 +159,29 @@ def _single_process_masks(torch, n, steps):
     return np.stack(expect), env.state.robot.cpu().numpy()
 
 
+def test_mask_bits_native_vs_numpy(torch_cuda):
+    """bcp_pack_mask_bits / bcp_unpack_mask_bits (what DoneGather(packed=True) sends): numpy's little-endian packbits, for
+    whole words, a ragged tail and a source that is not 16-byte aligned"""
+    torch = torch_cuda
+    import ctypes as C
+    from bc_gym_planning_env_amd import _lib, distributed as bdist
+    lib = _lib.load()
+    rng = np.random.RandomState(3)
+    for n, offset in ((65536 * 8, 0), (4096 + 19, 0), (1024, 5), (31, 1)):
+        host = (rng.rand(n + offset) < 0.3).astype(np.uint8) * rng.randint(1, 255, n + offset).astype(np.uint8)
+        src = torch.from_numpy(host).cuda()[offset:]
+        words = torch.zeros((n + 31) // 32, dtype=torch.int32, device="cuda")
+        _lib.check(lib.bcp_pack_mask_bits(src.data_ptr(), n, words.data_ptr(), None))
+        want = np.packbits(np.pad(host[offset:] != 0, (0, (-n) % 32)), bitorder="little").view(np.uint32)
+        assert (words.cpu().numpy().view(np.uint32) == want).all(), (n, offset)
+        back = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.bcp_unpack_mask_bits(words.data_ptr(), n, back.data_ptr(), None))
+        assert (back.cpu().numpy() == (host[offset:] != 0)).all(), (n, offset)
+    m = torch.from_numpy((rng.rand(4096) < 0.5).astype(np.uint8) * 3).cuda()
+    assert torch.equal(bdist.pack_mask_bits(m).cpu(), bdist.pack_mask_bits(m.cpu()))            # native == tensor arithmetic
+    assert torch.equal(bdist.unpack_mask_bits(bdist.pack_mask_bits(m)).cpu(), (m != 0).to(torch.uint8).cpu())
+
+
 def test_rccl_branch_at_world_size_one(torch_cuda, launcher, tmp_path):
     """The RCCL path for real, on the one GPU of this box: BCP_DIST_FORCE=1 makes init_from_env build a `nccl` process
     group at world size 1 (device_id path, communicator set-up) and DoneGather take its collective branch --
