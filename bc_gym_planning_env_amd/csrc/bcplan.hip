@@ -2226,10 +2226,14 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
             HIP_TRY(hipStreamSynchronize(st));
         }
         if (h->ego_cells && h->ego_cells_max >= 0 && h->ego_cells_max <= kEgoCellCap) {
+            // One image per wave, eight per workgroup: 8 192 short workgroups for 65 536 images.  (Round 3 first ran this kernel
+            // persistently -- as many workgroups as the chip holds, 64 images per wave, the lanes sharing the transforms' float64
+            // arithmetic: 11 % slower on the same box, 0.249 against 0.222 ms.  Stores from many short workgroups drain faster than
+            // from a few long-lived ones, tools/fill_rate.hip; the arithmetic saved was never the bottleneck, VALU busy 17 %.
+            // Also measured: an image split over 2 / 4 waves of a workgroup (+- 0 / 14 % slower), a plain one-image kernel with
+            // 48 instead of 83 registers (3 - 8 % slower), fewer workgroups per CU by way of unused LDS (within the noise).)
             const dim3 wide(64 * kEgoWaves);
-            int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ego_sparse_kernel, 64 * kEgoWaves, 0));
-            const dim3 grid((unsigned)std::min<int64_t>((n + kEgoWaves - 1) / kEgoWaves, (int64_t)std::max(per_cu, 1) * cus));
+            const dim3 grid((unsigned)((n + kEgoWaves - 1) / kEgoWaves));
             hipLaunchKernelGGL(ego_sparse_kernel, grid, wide, 0, st, a, h->ego_cells, h->ego_cell_counts, kEgoCellCap);
             HIP_TRY(hipGetLastError());
             return BCP_OK;
