@@ -14,6 +14,9 @@ STEP_AUTO_RESET, STEP_ACTIONS_F32 = 1, 2
 ERR_ANGLE_JUMP, ERR_TIME_ORDER, ERR_INTERNAL = 1, 2, 4
 TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL, TUNE_DEFER, TUNE_EDT_LDS, TUNE_FUSED, TUNE_EGO_SPARSE, TUNE_NEAR_DILATE = 0, 1, 2, 3, 4, 5, 6, 7
 E_NO_DEVICE = -2
+OPT_DIFFDRIVE_NOISE = 1
+EGO_KERNELS = {0: "none", 1: "ego_sparse_kernel", 2: "ego_costmap_kernel<staged>", 3: "ego_costmap_binned_kernel",
+               4: "ego_costmap_window_kernel", 5: "ego_costmap_kernel<global>"}
 
 _f64p = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)
@@ -24,7 +27,7 @@ class BcpParams(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("model", C.c_int32), ("n_verts", C.c_int32), ("dynamic_model", C.c_int32),
         ("model_front_column_pid", C.c_int32), ("noise_on", C.c_int32), ("iteration_timeout", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("options", C.c_int32),
         ("verts", (C.c_double * 2) * MAX_VERTS),
         ("dt", C.c_double), ("front_wheel_from_axis", C.c_double), ("max_front_wheel_angle", C.c_double),
         ("max_front_wheel_speed", C.c_double), ("max_linear_acceleration", C.c_double),
@@ -79,6 +82,7 @@ SYMBOLS = {
     "bcp_broadcast_state": (C.c_int, [_H, C.c_int64, C.c_void_p, C.c_void_p]),
     "bcp_step": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_void_p]),
     "bcp_expired_waits": (C.c_int, [_H, C.POINTER(C.c_int64), C.c_void_p]),
+    "bcp_parked_poses": (C.c_int, [_H, C.POINTER(C.c_int64), C.c_void_p]),
     "bcp_side_stream": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p)]),
     "bcp_robot_step": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcp_pose_collides": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -98,6 +102,7 @@ SYMBOLS = {
     "bcp_egocentric_shape": (C.c_int, [_H, _f64p, _i32p]),
     "bcp_egocentric_costmaps": (C.c_int, [_H, C.c_void_p, C.c_int64, _f64p, _f64p, C.c_uint8, C.c_void_p,
                                           C.c_void_p]),
+    "bcp_egocentric_route": (C.c_int, [_H, _i32p]),
     "bcp_goal_n_state": (C.c_int, [_H, _f64p, C.c_void_p, C.c_void_p]),
     "bcp_goal_direction_state": (C.c_int, [_H, _f64p, C.c_void_p, C.c_void_p]),
     "bcp_mini_world_seed": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -251,8 +251,10 @@ class BatchedPlanEnv(object):
     :param n_envs int: number of envs on this device
     :param device: torch device / index of the GPU
     :param robot_name: robot model + footprint; default params.robot_name (PlanEnv itself always drives a tricycle)
-    :param noise_parameters: 'planenv' = the odometry noise PlanEnv hard-codes (env.py:226-232), None = off, or a
-        dict alpha1..alpha6
+    :param noise_parameters: 'planenv' = the odometry noise PlanEnv hard-codes on its tricycle (env.py:226-232; for a
+        diff-drive robot, which PlanEnv never builds, that default means None), None = off, or a dict alpha1..alpha6.
+        A diff-drive robot WITH noise raises IndexError like the reference (differential_drive.py:73) unless
+        unpinned_diffdrive_noise=True opts in to the library's unpinned analogue
     :param auto_reset bool: restore an env's initial state right after the step that finished it
     :param env_id_base int: global index of env 0 (rank * n_envs when sharded over GPUs); keys the noise stream
     :param template_of_env: optional int array [n_envs]; `costmap` and `path` are then lists of T templates and env i
@@ -268,7 +270,8 @@ class BatchedPlanEnv(object):
 
     def __init__(self, costmap, path, params=None, n_envs=1, device=0, robot_name=None, noise_parameters='planenv',
                  auto_reset=False, env_id_base=0, seed=0, footprint_scale=1.0, dynamic_model=True,
-                 model_front_column_pid=True, template_of_env=None, geom_of_env=None, next_geom=None, map_storage=None):
+                 model_front_column_pid=True, template_of_env=None, geom_of_env=None, next_geom=None, map_storage=None,
+                 unpinned_diffdrive_noise=False):
         params = EnvParams() if params is None else params
         self.params = params
         self._pure_pursuit = params.reward_provider_name == CONTINUOUS_REWARD_PURE_PURSUIT
@@ -277,14 +280,14 @@ class BatchedPlanEnv(object):
         self.robot_name = params.robot_name if robot_name is None else robot_name
         self.is_tricycle = self.robot_name == INDUSTRIAL_TRICYCLE_V1
         if noise_parameters == 'planenv':
-            noise_parameters = dict(robots.PLANENV_NOISE)
+            noise_parameters = dict(robots.PLANENV_NOISE) if self.is_tricycle else None
         self.noise_parameters = noise_parameters
         self.auto_reset = bool(auto_reset)
         self._lib = _lib.load()  # raises when libbcplan.so is missing: no fallback
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedPlanEnv needs a GPU (libbcplan has no CPU path)")
         self._bcp_params = robots.make_bcp_params(params, self.robot_name, noise_parameters, footprint_scale,
-                                                  dynamic_model, model_front_column_pid)
+                                                  dynamic_model, model_front_column_pid, unpinned_diffdrive_noise)
         self._h = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(self._lib.bcp_create(C.byref(self._bcp_params), self.n_envs, dev_index, int(env_id_base),
@@ -719,6 +722,28 @@ class BatchedPlanEnv(object):
         bad = torch.nonzero(self.err & _lib.ERR_ANGLE_JUMP).flatten()
         if len(bad):
             raise Exception("Path has missing/corrupted angle data at env indices: %s" % bad.cpu().numpy())
+
+    def geometry_digest(self):
+        """Digest of the geometry this rank's envs share (distributed.geometry_digest): the costmap(s) and path(s) as they
+        were given -- for distributed.check_same_geometry at set-up of a sharded job."""
+        import numpy as np
+        from . import distributed
+        parts = []
+        dp = getattr(self, "_device_pool", None)
+        if dp is not None:   # a pool that lives on the GPU: its first entries stand for it
+            return distributed.geometry_digest(dp.maps[:16].cpu().numpy(), dp.origin, np.float64(dp.resolution),
+                                               dp.path_points[:16].cpu().numpy(), dp.lens[:16].cpu().numpy())
+        for cm in self._costmaps[:16]:
+            parts += [cm.get_data(), np.asarray(cm.get_origin(), dtype=np.float64), np.float64(cm.get_resolution())]
+        parts += [np.asarray(p, dtype=np.float64) for p in self._paths[:16]]
+        return distributed.geometry_digest(*parts)
+
+    def parked_poses(self):
+        """Poses the single-launch step handed to the exact footprint test since the env was created (bcp_parked_poses;
+        synchronises).  Measurement only."""
+        count = C.c_int64()
+        _lib.check(self._lib.bcp_parked_poses(self._h, C.byref(count), self._stream()))
+        return int(count.value)
 
     def _timing_io(self, actions, noise_z):
         a = _as_device_actions(actions, self.n_envs, self.device)

@@ -736,24 +736,27 @@ __global__ void __launch_bounds__(256) ego_costmap_window_kernel(const EgoArgs a
 }
 
 // ---- sparse costmaps: fill + patch ---------------------------------------------------------------------------------------
-// The costmaps this path meets are nearly empty (RandomMiniEnv: two walls one cell thick, ~120 cells of 33 489 non-zero) and
-// the border value of extract_egocentric_costmap is 0 (costmap_utils.py:27): an egocentric image is then ZEROS plus the few
-// pixels whose source cell is not.  INTER_NEAREST is an exact inverse map, so instead of asking every destination pixel for
-// its source cell (15 561 fixed-point evaluations and LDS reads per image, issue-bound at 46 % of the HBM write rate)
+// The costmaps this path meets are nearly empty (RandomMiniEnv: two walls one cell thick, ~120 cells of 33 489 non-zero; the
+// AisleTurn maps of the reference's PPO runner: 543 of 60 939 and 1 040 of 179 200) and the border value of
+// extract_egocentric_costmap is 0 (costmap_utils.py:27): an egocentric image is then ZEROS plus the few pixels whose source
+// cell is not.  INTER_NEAREST is an exact inverse map, so instead of asking every destination pixel for its source cell
+// (15 561 fixed-point evaluations and LDS reads per image, issue-bound at 46 % of the HBM write rate)
 //   1. the image is filled with zeros in 16-byte stores -- a plain memset, all the HBM traffic there is;
-//   2. every non-zero source cell (X, Y) is mapped FORWARD to the image with the inverse of the dst -> src matrix, and the
-//      3 x 3 pixels around that position are tested with cv::warpAffine's own 22.10 formula: a pixel whose source cell is
-//      (X, Y) gets the cell's value.  A rotation has scale 1: the pixels whose source coordinate rounds to (X, Y) lie within
-//      0.5 (|cos| + |sin|) + 2^-9 <= 0.71 px of the forward image of the cell centre in each axis, hence within the 3 x 3
-//      block around its rounding -- the test is exact, the neighbourhood only has to contain the candidates.
-// ~120 cells x 9 candidates = ~1 100 evaluations per image instead of 15 561.  Lists of the non-zero cells are built per map
-// entry (ego_cells_kernel); an entry with more than `cap` of them is drawn pixel by pixel (ego_image_slow), and the host
-// routes whole calls whose maps are dense -- or whose border value is not 0 -- to the sampling kernels above.
-constexpr int kEgoCellCap = 512;   // cells per map entry a list holds (a RandomMiniEnv world: <= 2 x 183)
+//   2. every non-zero source cell (X, Y) is mapped FORWARD to the image with the inverse of the dst -> src matrix; cells whose
+//      image lies outside the window drop out here (a window sees a tenth of a 350 x 512 map), the others are compacted into
+//      a per-wave LDS list so that step 3 runs on full wavefronts whatever the order of the cell list;
+//   3. the 3 x 3 pixels around the forward position are tested with cv::warpAffine's own 22.10 formula: a pixel whose source
+//      cell is (X, Y) gets the cell's value.  A rotation has scale 1: the pixels whose source coordinate rounds to (X, Y) lie
+//      within 0.5 (|cos| + |sin|) + 2^-9 <= 0.71 px of the forward image of the cell centre in each axis, hence within the
+//      3 x 3 block around its rounding -- the test is exact, the neighbourhood only has to contain the candidates.
+// Lists of the non-zero cells are built per map entry (ego_cells_kernel: a counting pass sizes them, round 4); an entry with
+// more than `cap` of them (a pool entry re-sampled after the lists were sized) is drawn pixel by pixel (ego_image_slow), and
+// the host routes whole calls whose maps are dense -- or whose border value is not 0 -- to the sampling kernels above.
+constexpr int kEgoCellCapMin = 512;   // least stride of a list (a RandomMiniEnv world: <= 2 x 183 cells; pool entries change)
 
 // list[entry][k] = value << 24 | row << 12 | column of the k-th non-zero cell inside the entry's valid region (any order);
 // counts[entry] = how many there are (may exceed `cap`: the list then holds the first `cap` found); *max_count = running
-// maximum over the entries built so far.  One workgroup per entry.
+// maximum over the entries built so far.  One workgroup per entry.  cells == nullptr: the counting pass only.
 __global__ void __launch_bounds__(256) ego_cells_kernel(const uint8_t* __restrict__ data, EntrySelect sel, int rows, int cols,
                                                         const int32_t* __restrict__ valid_rows,
                                                         const int32_t* __restrict__ valid_cols, int cap,
@@ -782,7 +785,7 @@ __global__ void __launch_bounds__(256) ego_cells_kernel(const uint8_t* __restric
                 const int idx = base + j, r = idx / cols, c = idx - r * cols;
                 if (r >= vr || c >= vc) continue;
                 const int at = atomicAdd(&n_found, 1);
-                if (at < cap) cells[m * cap + at] = (v << 24) | ((uint32_t)r << 12) | (uint32_t)c;
+                if (cells && at < cap) cells[m * cap + at] = (v << 24) | ((uint32_t)r << 12) | (uint32_t)c;
             }
         }
         __syncthreads();
@@ -811,13 +814,53 @@ __device__ __forceinline__ void ego_image_slow(const EgoArgs& a, const EgoImage&
 
 typedef uint32_t EgoU32x4 __attribute__((ext_vector_type(4)));
 
-// One wavefront per image (border value 0, cell lists built): zero fill, then the patches.  No LDS.
+// the 3 x 3 candidates of one source cell: cv::hal::warpAffine's expression decides which of them copy the cell
+__device__ __forceinline__ void ego_patch_cell(const EgoArgs& a, const EgoImage& I, uint8_t* __restrict__ image, uint32_t cell,
+                                               double f0, double f1, double f2, double f3, double f4, double f5)
+{
+    const int sx = (int)(cell & 0xFFFu), sy = (int)((cell >> 12) & 0xFFFu);
+    const uint8_t v = (uint8_t)(cell >> 24);
+    const double fx = f0 * sx + f1 * sy + f2, fy = f3 * sx + f4 * sy + f5;
+    const int xc = (int)rint(fx), yc = (int)rint(fy);
+    int cx[3], cy[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {   // adelta / bdelta of the three candidate columns
+        cx[j] = sat_int(I.m0 * (xc - 1 + j) * 1024);
+        cy[j] = sat_int(I.m3 * (xc - 1 + j) * 1024);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int y = yc - 1 + r;
+        if ((unsigned)y >= (unsigned)a.drows) continue;
+        const int rx = sat_int((I.m1 * y + I.m2) * 1024) + 512, ry = sat_int((I.m4 * y + I.m5) * 1024) + 512;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int x = xc - 1 + j;
+            if ((unsigned)x < (unsigned)a.dcols && ((rx + cx[j]) >> 10) == sx && ((ry + cy[j]) >> 10) == sy)
+                image[(int64_t)y * a.dcols + x] = v;
+        }
+    }
+}
+
+constexpr int kEgoHeld = 256;   // cells a wave can hold back in LDS between the culling pass and the patches
+
+// One wavefront per image (border value 0, cell lists built).  Order of a wave's work, chosen for what it waits on:
+//   A. the cell list is read and culled FIRST (four loads in flight per lane; the cells whose forward image meets the window
+//      are compacted into the wave's LDS list) -- loads and stores retire through one in-order counter on this chip, so a
+//      list load issued behind the zero fill would wait for every store of the fill;
+//   B. the zero fill (all the HBM traffic there is);
+//   C. s_waitcnt vmcnt(0) -- a patch must not be overtaken by the zeros: same wave, same addresses, no other ordering --,
+//      then the patches, a held cell per lane.
+// More than kEgoHeld cells inside one window (a dense corner of an otherwise sparse map): the wave streams the whole list once
+// more behind the fill, culling and patching 64 cells at a time through the same LDS list.
 __global__ void __launch_bounds__(64 * kEgoWaves) ego_sparse_kernel(const EgoArgs a, const uint32_t* __restrict__ cells,
                                                                      const int32_t* __restrict__ counts, int cap)
 {
+    __shared__ uint32_t near_cells[kEgoWaves][kEgoHeld];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const int64_t P = (int64_t)a.drows * a.dcols;
     const int64_t first = (int64_t)blockIdx.x * waves + wave, stride = (int64_t)gridDim.x * waves;
+    uint32_t* const mine_cells = near_cells[wave];
     for (int64_t base = first; base < a.n_images; base += 64 * stride) {
         EgoXform T;
         memset(&T, 0, sizeof(T));
@@ -834,7 +877,39 @@ __global__ void __launch_bounds__(64 * kEgoWaves) ego_sparse_kernel(const EgoArg
                 ego_image_slow(a, I, a.data + I.g * a.map_stride, image, lane);
                 continue;
             }
-            // ---- 1. zeros: bytes up to the first 16-byte boundary, aligned 16-byte stores, the tail
+            // forward map of a source cell: the inverse of the dst -> src matrix
+            const double det = I.m0 * I.m4 - I.m1 * I.m3;
+            const double id = det != 0.0 ? 1.0 / det : 0.0;
+            const double f0 = I.m4 * id, f1 = -I.m1 * id, f3 = -I.m3 * id, f4 = I.m0 * id;
+            const double f2 = -(f0 * I.m2 + f1 * I.m5), f5 = -(f3 * I.m2 + f4 * I.m5);
+            const double x_hi = (double)a.dcols + 1.0, y_hi = (double)a.drows + 1.0;
+            const uint32_t* const list = cells + I.g * (int64_t)cap;
+            auto meets_window = [&](uint32_t cell) -> bool {
+                const int sx = (int)(cell & 0xFFFu), sy = (int)((cell >> 12) & 0xFFFu);
+                const double fx = f0 * sx + f1 * sy + f2, fy = f3 * sx + f4 * sy + f5;
+                return cell != 0u && fx > -2.0 && fx < x_hi && fy > -2.0 && fy < y_hi;   // (a listed cell has a non-zero value byte)
+            };
+            // ---- A. cull: which cells can reach the window at all
+            int held = 0;            // cells in the wave's LDS list (uniform)
+            bool overflow = false;
+            for (int c0 = 0; c0 < n_cells && !overflow; c0 += 256) {
+                uint32_t cell[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cell[u] = c0 + 64 * u + lane < n_cells ? list[c0 + 64 * u + lane] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = meets_window(cell[u]);
+                    const uint64_t hits = __ballot(in);
+                    const int more = __builtin_popcountll(hits);
+                    if (held + more > kEgoHeld) {
+                        overflow = true;
+                        break;
+                    }
+                    if (in) mine_cells[held + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u))] = cell[u];
+                    held += more;
+                }
+            }
+            // ---- B. zeros: bytes up to the first 16-byte boundary, aligned 16-byte stores, the tail
             {
                 const int head = (int)((16u - (uint32_t)(uintptr_t)image) & 15u);
                 const int64_t body = (P - head) >> 4;           // whole 16-byte pieces
@@ -845,45 +920,41 @@ __global__ void __launch_bounds__(64 * kEgoWaves) ego_sparse_kernel(const EgoArg
                 for (int64_t c = lane; c < body; c += 64) q[c] = zero;   // (non-temporal stores: 7 % slower)
                 if (lane < tail) image[head + (body << 4) + lane] = 0;
             }
-            if (n_cells == 0) continue;
-            // (the patches below must land after the zeros: same wave, same addresses -- wait for the fill to be done.
-            //  Measured alternatives, both slower than this plain form (0.203 ms per 65 536 images): all the fills of a
-            //  batch of 64 images first, one wait, then all the patches 0.32 ms -- the waves then fill and patch in step
-            //  and stores never overlap arithmetic --; a two-stage pipeline with s_waitcnt vmcnt(16) 0.27 ms.)
+            if (held == 0 && !overflow) continue;
+            // ---- C. the patches, behind the zeros (measured alternatives to this wait, round 3: all the fills of a batch of
+            // images first 0.32 against 0.20 ms; a two-stage pipeline with s_waitcnt vmcnt(16) 0.27 ms)
+            __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-            // ---- 2. forward map of the source cells: the inverse of the (dst -> src) matrix
-            const double det = I.m0 * I.m4 - I.m1 * I.m3;
-            const double id = det != 0.0 ? 1.0 / det : 0.0;
-            const double f0 = I.m4 * id, f1 = -I.m1 * id, f3 = -I.m3 * id, f4 = I.m0 * id;
-            const double f2 = -(f0 * I.m2 + f1 * I.m5), f5 = -(f3 * I.m2 + f4 * I.m5);
-            const uint32_t* const list = cells + I.g * (int64_t)cap;
+            if (!overflow) {
+                for (int c0 = 0; c0 < held; c0 += 64)
+                    if (c0 + lane < held) ego_patch_cell(a, I, image, mine_cells[c0 + lane], f0, f1, f2, f3, f4, f5);
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+            held = 0;
             for (int c0 = 0; c0 < n_cells; c0 += 64) {
-                if (c0 + lane >= n_cells) continue;
-                const uint32_t cell = list[c0 + lane];
-                const int sx = (int)(cell & 0xFFFu), sy = (int)((cell >> 12) & 0xFFFu);
-                const uint8_t v = (uint8_t)(cell >> 24);
-                const double fx = f0 * sx + f1 * sy + f2, fy = f3 * sx + f4 * sy + f5;
-                if (!(fx > -2.0 && fx < (double)a.dcols + 1.0 && fy > -2.0 && fy < (double)a.drows + 1.0)) continue;
-                const int xc = (int)rint(fx), yc = (int)rint(fy);
-                int cx[3], cy[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {   // cv::hal::warpAffine's adelta / bdelta of the three candidate columns
-                    cx[j] = sat_int(I.m0 * (xc - 1 + j) * 1024);
-                    cy[j] = sat_int(I.m3 * (xc - 1 + j) * 1024);
-                }
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const int y = yc - 1 + r;
-                    if ((unsigned)y >= (unsigned)a.drows) continue;
-                    const int rx = sat_int((I.m1 * y + I.m2) * 1024) + 512, ry = sat_int((I.m4 * y + I.m5) * 1024) + 512;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int x = xc - 1 + j;
-                        if ((unsigned)x < (unsigned)a.dcols && ((rx + cx[j]) >> 10) == sx && ((ry + cy[j]) >> 10) == sy)
-                            image[(int64_t)y * a.dcols + x] = v;
-                    }
+                const uint32_t cell = c0 + lane < n_cells ? list[c0 + lane] : 0u;
+                const bool in = meets_window(cell);
+                const uint64_t hits = __ballot(in);
+                if (hits == 0) continue;
+                if (in) mine_cells[held + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u))] = cell;
+                held += __builtin_popcountll(hits);
+                __builtin_amdgcn_wave_barrier();
+                if (held >= 64) {
+                    const uint32_t take = mine_cells[lane];
+                    const uint32_t keep = mine_cells[64 + lane];
+                    __builtin_amdgcn_wave_barrier();
+                    held -= 64;
+                    if (lane < held) mine_cells[lane] = keep;
+                    ego_patch_cell(a, I, image, take, f0, f1, f2, f3, f4, f5);
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
+            if (held > 0) {
+                const uint32_t take = mine_cells[lane < held ? lane : 0];
+                if (lane < held) ego_patch_cell(a, I, image, take, f0, f1, f2, f3, f4, f5);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }

@@ -2121,6 +2121,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
 #endif
     if (poll_expired && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 4), 1ull);   // (bcp_expired_waits)
     if ((a.flags & kStepAdvances) && tid == (kLocalWaves - 1) * kBlock) {   // the last workgroup to get here moves the step counter on
+        if (n_parked) atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 5), (unsigned long long)n_parked);   // (bcp_parked_poses; no return value: not waited for)
         unsigned int* ticket = reinterpret_cast<unsigned int*>(a.tick + 3);
         if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
             *ticket = 0u;

@@ -96,13 +96,24 @@ struct bcp_handle {
     int32_t* ego_order;       // owned: [2][images] rank within the bin / images grouped by map entry
     int64_t ego_order_cap;
     // sparse egocentric views (ego_sparse_kernel): per map entry the list of its non-zero cells
-    uint32_t* ego_cells;      // owned: [entries][kEgoCellCap]
+    uint32_t* ego_cells;      // owned: [entries][ego_cell_cap] (nullptr while the maps count as dense)
     int32_t* ego_cell_counts; // owned: [entries] + [1] running maximum
     int64_t ego_cells_entries;
-    bool ego_cells_built;     // the lists describe the current maps (rebuilt entry by entry when a pool is refreshed)
+    int32_t ego_cell_cap;     // stride of a list, sized from the counting pass
+    bool ego_cells_built;     // counts (and lists, if any) describe the current maps (rebuilt entry by entry by a pool refresh)
     bool ego_cells_refused;   // allocation failed once: the sampling kernels serve this handle
     int32_t ego_cells_max;    // host copy of the maximum count, -1 = not fetched since the last (re)build
-    int32_t ego_sparse;       // BCP_TUNE_EGO_SPARSE
+    int32_t ego_sparse;       // BCP_TUNE_EGO_SPARSE: 0 never, 1 cost model, >= 2 explicit limit of cells per map
+    int32_t ego_route[4];     // what the last bcp_egocentric_costmaps call ran: kernel, largest count, list stride, limit
+    // watchdog of the step kernel's bounded waits: every kWatchdogSteps calls bcp_step copies tick[4] to pinned host memory
+    // behind the step (no synchronisation) and a later call looks at what arrived
+    uint64_t* waits_host;     // owned, pinned
+    hipEvent_t waits_event;   // owned
+    bool waits_in_flight;
+    uint64_t waits_seen;
+    uint32_t steps_since_probe;
+    hipEvent_t refresh_done;  // owned: end of the last bcp_refresh_mini_worlds (whoever derives data from the maps on
+    bool refresh_recorded;    // another stream waits for it first)
     hipStream_t side_stream;  // owned: the CU-masked stream of bcp_side_stream (nullptr: not created)
     int32_t side_share;       // ... and the share of the CUs it was created with
     const uint8_t* map_data;  // caller-owned raw costmap(s) as given to bcp_set_costmaps (egocentric views read them)
@@ -574,7 +585,7 @@ __global__ void __launch_bounds__(256) edt_lds_kernel(const uint32_t* __restrict
 // exactly once and shifts the window by +-w: ~250 integer instructions per 32-cell output word against ~1200 of the
 // distance transform + threshold (edt_lds_kernel + near_tiles_kernel), and no 16 KB uint8 field to write and read back.
 // The bits are those of near_tiles_kernel by construction (floor(sqrt(D2)) < t_out  <=>  D2 <= t_out^2 - 1; the transform's
-// windows are wider than t_out); tests/test_gpu_distance_field.py compares the two word for word.  What a pool refresh runs
+// windows are wider than t_out); tests/test_gpu_pool.py::test_near_tiles_by_dilation_vs_thresholded_field compares the two word for word.  What a pool refresh runs
 // while the steps only read the tiles (step_local_kernel); the uint8 field of such entries is marked stale (ensure_fields).
 // One workgroup per map; LDS: the padded lethal rows with a zero word either side and t_out - 1 zero rows above and below.
 __global__ void __launch_bounds__(256) near_dilate_kernel(const uint32_t* __restrict__ bits, EntrySelect sel, int rows, int cols,
@@ -999,6 +1010,10 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     if (params->model != BCP_MODEL_TRICYCLE && params->model != BCP_MODEL_DIFFDRIVE)
         return fail(BCP_E_INVALID, "bcp_create: unknown robot model %d", params->model);
     if (!(params->dt > 0)) return fail(BCP_E_INVALID, "bcp_create: dt must be > 0 (path_tools.py:307)");
+    if (params->model == BCP_MODEL_DIFFDRIVE && params->noise_on && !(params->options & BCP_OPT_DIFFDRIVE_NOISE))
+        return fail(BCP_E_INVALID, "bcp_create: the reference's DiffDriveRobot raises IndexError with noise_parameters "
+                                   "(differential_drive.py:73); set BCP_OPT_DIFFDRIVE_NOISE in bcp_params.options to opt in to "
+                                   "the unpinned 1-pose analogue");
     if (params->reward_provider != BCP_REWARD_CONTINUOUS && params->reward_provider != BCP_REWARD_PURE_PURSUIT)
         return fail(BCP_E_INVALID, "bcp_create: unknown reward provider %d", params->reward_provider);
     if (params->control_delay < 0 || params->pose_delay < 0 || params->state_delay < 0)
@@ -1063,6 +1078,9 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->ego_cells) (void)hipFree(h->ego_cells);
     if (h->ego_cell_counts) (void)hipFree(h->ego_cell_counts);
+    if (h->refresh_done) (void)hipEventDestroy(h->refresh_done);
+    if (h->waits_event) (void)hipEventDestroy(h->waits_event);
+    if (h->waits_host) (void)hipHostFree(h->waits_host);
     if (h->ring) (void)hipFree(h->ring);
     delete h;
     return BCP_OK;
@@ -1127,7 +1145,9 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
             h->near_dilate = value;
             return BCP_OK;
         case BCP_TUNE_EGO_SPARSE:
-            h->ego_sparse = value ? 1 : 0;
+            if (value < 0) return fail(BCP_E_INVALID, "bcp_set_tuning: BCP_TUNE_EGO_SPARSE takes 0, 1 or a limit of cells per map");
+            if (value != h->ego_sparse) h->ego_cells_built = false;   // (the lists are sized for the limit in force)
+            h->ego_sparse = value;
             return BCP_OK;
         case BCP_TUNE_FUSED:
             h->fused = value ? 1 : 0;
@@ -1147,7 +1167,7 @@ static void launch_ego_cells(bcp_handle* h, EntrySelect sel, int64_t max_entries
 {
     const MapDesc& m = h->map;
     hipLaunchKernelGGL(ego_cells_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(max_entries, 8192))), dim3(256), 0, s,
-                       h->map_data, sel, m.rows, m.cols, h->map_valid_rows, h->map_valid_cols, kEgoCellCap, h->ego_cells,
+                       h->map_data, sel, m.rows, m.cols, h->map_valid_rows, h->map_valid_cols, h->ego_cell_cap, h->ego_cells,
                        h->ego_cell_counts, h->ego_cell_counts + h->ego_cells_entries);
     h->ego_cells_max = -1;
 }
@@ -1160,7 +1180,7 @@ static void launch_pack_bitmap(bcp_handle* h, EntrySelect sel, int64_t max_entri
     // the cell lists of the sparse egocentric views follow the maps: all of them are rebuilt lazily after a re-bind
     // (sel.list == nullptr), the re-sampled entries of a pool refresh right here, in stream order
     if (h->ego_cells_built) {
-        if (sel.list) launch_ego_cells(h, sel, max_entries, s);
+        if (sel.list && h->ego_cell_counts) launch_ego_cells(h, sel, max_entries, s);
         else h->ego_cells_built = false;
     }
 }
@@ -1231,6 +1251,8 @@ static int launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_ent
     return BCP_OK;
 }
 
+// (One scratch list per handle: the readers of the uint8 field of ONE handle must share a stream, like everything else a
+// handle does -- include/bcplan.h, "a handle is not thread-safe".)
 // Before anything reads the uint8 field (two-launch and single-kernel step forms, bcp_pose_collides,
 // bcp_get_distance_field): the transform of the entries a tiles-only refresh has left stale, on the reader's stream.  An
 // entry is marked at the end of its refresh, in the refresh's stream order, so a refresh still running on another stream
@@ -1238,6 +1260,13 @@ static int launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_ent
 static int ensure_fields(bcp_handle* h, hipStream_t s)
 {
     if (!h->edt_lazy || !h->cull.edt || !h->edt_stale) return BCP_OK;
+    // Has every tiles-only refresh issued so far finished?  Then this pass leaves no stale field behind and later calls can
+    // skip their three launches until the next such refresh (which raises the flag again).
+    bool settled = false;
+    if (h->refresh_recorded) {
+        settled = hipEventQuery(h->refresh_done) == hipSuccess;
+        if (!settled) (void)hipGetLastError();   // (hipErrorNotReady)
+    }
     const int64_t entries = h->edt_stale_cap;
     int32_t* count = h->edt_stale_list + entries;
     HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), s));
@@ -1246,6 +1275,7 @@ static int ensure_fields(bcp_handle* h, hipStream_t s)
     const EntrySelect sel = {h->edt_stale_list, count, entries};
     launch_edt(h, sel, entries, s);
     HIP_TRY(hipGetLastError());
+    if (settled) h->edt_lazy = false;
     return BCP_OK;
 }
 
@@ -1775,6 +1805,50 @@ static int check_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, cons
     return BCP_OK;
 }
 
+// A wait of step_local_kernel that gives up lets its envs finish as free (bcp_step.h: BCP_ERR_INTERNAL): a training loop
+// that never calls bcp_expired_waits would not notice.  So bcp_step itself looks, without ever waiting for the GPU: every
+// kWatchdogSteps calls the counter is copied to pinned host memory behind the step just launched, and a later call, once
+// that copy has landed, compares it with what was seen before.
+constexpr uint32_t kWatchdogSteps = 256;
+
+static int step_watchdog(bcp_handle* h, hipStream_t s)
+{
+    if (h->last_step_form != 3) return BCP_OK;   // (only step_local_kernel has such waits)
+    if (h->waits_in_flight) {
+        const hipError_t q = hipEventQuery(h->waits_event);
+        if (q == hipSuccess) {
+            h->waits_in_flight = false;
+            const uint64_t now = *h->waits_host;
+            if (now > h->waits_seen) {
+                const uint64_t fresh = now - h->waits_seen;
+                h->waits_seen = now;
+                return fail(BCP_E_INTERNAL, "bcp_step: %llu bounded wait(s) of the step kernel gave up during earlier steps "
+                                            "(BCP_ERR_INTERNAL in err[] marks the envs; their verdicts are unreliable)",
+                            (unsigned long long)fresh);
+            }
+        } else {
+            (void)hipGetLastError();   // hipErrorNotReady is not an error here
+        }
+        return BCP_OK;
+    }
+    if (++h->steps_since_probe < kWatchdogSteps) return BCP_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return BCP_OK;   // (a captured step is replayed without this function: the caller asks bcp_expired_waits)
+    }
+    if (!h->waits_host) {
+        HIP_TRY(hipHostMalloc((void**)&h->waits_host, sizeof(uint64_t), hipHostMallocDefault));
+        *h->waits_host = 0;
+        HIP_TRY(hipEventCreateWithFlags(&h->waits_event, hipEventDisableTiming));
+    }
+    HIP_TRY(hipMemcpyAsync(h->waits_host, h->tick + 4, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(h->waits_event, s));
+    h->waits_in_flight = true;
+    h->steps_since_probe = 0;
+    return BCP_OK;
+}
+
 extern "C" int bcp_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, void* stream)
 {
     int rc = check_step(h, io, flags, "bcp_step");
@@ -1783,7 +1857,7 @@ extern "C" int bcp_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, vo
     rc = launch_step(h, io, flags, (hipStream_t)stream);
     if (rc != BCP_OK) return rc;
     HIP_TRY(hipGetLastError());
-    return BCP_OK;
+    return step_watchdog(h, (hipStream_t)stream);
 }
 
 extern "C" int bcp_side_stream(bcp_handle* h, int32_t cu_percent, void** stream)
@@ -1828,6 +1902,17 @@ extern "C" int bcp_expired_waits(bcp_handle* h, int64_t* count, void* stream)
     HIP_TRY(hipSetDevice(h->device));
     uint64_t v = 0;
     HIP_TRY(hipMemcpyAsync(&v, h->tick + 4, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    *count = (int64_t)v;
+    return BCP_OK;
+}
+
+extern "C" int bcp_parked_poses(bcp_handle* h, int64_t* count, void* stream)
+{
+    if (!h || !count) return fail(BCP_E_INVALID, "bcp_parked_poses: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    uint64_t v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, h->tick + 5, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     *count = (int64_t)v;
     return BCP_OK;
@@ -2135,6 +2220,24 @@ extern "C" int bcp_egocentric_shape(bcp_handle* h, const double* window_size, in
     return BCP_OK;
 }
 
+// The cost model of the sparse route (tools/bench_ego_cells.py measures both sides on the box): per image the fill-and-patch
+// kernel pays ~0.4 instructions per listed cell for the culling pass and ~2.5 per cell that meets the window, the sampling
+// kernels ~0.1 per destination pixel when the map is staged in LDS whole and five times that when every workgroup stages the
+// part of the map its window sees.  BCP_TUNE_EGO_SPARSE >= 2 is an explicit limit (tests, sweeps).
+static int32_t ego_sparse_limit(int32_t tuning, int64_t pixels, bool fits_lds)
+{
+    if (tuning >= 2) return tuning;
+    const int64_t lim = fits_lds ? pixels / 8 : pixels / 2;
+    return (int32_t)std::max<int64_t>(kEgoCellCapMin, std::min<int64_t>(lim, 16384));
+}
+
+extern "C" int bcp_egocentric_route(bcp_handle* h, int32_t* info4)
+{
+    if (!h || !info4) return fail(BCP_E_INVALID, "bcp_egocentric_route: null argument");
+    for (int k = 0; k < 4; ++k) info4[k] = h->ego_route[k];
+    return BCP_OK;
+}
+
 extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64_t n, const double* window_origin,
                                        const double* window_size, uint8_t border_value, uint8_t* out, void* stream)
 {
@@ -2191,41 +2294,70 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
     cus = std::max(cus, 1);
     const dim3 block(256);
     // Sparse maps and a zero border (extract_egocentric_costmap's default): zero fill + one patch per non-zero source cell
-    // (ego_sparse_kernel).  Decided per call from the lists of non-zero cells: they are built on the first such call after
-    // the maps were (re)bound -- one pass over the maps and one read-back of the largest count -- and kept up to date by the
-    // pool refresh.  Dense maps (any entry with more than kEgoCellCap non-zero cells) keep the sampling kernels below.
+    // (ego_sparse_kernel).  Decided per call from the counts of non-zero cells: a counting pass over the maps on the first
+    // such call after the maps were (re)bound, one read-back of the largest count, lists sized from it; a pool refresh keeps
+    // counts and lists of the entries it re-samples up to date.  Maps with more cells than the cost model's limit (or a
+    // non-zero border) keep the sampling kernels below.
+    const bool fits_lds = map_bytes + 4 * row_bytes <= 150 * 1024;
+    h->ego_route[0] = h->ego_route[1] = h->ego_route[2] = h->ego_route[3] = 0;
     if (border_value == 0 && a.rows <= 4095 && a.cols <= 4095 && !h->ego_cells_refused && h->ego_sparse) {
         const int64_t entries = a.shared ? 1 : n_slots(h);
-        if (h->ego_cells_entries != entries || !h->ego_cells) {
-            if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
-    if (h->ego_cells) (void)hipFree(h->ego_cells);
+        const int32_t limit = ego_sparse_limit(h->ego_sparse, (int64_t)a.drows * a.dcols, fits_lds);
+        if (h->refresh_recorded && (!h->ego_cells_built || h->ego_cells_max < 0))
+            HIP_TRY(hipStreamWaitEvent(st, h->refresh_done, 0));   // (a refresh on another stream may still be writing the maps / counts)
+        if (h->ego_cells_entries != entries || !h->ego_cell_counts) {
+            if (h->ego_cells) (void)hipFree(h->ego_cells);
             if (h->ego_cell_counts) (void)hipFree(h->ego_cell_counts);
             h->ego_cells = nullptr;
             h->ego_cell_counts = nullptr;
+            h->ego_cells_entries = 0;
+            h->ego_cell_cap = 0;
             h->ego_cells_built = false;
-            if (hipMalloc((void**)&h->ego_cells, (size_t)entries * kEgoCellCap * sizeof(uint32_t)) != hipSuccess ||
-                hipMalloc((void**)&h->ego_cell_counts, (size_t)(entries + 1) * sizeof(int32_t)) != hipSuccess) {
+            if (hipMalloc((void**)&h->ego_cell_counts, (size_t)(entries + 1) * sizeof(int32_t)) != hipSuccess) {
                 (void)hipGetLastError();
-                if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
-    if (h->ego_cells) (void)hipFree(h->ego_cells);
-                h->ego_cells = nullptr;
                 h->ego_cell_counts = nullptr;
-                h->ego_cells_refused = true;   // (no room for the lists: not an error, the sampling kernels take over)
+                h->ego_cells_refused = true;   // (no room: not an error, the sampling kernels take over)
             } else {
                 h->ego_cells_entries = entries;
             }
         }
-        if (h->ego_cells && !h->ego_cells_built) {
-            HIP_TRY(hipMemsetAsync(h->ego_cell_counts + entries, 0, sizeof(int32_t), st));
+        if (h->ego_cell_counts && !h->ego_cells_built) {
+            // counting pass -> largest count -> stride of the lists -> lists
             const EntrySelect all = {nullptr, nullptr, entries};
+            if (h->ego_cells) (void)hipFree(h->ego_cells);
+            h->ego_cells = nullptr;
+            h->ego_cell_cap = 0;
+            HIP_TRY(hipMemsetAsync(h->ego_cell_counts + entries, 0, sizeof(int32_t), st));
             launch_ego_cells(h, all, entries, st);
+            HIP_TRY(hipMemcpyAsync(&h->ego_cells_max, h->ego_cell_counts + entries, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
             h->ego_cells_built = true;
+            if (h->ego_cells_max <= limit) {
+                // pool entries change under a refresh: leave room for a world with more cells than today's largest
+                int64_t cap = std::max<int64_t>(kEgoCellCapMin, ((int64_t)h->ego_cells_max + 63) & ~(int64_t)63);
+                const int64_t budget = (int64_t)1 << 30;   // bytes of lists per handle
+                if (entries * cap * 4 > budget) cap = ((int64_t)h->ego_cells_max + 63) & ~(int64_t)63;
+                if (cap > 0 && entries * cap * 4 <= budget &&
+                    hipMalloc((void**)&h->ego_cells, (size_t)entries * cap * sizeof(uint32_t)) == hipSuccess) {
+                    h->ego_cell_cap = (int32_t)cap;
+                    const int32_t counted = h->ego_cells_max;
+                    launch_ego_cells(h, all, entries, st);   // (the same counts again, and the lists)
+                    h->ego_cells_max = counted;
+                } else {
+                    (void)hipGetLastError();
+                    h->ego_cells = nullptr;
+                    if (cap > 0) h->ego_cells_refused = true;
+                }
+            }
         }
-        if (h->ego_cells && h->ego_cells_max < 0) {
+        if (h->ego_cell_counts && h->ego_cells_built && h->ego_cells_max < 0) {   // (a refresh re-counted some entries)
             HIP_TRY(hipMemcpyAsync(&h->ego_cells_max, h->ego_cell_counts + entries, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
-        if (h->ego_cells && h->ego_cells_max >= 0 && h->ego_cells_max <= kEgoCellCap) {
+        h->ego_route[1] = h->ego_cells_max;
+        h->ego_route[2] = h->ego_cell_cap;
+        h->ego_route[3] = limit;
+        if (h->ego_cells && h->ego_cells_built && h->ego_cells_max >= 0 && h->ego_cells_max <= limit) {
             // One image per wave, eight per workgroup: 8 192 short workgroups for 65 536 images.  (Round 3 first ran this kernel
             // persistently -- as many workgroups as the chip holds, 64 images per wave, the lanes sharing the transforms' float64
             // arithmetic: 11 % slower on the same box, 0.249 against 0.222 ms.  Stores from many short workgroups drain faster than
@@ -2234,12 +2366,14 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
             // 48 instead of 83 registers (3 - 8 % slower), fewer workgroups per CU by way of unused LDS (within the noise).)
             const dim3 wide(64 * kEgoWaves);
             const dim3 grid((unsigned)((n + kEgoWaves - 1) / kEgoWaves));
-            hipLaunchKernelGGL(ego_sparse_kernel, grid, wide, 0, st, a, h->ego_cells, h->ego_cell_counts, kEgoCellCap);
+            hipLaunchKernelGGL(ego_sparse_kernel, grid, wide, 0, st, a, h->ego_cells, h->ego_cell_counts, h->ego_cell_cap);
             HIP_TRY(hipGetLastError());
+            h->ego_route[0] = BCP_EGO_SPARSE;
             return BCP_OK;
         }
     }
-    if (!a.shared && map_bytes + 4 * row_bytes <= 150 * 1024 && n < ((int64_t)1 << 31)) {
+    if (!a.shared && fits_lds && n < ((int64_t)1 << 31)) {
+        h->ego_route[0] = BCP_EGO_BINNED;
         // private / pooled maps that fit LDS: group the images by map entry, then one workgroup per entry at a time
         const int64_t n_bins = n_slots(h);
         if (n_bins > h->ego_bins_cap) {
@@ -2279,7 +2413,7 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
         // shared map (staged in LDS when it fits) or maps too large for LDS: persistent workgroups, as many as are
         // resident at once
         // (gfx950 gives a workgroup up to 160 KB of LDS; a big copy costs occupancy, but LDS sampling still wins)
-        a.stage_map = (a.shared && map_bytes + 4 * row_bytes <= 150 * 1024) ? 1 : 0;
+        a.stage_map = (a.shared && fits_lds) ? 1 : 0;
         // too large: each workgroup stages just the part of the map its window can see -- at most the window's
         // diagonal (+ 2 px of rounding, + ring) squared
         const double diag = std::sqrt((double)a.drows * a.drows + (double)a.dcols * a.dcols);
@@ -2295,9 +2429,11 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
             if (px8) hipLaunchKernelGGL((ego_costmap_window_kernel<8>), grid, block, lds, st, a);
             else hipLaunchKernelGGL((ego_costmap_window_kernel<4>), grid, block, lds, st, a);
             HIP_TRY(hipGetLastError());
+            h->ego_route[0] = BCP_EGO_WINDOW;
             return BCP_OK;
         }
         const int waves = kEgoWaves;
+        h->ego_route[0] = a.stage_map ? BCP_EGO_STAGED : BCP_EGO_GLOBAL;
         const size_t lds = waves * row_bytes + (a.stage_map ? map_bytes : 0);
         const void* fn = a.stage_map ? (px8 ? (const void*)ego_costmap_kernel<true, 8> : (const void*)ego_costmap_kernel<true, 4>)
                                      : (px8 ? (const void*)ego_costmap_kernel<false, 8> : (const void*)ego_costmap_kernel<false, 4>);
@@ -2488,6 +2624,9 @@ extern "C" int bcp_refresh_mini_worlds(bcp_handle* h, const bcp_mini_world_param
     hipLaunchKernelGGL(pool_initial_state_kernel, dim3(stride_grid(G, 256, true)), dim3(256), 0, s, sel, paths,
                        (int)h->path.max_len, init, h->init);
     HIP_TRY(hipGetLastError());
+    if (!h->refresh_done) HIP_TRY(hipEventCreateWithFlags(&h->refresh_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->refresh_done, s));
+    h->refresh_recorded = true;
     h->ring_planned = false;
     h->ring_refreshed = true;
     return BCP_OK;

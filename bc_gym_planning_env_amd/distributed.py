@@ -50,6 +50,11 @@ def init_from_env(backend=None, timeout_s=180, force=None):
             os.environ.setdefault("MASTER_PORT", "29517")
         kwargs = {}
         if backend == "nccl":
+            # The only collective of this job is a ~1 MB all-gather per 128 steps, and every compute unit its kernel holds is
+            # one the step kernel's workgroups queue for: cap RCCL at RCCL_CHANNELS channels (= workgroups = CUs, of 256)
+            # unless the job's environment says otherwise.  Must be set before the communicator exists.
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(RCCL_CHANNELS))
+            os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
             gpus = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
             local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
             if gpus < local_world:
@@ -61,6 +66,57 @@ def init_from_env(backend=None, timeout_s=180, force=None):
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
     return rank, world, local_rank
+
+
+RCCL_CHANNELS = 4   # workgroups RCCL's all-gather may run with (init_from_env)
+
+
+def geometry_digest(*arrays):
+    """SHA-256 over the bytes (and shapes / dtypes) of the arrays that make up a rank's replicated geometry -- shared
+    costmap, origin, resolution, shared path --, as four int64 (a tensor that any backend can gather)."""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(("%s%s|" % (a.dtype.str, a.shape)).encode())
+        h.update(a.tobytes())
+    return torch.from_numpy(np.frombuffer(h.digest(), dtype=np.int64).copy())
+
+
+def check_same_geometry(digest, group=None, what="the shared costmap / path"):
+    """Every rank steps replicas of ONE geometry (the shared costmap and path are replicated, each rank builds
+    its copy from its own inputs).  All-gather the ranks' digests and raise on every rank if any differs from rank 0's:
+    a job whose ranks disagree would train on a mixture nobody asked for, silently.  No-op without a process group."""
+    if not dist.is_initialized():
+        return
+    world = dist.get_world_size(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    mine = digest.to(torch.device("cuda", torch.cuda.current_device())) if on_gpu else digest.cpu()
+    out = torch.empty(world * mine.numel(), dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
+    rows = out.view(world, -1).cpu()
+    bad = [r for r in range(world) if not torch.equal(rows[r], rows[0])]
+    if bad:
+        raise RuntimeError("ranks %s hold a different copy of %s than rank 0: refusing to step a sharded batch on mixed geometry"
+                           % (bad, what))
+
+
+def broadcast_geometry(arrays, src=0, group=None):
+    """Rank `src`'s arrays for everybody (ncclBroadcast of SURVEY 8e; gloo on the CPU): a list of numpy arrays whose
+    shapes and dtypes all ranks already agree on (they come from the same configuration).  Returns numpy arrays."""
+    import numpy as np
+    if not dist.is_initialized():
+        return [np.ascontiguousarray(a) for a in arrays]
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    out = []
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(dev)
+        dist.broadcast(t, src=src, group=group)
+        out.append(t.cpu().numpy().view(a.dtype).reshape(a.shape))
+    return out
 
 
 def local_device(local_rank):

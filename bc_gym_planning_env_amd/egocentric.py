@@ -64,6 +64,13 @@ class BatchedEgocentricCostmap(object):
             self._border, self.images.data_ptr(), stream))
         return stream
 
+    def route(self):
+        """Which kernel drew the last observation (bcp_egocentric_route): dict(kernel=name, max_cells, list_stride, limit)."""
+        info = (C.c_int32 * 4)()
+        _lib.check(self._lib.bcp_egocentric_route(self.env._h, info))
+        return {"kernel": _lib.EGO_KERNELS.get(int(info[0]), "?"), "max_cells": int(info[1]), "list_stride": int(info[2]),
+                "limit": int(info[3])}
+
     def step(self, actions, **kw):
         _o, reward, done, info = self.env.step(actions, **kw)
         return self.observation(), reward, done, info

@@ -43,11 +43,17 @@ def get_footprint(robot_name, footprint_scale=1.0):
 
 
 def make_bcp_params(env_params, robot_name, noise_parameters, footprint_scale=1.0, dynamic_model=True,
-                    model_front_column_pid=True):
+                    model_front_column_pid=True, unpinned_diffdrive_noise=False):
     """EnvParams + robot -> bcp_params (include/bcplan.h)."""
     p = _lib.BcpParams()
     p.abi_version = _lib.ABI_VERSION
     p.model = MODELS[robot_name]
+    if p.model == _lib.MODEL_DIFFDRIVE and noise_parameters is not None:
+        if not unpinned_diffdrive_noise:
+            # what the reference's own DiffDriveRobot.step does with noise_parameters (differential_drive.py:73)
+            raise IndexError("too many indices for array: DiffDriveRobot with noise_parameters fails in the reference "
+                             "(new_pose[:, 2] on a 1-D pose); pass unpinned_diffdrive_noise=True for the unpinned analogue")
+        p.options |= _lib.OPT_DIFFDRIVE_NOISE
     fp = get_footprint(robot_name, footprint_scale)
     p.n_verts = len(fp)
     for k, (x, y) in enumerate(fp):

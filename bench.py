@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 65536
 GATHER_EVERY = 128        # multi-GPU: the done masks of this many steps travel in one all-gather (see run_rank): one
-                          # rollout of the reference's PPO runner (StepEnvRoller number_of_steps=128, scripts/rl_runners/ppo_runner.py:69)
+                          # rollout of the reference's PPO runner (StepEnvRoller number_of_steps=128, scripts/rl_runners/ppo_runner.py:70)
 MIN_REGION_MS = 50.0     # the timed region lasts at least this long (see run_rank: reps)
 # ALGORITHMIC bytes per env-step (DESIGN.md "Bytes"): SoA state in + out (7 f64 robot + min_dist f64 +
 # target_idx i32 + current_iter i32 + robot_collided u8 = 73 B each way) + action 2 x f32 + reward f64 + done u8.
@@ -102,10 +102,14 @@ def spawn_ranks(args, script=None, argv=None):
 
 
 # ------------------------------------------------------------------------------------------------ workloads
-def make_env(n, device, env_id_base, seed):
+def make_env(n, device, env_id_base, seed, broadcast=False):
     from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
     g = np.load(os.path.join(ROOT, "tests", "golden", "g8_traj_mini_00.npz"))
-    res = float(g["resolution"])
+    if broadcast:   # a sharded job: rank 0's copy of the shared costmap / origin / resolution / path for everybody
+        from bc_gym_planning_env_amd import distributed as bdist
+        names = ("costmap", "origin", "resolution", "path")
+        g = dict(zip(names, bdist.broadcast_geometry([g[k] for k in names])))
+    res = float(np.asarray(g["resolution"]).reshape(-1)[0])
     params = EnvParams(goal_spat_dist=0.2, goal_ang_dist=np.pi / 8, resolution=res, refine_path=False)
     env = BatchedPlanEnv(CostMap2D(g["costmap"], res, g["origin"]), g["path"], params, n_envs=n, device=device,
                          auto_reset=True, env_id_base=env_id_base, seed=seed)
@@ -152,7 +156,8 @@ def cpu_baseline(g, envs=ENVS_PER_GPU, budget_s=12.0):
     import oracle
     avail = usable_cores()
     p = oracle.make_params("tricycle", noise=oracle.PLANENV_NOISE, spatial_precision=0.2, angular_precision=np.pi / 8)
-    ref = oracle.OracleBatch(p, envs, g["costmap"], g["origin"], float(g["resolution"]), g["path"])
+    res = float(np.asarray(g["resolution"]).reshape(-1)[0])
+    ref = oracle.OracleBatch(p, envs, g["costmap"], g["origin"], res, g["path"])
     ref.reset_from_paths()
     rng = np.random.RandomState(1)
     lo = np.array([np.pi / 30, -np.pi / 2])
@@ -176,7 +181,7 @@ def cpu_baseline(g, envs=ENVS_PER_GPU, budget_s=12.0):
     ref.run_steps(acts, zs, steps, threads=threads)
     dt = time.perf_counter() - t0
     # C1 (BASELINE.json configs[0]): ONE RandomMiniEnv, random actions, reset on done -- the reference's own shape
-    ref1 = oracle.OracleBatch(p, 1, g["costmap"], g["origin"], float(g["resolution"]), g["path"])
+    ref1 = oracle.OracleBatch(p, 1, g["costmap"], g["origin"], res, g["path"])
     ref1.reset_from_paths()
     a1 = rng.uniform(lo, hi, (4096, 1, 2)).astype(np.float32).astype(np.float64)
     z1 = rng.standard_normal((4096, 1, 3))
@@ -212,6 +217,42 @@ def newest_profile(name):
         return os.path.relpath(best[1], ROOT), data
     except (OSError, ValueError, KeyError, TypeError):
         return None, None
+
+
+def issue_object(name="step_alu_pmc.json", waves_per_simd=4):
+    """The resource that binds the shared-map step (ALU / latency, not HBM): what the SQ counters of the newest
+    committed profiles/rNN_<name> say about the step kernel's waves.  PMC passes cannot run inside bench.py; the file is named."""
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_" + name)):
+        m = re.match(r"^r(\d+)_" + re.escape(name) + "$", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    if best is None:
+        return None
+    try:
+        with open(best[1]) as f:
+            d = json.load(f)["derived"]["step_local_kernel"]
+        valu = d["valu_active_fraction_of_wave_cycles"]
+        return {"bound": "instruction issue + dependent-chain latency (no HBM or MFMA roofline applies: 163 B and no contraction per env-step)",
+                "valu_busy_per_simd": valu * waves_per_simd, "waves_per_simd": waves_per_simd,
+                "wave_cycles": {"waiting": d["waiting_fraction_of_wave_cycles"], "issuing": d["issuing_fraction_of_wave_cycles"],
+                                "issue_stalled": d["issue_stalled_fraction_of_wave_cycles"], "valu_active": valu,
+                                "scalar_active": d.get("scalar_active_fraction_of_wave_cycles"),
+                                "lds_active": d.get("lds_active_fraction_of_wave_cycles")},
+                "instructions_per_wave": {k.replace("_instructions_per_wave", ""): v for k, v in d.items() if k.endswith("_instructions_per_wave")},
+                "icache_miss_fraction": d.get("icache_miss_fraction_of_requests"),
+                "what": "valu_busy_per_simd = fraction of its lifetime in which a wave has a VALU instruction executing x the waves "
+                        "resident per SIMD: the share of the step during which a SIMD's vector ALU is busy (1 = saturated)",
+                "source": os.path.relpath(best[1], ROOT)}
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
+def parked_fraction(env, run, steps):
+    """Share of env-steps whose pose needed the exact footprint test (bcp_parked_poses) over `steps` steps driven by run()."""
+    before = env.parked_poses()
+    run()
+    return (env.parked_poses() - before) / float(env.n_envs * steps)
 
 
 def steady_state(env, pool, rng):
@@ -257,9 +298,10 @@ def aux_other_configs(device):
                                       for _ in range(8)])).to(env.device)
     steady_state(env, pool, rng)
     ms = env.time_steps(pool[0], 200)
+    parked_c2 = parked_fraction(env, lambda: env.time_steps(pool[0], 100), 100)
     out["c2_diffdrive_4096_shared_64x64"] = {
         "what": "BASELINE configs[1]: RandomMiniEnv geometry at 5.5 m / 64 px, 4096 envs, diff-drive model, noise off",
-        "ms_per_step": ms, "env_steps_per_s": n / (ms * 1e-3),
+        "ms_per_step": ms, "env_steps_per_s": n / (ms * 1e-3), "parked_pose_fraction": parked_c2,
         "roofline": {"bound": "hbm", "achieved": BYTES_PER_ENV_STEP_C2 * n / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": BYTES_PER_ENV_STEP_C2 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP_C2 * n,
@@ -275,22 +317,101 @@ def aux_other_configs(device):
     pool = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(8)])).to(env.device)
     steady_state(env, pool, rng)
     ms = env.time_steps(pool[0], 100)
+    parked = parked_fraction(env, lambda: env.time_steps(pool[0], 50), 50)
     path, pmc = newest_profile("c4_pmc_summary.json")
     traffic = pmc["corrected_bytes_per_step"]["total"] if pmc else None
-    ach = BYTES_PER_ENV_STEP_C4 * n / (ms * 1e-3) / 1e9
+    ach = (traffic / (ms * 1e-3) / 1e9) if traffic else None
+    survey = BYTES_PER_ENV_STEP_C4 * n / (ms * 1e-3) / 1e9
+    # what re-binding the 65 536 private maps costs (bcp_set_costmaps: lethal bitmaps, distance fields -- edt_lds_kernel --
+    # and their 1-bit tiles): irrelevant for static maps, the price of a RandomAisleTurnEnv that redraws its map on reset
+    k = env._keep
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream(env.device))
+    env.set_costmap_tensors(k["map"], k["origins"], env.resolution, k["vr"], k["vc"])
+    e1.record(torch.cuda.current_stream(env.device))
+    torch.cuda.synchronize()
+    rebuild_ms = e0.elapsed_time(e1)
+    setup = {"derived_map_data_rebuild_ms": rebuild_ms, "per_map_us": rebuild_ms * 1e3 / n,
+             "what": "bcp_set_costmaps on the resident [N, 256, 256] maps: pack_bitmap_kernel + edt_lds_kernel + near_tiles_kernel"}
     out["c4_aisle_private_maps"] = {
         "what": "BASELINE configs[3]: AisleTurnEnv at 10 m / 256 px, 65536 envs, private costmaps stored uint8 "
                 "[N, 256, 256] (valid 256 x 141, 4 templates x flips) + private 130-point paths, tricycle + noise",
-        "map_storage": list(env._keep["map"].shape), "setup_s": t_setup,
+        "map_storage": list(env._keep["map"].shape), "setup_s": t_setup, "setup_detail": setup,
         "ms_per_step": ms, "env_steps_per_s": n / (ms * 1e-3),
         "collisions_per_step": float(env.collided_now.float().mean()), "done_per_step": float(env.done.float().mean()),
-        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        "parked_pose_fraction": parked,
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (ach / HBM_PEAK_GBS) if ach else None,
                      "traffic": traffic, "traffic_source": path,
-                     "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP_C4 * n,
-                     "note": "algorithmic bytes per SURVEY 8(d): 163 state I/O + 900 footprint cells of the private uint8 "
-                             "map + 3120 of the private path; the kernels read a 1-bit lethal mask, a uint8 distance "
-                             "field and a bucketed path window instead, so the counter traffic is the honest figure"}}
+                     "bytes_basis": "HBM bytes the kernel really moves per launch (FETCH_SIZE / WRITE_SIZE passes of the committed "
+                                    "profile, calibrated) / this run's launch time: <= 1 by construction",
+                     "survey_algorithmic": {"bytes_per_launch": BYTES_PER_ENV_STEP_C4 * n, "gbs_if_moved": survey,
+                                            "quotient_of_peak": survey / HBM_PEAK_GBS, "not_a_utilisation": True,
+                                            "note": "SURVEY 8(d)'s 163 B state I/O + 900 footprint cells of the private uint8 map + "
+                                                    "3120 B of private path per env-step; the kernel reads 1-bit lethal masks, 1-bit "
+                                                    "distance tiles, float32 prefilter records and a bucketed path window instead and "
+                                                    "does not move these bytes"}}}
     env.close()
+    return out
+
+
+def aux_ego_aisle(device, n=ENVS_PER_GPU):
+    """The observation the reference's own vectorised consumer builds (scripts/rl_runners/ppo_runner.py:35-43:
+    ColoredEgoCostmapRandomAisleTurnEnv, envs/synth_turn_env.py:376-451) and EgocentricCostmap on the default AisleTurn map:
+    n replicas of the fixture's geometry at steady state, one observation call per timed repetition."""
+    import torch
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    from bc_gym_planning_env_amd.egocentric import BatchedColoredEgoCostmap, BatchedEgocentricCostmap
+    out = {}
+    rng = np.random.RandomState(5)
+    for key, fixture, wrapper, what in (
+            ("egocentric_aisle_default_map", "g10_ego_aisle.npz", BatchedEgocentricCostmap,
+             "EgocentricCostmap(AisleTurnEnv()) (envs/egocentric.py:102-160)"),
+            ("colored_ego_aisle_350x512", "g12_colored_ego.npz", BatchedColoredEgoCostmap,
+             "ColoredEgoCostmapRandomAisleTurnEnv's observation (envs/synth_turn_env.py:376-451), the env of ppo_runner.py:35-43")):
+        g = np.load(os.path.join(ROOT, "tests", "golden", fixture))
+        res = float(g["resolution"])
+        env = BatchedPlanEnv(CostMap2D(g["costmap"], res, g["origin"]), g["path"], EnvParams(resolution=res, refine_path=False),
+                             n_envs=n, auto_reset=True, device=device, seed=17)
+        pool = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(8)])).to(env.device)
+        steady_state(env, pool, rng)
+        wrap = wrapper(env)
+        stream = torch.cuda.current_stream(env.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            wrap.observation()
+        reps = 20
+        e0.record(stream)
+        for _ in range(reps):
+            wrap.observation()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        route = wrap.route()
+        img_bytes = wrap.images.numel()
+        env.set_tuning(ego_sparse=0)          # the sampling kernel the same call fell to before round 4
+        for _ in range(2):
+            wrap.observation()
+        e0.record(stream)
+        for _ in range(5):
+            wrap.observation()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms_dense = e0.elapsed_time(e1) / 5
+        dense_route = wrap.route()
+        env.set_tuning(ego_sparse=1)
+        ach = img_bytes / (ms * 1e-3) / 1e9
+        out[key] = {"what": "%s for %d envs: costmap %s -> %d x %d px uint8 per env" % ((what, n, list(g["costmap"].shape)) + wrap.image_shape),
+                    "kernel": route["kernel"], "non_zero_cells_of_the_map": route["max_cells"], "sparse_limit": route["limit"],
+                    "ms_per_call": ms, "bytes_written_per_call": img_bytes,
+                    "lethal_pixel_fraction": float((wrap.images == 254).float().mean()),
+                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                 "bytes_basis": "algorithmic = bytes written: every image byte is stored once, inputs are cache-resident"},
+                    "sampling_kernel_same_call": {"kernel": dense_route["kernel"], "ms_per_call": ms_dense,
+                                                  "frac": img_bytes / (ms_dense * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        env.close()
+        del wrap, env, pool
+        torch.cuda.empty_cache()
     return out
 
 
@@ -322,7 +443,7 @@ def aux_measurements(env, pool, n):
     out["egocentric_observation"] = {
         "what": "EgocentricCostmap.observation for every env: %d x %d px uint8 + goal_n_state (envs/egocentric.py:102-160)"
                 % wrap.image_shape,
-        "kernel": "ego_sparse_kernel (zero fill + one patch per non-zero source cell; ego_costmap_kernel for maps that do not qualify)", "ms_per_call": ms, "bytes_written_per_call": img_bytes,
+        "kernel": wrap.route()["kernel"], "non_zero_cells_of_the_map": wrap.route()["max_cells"], "ms_per_call": ms, "bytes_written_per_call": img_bytes,
         "roofline": {"bound": "hbm", "achieved": img_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": img_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "step_plus_observation_ms": ms_both, "env_steps_per_s_with_observation": n / (ms_both * 1e-3)}
@@ -401,49 +522,24 @@ def run_rank(args):
     device = bdist.local_device(local_rank)
     torch.cuda.set_device(device)
     n = args.envs_per_gpu
-    env, g = make_env(n, device, env_id_base=rank * n, seed=2024)
     sharded = dist.is_initialized()     # world > 1, or a forced group at world size 1 (BCP_DIST_FORCE=1)
+    # the replicated geometry comes from rank 0 (one broadcast at set-up), and every rank proves it holds the same
+    env, g = make_env(n, device, env_id_base=rank * n, seed=2024, broadcast=sharded)
+    bdist.check_same_geometry(env.geometry_digest())
     backend = dist.get_backend() if sharded else None
     # Multi-GPU: the only cross-rank traffic is the done mask.  Every rank writes its mask of step k into row k % R of a
     # ring (the step kernel stores it there directly) and the ring is all-gathered every R steps, asynchronously (the
     # gather of one block overlaps the kernels of the next).  R = 128: the consumer the reference itself has, its PPO
-    # runner, collects 128 steps per rollout before it looks at anything (ppo_runner.py:69).  One gather costs ~31 us of
+    # runner, collects 128 steps per rollout before it looks at anything (ppo_runner.py:70).  One gather costs ~31 us of
     # launch work on the host and of stream time whatever it carries (measured with the RCCL branch forced at world size 1:
     # R = 8 15.4 us per step, 32 12.6, 128 11.9, no group at all 11.55), so a short ring would measure the collective's
     # launch, not the step.  The rows of an unfinished block are gathered at the end of the timed region, inside it.
-    gather_every = max(1, int(args.gather_every))
-    ring = torch.zeros(gather_every, n, dtype=torch.uint8, device=torch.device("cuda", device)) if sharded else None
-    gather = bdist.DoneGather(gather_every * n, torch.device("cuda", device), packed=True) if sharded else None   # (one bit per env on the links)
-    if sharded:
-        # the first collectives run here, untimed (communicator set-up)
-        gather.launch(ring.view(-1))
-        gather.flush()
-        dist.barrier()
-        torch.cuda.synchronize()
-
+    # A sharded run also times rounds 1-2's definition (R = 8) in a second region and prints it beside the metric
+    # ("gather_every_8"), so that lines of different rounds can be compared.
     # pre-staged synthetic actions: a pool of 16 batches ~ U(action_space), float32, resident in HBM
     rng = np.random.RandomState(1234 + rank)
     pool = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(16)])).to(env.device)
-
-    def one_step(k):
-        if gather is None:
-            env.step(pool[k % 16])
-            return
-        env.step(pool[k % 16], done_out=ring[k % gather_every])
-        if k % gather_every == gather_every - 1:
-            gather.launch(ring.view(-1))
-
-    def drain():
-        """This rank's own work is finished: its gathers have landed and its stream is empty.  No collective in here."""
-        if gather is not None:
-            gather.flush()
-        torch.cuda.synchronize()
-
-    def barrier():
-        drain()
-        if sharded:
-            dist.barrier()
-            torch.cuda.synchronize()
+    stream = torch.cuda.current_stream(env.device)  # the stream libbcplan launches on
 
     def max_over_ranks(x):
         if not sharded:
@@ -452,60 +548,99 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # Pre-roll to the steady state of the rollout (untimed set-up): every env gets a random episode phase, then one
-    # full timeout's worth of steps runs, so that at any timed step the batch holds envs at all stages of an
-    # episode (fresh, en route, off the map, about to time out) instead of 65 536 envs marching in lock-step.
-    steady_state(env, pool, rng)
-    if gather is not None:   # first collectives outside the timed region whatever --warmup says (communicator set-up)
-        for _ in range(2):
+    state = {"k0": 0, "pre_rolled": False}
+
+    def measure(gather_every, warmup):
+        """One timed region with the done-mask ring of `gather_every` rows: dict(elapsed, stream_ms, total, reps)."""
+        ring = torch.zeros(gather_every, n, dtype=torch.uint8, device=torch.device("cuda", device)) if sharded else None
+        gather = bdist.DoneGather(gather_every * n, torch.device("cuda", device), packed=True) if sharded else None   # (one bit per env on the links)
+        if sharded:
+            # the first collectives run here, untimed (communicator set-up)
             gather.launch(ring.view(-1))
-    barrier()
+            gather.flush()
+            dist.barrier()
+            torch.cuda.synchronize()
 
-    stream = torch.cuda.current_stream(env.device)  # the stream libbcplan launches on
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    k0 = 0
-    for k in range(args.warmup):
-        one_step(k0 + k)
-    k0 += args.warmup
-    # How long is one block of `steps` steps?  (an untimed probe, so that --warmup 0 works too.)  A block shorter
-    # than MIN_REGION_MS is no instrument -- at the driver's --steps 20 it lasts 0.3 ms and one host synchronisation is
-    # 9 % of it -- so the timed region repeats the block `reps` times back to back; `steps` stays what was asked for,
-    # ms_per_step and value are per step.  Every rank uses the same `reps` (MAX of the probes).
-    # (the probe's first block only fills the launch queue -- timed from a standing start it reads up to 20 % slow, and
-    #  the region then ends before MIN_REGION_MS --, its second block is the one that is timed; 10 % on top)
-    probe = max(1, min(args.steps, 32))
-    barrier()
-    for k in range(probe):
-        one_step(k0 + k)
-    ev0.record(stream)
-    for k in range(probe):
-        one_step(k0 + probe + k)
-    ev1.record(stream)
-    k0 += 2 * probe
-    drain()
-    probe_ms = max_over_ranks(ev0.elapsed_time(ev1) / probe)
-    reps = args.reps if args.reps > 0 else int(min(8192, max(1, np.ceil(1.1 * MIN_REGION_MS / max(probe_ms * args.steps, 1e-6)))))
-    k0 = (k0 + gather_every - 1) // gather_every * gather_every   # (the ring starts the region at row 0)
-    total = reps * args.steps
+        def one_step(k):
+            if gather is None:
+                env.step(pool[k % 16])
+                return
+            env.step(pool[k % 16], done_out=ring[k % gather_every])
+            if k % gather_every == gather_every - 1:
+                gather.launch(ring.view(-1))
 
-    # ---- the timed region: barrier + synchronize | reps x steps steps | this rank's stream and gathers drained ----
-    # The clock of a rank stops when ITS work is done (drain: no collective); the closing barrier comes after it and
-    # is not part of what `value` is computed from; the job's time is the MAX over ranks.  Beside the wall clock the
-    # device time of the same region (HIP events on the launch stream, MAX over ranks).
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for k in range(total):
-        one_step(k0 + k)
-    if gather is not None and total % gather_every:   # (the rows of the last, unfinished block)
-        gather.launch(ring.view(-1))
-    ev1.record(stream)
-    drain()
-    elapsed_local = time.perf_counter() - t0
-    barrier()
-    stream_ms_local = ev0.elapsed_time(ev1)
-    elapsed = max_over_ranks(elapsed_local)
-    stream_ms = max_over_ranks(stream_ms_local)
+        def drain():
+            """This rank's own work is finished: its gathers have landed and its stream is empty.  No collective in here."""
+            if gather is not None:
+                gather.flush()
+            torch.cuda.synchronize()
+
+        def barrier():
+            drain()
+            if sharded:
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        # Pre-roll to the steady state of the rollout (untimed set-up): every env gets a random episode phase, then one
+        # full timeout's worth of steps runs, so that at any timed step the batch holds envs at all stages of an
+        # episode (fresh, en route, off the map, about to time out) instead of 65 536 envs marching in lock-step.
+        if not state["pre_rolled"]:
+            steady_state(env, pool, rng)
+            state["pre_rolled"] = True
+        if gather is not None:   # first collectives outside the timed region whatever --warmup says (communicator set-up)
+            for _ in range(2):
+                gather.launch(ring.view(-1))
+        barrier()
+
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0 = state["k0"]
+        for k in range(warmup):
+            one_step(k0 + k)
+        k0 += warmup
+        # How long is one block of `steps` steps?  (an untimed probe, so that --warmup 0 works too.)  A block shorter
+        # than MIN_REGION_MS is no instrument -- at the driver's --steps 20 it lasts 0.3 ms and one host synchronisation is
+        # 9 % of it -- so the timed region repeats the block `reps` times back to back; `steps` stays what was asked for,
+        # ms_per_step and value are per step.  Every rank uses the same `reps` (MAX of the probes).
+        # (the probe's first block only fills the launch queue -- timed from a standing start it reads up to 20 % slow, and
+        #  the region then ends before MIN_REGION_MS --, its second block is the one that is timed; 10 % on top)
+        probe = max(1, min(args.steps, 32))
+        barrier()
+        for k in range(probe):
+            one_step(k0 + k)
+        ev0.record(stream)
+        for k in range(probe):
+            one_step(k0 + probe + k)
+        ev1.record(stream)
+        k0 += 2 * probe
+        drain()
+        probe_ms = max_over_ranks(ev0.elapsed_time(ev1) / probe)
+        reps = args.reps if args.reps > 0 else int(min(8192, max(1, np.ceil(1.1 * MIN_REGION_MS / max(probe_ms * args.steps, 1e-6)))))
+        k0 = (k0 + gather_every - 1) // gather_every * gather_every   # (the ring starts the region at row 0)
+        total = reps * args.steps
+
+        # ---- the timed region: barrier + synchronize | reps x steps steps | this rank's stream and gathers drained ----
+        # The clock of a rank stops when ITS work is done (drain: no collective); the closing barrier comes after it and
+        # is not part of what `value` is computed from; the job's time is the MAX over ranks.  Beside the wall clock the
+        # device time of the same region (HIP events on the launch stream, MAX over ranks).
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for k in range(total):
+            one_step(k0 + k)
+        if gather is not None and total % gather_every:   # (the rows of the last, unfinished block)
+            gather.launch(ring.view(-1))
+        ev1.record(stream)
+        drain()
+        elapsed_local = time.perf_counter() - t0
+        barrier()
+        stream_ms_local = ev0.elapsed_time(ev1)
+        state["k0"] = k0 + total
+        return {"elapsed": max_over_ranks(elapsed_local), "stream_ms": max_over_ranks(stream_ms_local), "total": total, "reps": reps}
+
+    gather_every = max(1, int(args.gather_every))
+    main_run = measure(gather_every, args.warmup)
+    short_run = measure(8, 0) if sharded and gather_every != 8 else None   # rounds 1-2's ring, for comparison across rounds
+    elapsed, stream_ms, total, reps = main_run["elapsed"], main_run["stream_ms"], main_run["total"], main_run["reps"]
     env.check_errors()
 
     # The step's launches run back to back on one stream; their combined average duration is measured live with HIP
@@ -554,9 +689,19 @@ def run_rank(args):
                          "kernel": kernels, "kernel_ms": step_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n,
                          "traffic_source": traffic_src,
+                         "issue": issue_object(),
                          "note": "shared-map config is latency-bound (SURVEY 8d): the HBM fraction is low by "
                                  "construction; see DESIGN.md.  The HBM-bound config is aux.c4_aisle_private_maps"},
         }
+        out["gather_every"] = gather_every if sharded else None
+        out["done_masks_packed"] = bool(sharded)
+        if short_run is not None:
+            out["gather_every_8"] = {"value": total_envs * short_run["total"] / short_run["elapsed"], "unit": "env-steps/s",
+                                     "ms_per_step": short_run["elapsed"] / short_run["total"] * 1e3,
+                                     "device_ms_per_step": short_run["stream_ms"] / short_run["total"],
+                                     "what": "the same workload with the done-mask ring of rounds 1-2 (one all-gather per 8 steps, "
+                                             "bit-packed): a second timed region of this run, NOT the metric"}
+        out["parked_pose_fraction"] = parked_fraction(env, lambda: [env.step(pool[k % 16]) for k in range(64)], 64)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g)
         if world == 1 and not args.no_aux:
@@ -565,6 +710,7 @@ def run_rank(args):
                 env.close()
                 del env
                 torch.cuda.empty_cache()
+                aux.update(aux_ego_aisle(device))
                 aux.update(aux_other_configs(device))
                 out["aux"] = aux
             except Exception as exc:  # noqa: BLE001

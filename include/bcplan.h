@@ -50,7 +50,10 @@ enum {
     BCP_E_INVALID = -1,   /* bad argument / unsupported configuration */
     BCP_E_NO_DEVICE = -2, /* no usable GPU: the product has no CPU path */
     BCP_E_HIP = -3,       /* a HIP runtime call failed (message has the hipError string) */
-    BCP_E_STATE = -4      /* call order violated (e.g. step before costmaps/paths/state were bound) */
+    BCP_E_STATE = -4,     /* call order violated (e.g. step before costmaps/paths/state were bound) */
+    BCP_E_INTERNAL = -5   /* bcp_step's watchdog: a bounded hand-off wait inside an EARLIER step launch gave up (see
+                             bcp_expired_waits); the steps since then ran, but results of the affected workgroups are
+                             unreliable -- a defect of the library, never of the data */
 };
 
 /* per-env error bits written to bcp_step_io.err (mirror of the reference's Python exceptions) */
@@ -69,6 +72,15 @@ enum {
                                 otherwise float64[N,2].  float32 is widened to float64 before any arithmetic */
 };
 
+/* bcp_params.options */
+enum {
+    BCP_OPT_DIFFDRIVE_NOISE = 1 /* DiffDriveRobot with noise_parameters raises IndexError in the reference itself
+                                   (robot_models/differential_drive.py:73: new_pose[:, 2] on a 1-D pose), so there is no
+                                   reference behaviour to match: bcp_create refuses model = BCP_MODEL_DIFFDRIVE with noise_on
+                                   (BCP_E_INVALID) unless this bit opts in to the UNPINNED 1-pose analogue of
+                                   kinematic_body_pose_motion_step_with_noise */
+};
+
 /* POD flattening of EnvParams (envs/base/params.py:14-42), RewardParams (envs/base/reward.py:162-171),
  * the TricycleRobot switches (robot_models/tricycle_model.py:296-300) and the robot constants
  * (robot_models/robot_dimensions_examples.py:108-188).  host struct. */
@@ -80,7 +92,7 @@ typedef struct bcp_params {
     int32_t model_front_column_pid; /* TricycleRobot._model_front_column_pid */
     int32_t noise_on;               /* noise_parameters is not None (env.py:226-232) */
     int32_t iteration_timeout;      /* EnvParams.iteration_timeout */
-    int32_t reserved0;
+    int32_t options;                /* BCP_OPT_* bits, 0 = none */
     double verts[BCP_MAX_VERTS][2]; /* metres, robot frame, already multiplied by footprint_scale */
     double dt;
     double front_wheel_from_axis;
@@ -161,7 +173,9 @@ int bcp_seed(bcp_handle *h, uint64_t seed);
  *   BCP_TUNE_FUSED            0 = settle the parked poses in a second launch (step_fast_pair_kernel + step_pending_kernel)
  *                             instead of inside the step launch itself (step_local_kernel, the default)
  *   BCP_TUNE_EGO_SPARSE       0 = egocentric views always sample the costmap pixel by pixel; 1 (default) = sparse maps with
- *                             border value 0 are drawn as a zero fill plus one patch per non-zero source cell
+ *                             border value 0 are drawn as a zero fill plus one patch per non-zero source cell, "sparse"
+ *                             decided by a cost model from the largest number of non-zero cells any map entry holds;
+ *                             >= 2 = the same with this explicit limit of cells per map (tests, sweeps)
  *   BCP_TUNE_NEAR_DILATE      how the 1-bit tiles of the distance field (bcp_get_near_field) are made: 0 = always by
  *                             thresholding the uint8 field; 1 (default) = a pool refresh (bcp_refresh_mini_worlds) under the
  *                             single-launch step dilates the lethal mask by the sample disc instead and leaves the uint8
@@ -297,6 +311,13 @@ int bcp_world_to_pixel(bcp_handle *h, const double *xy, int64_t n, const double 
 int bcp_egocentric_shape(bcp_handle *h, const double *window_size /*host, or NULL*/, int32_t *shape_hw /*host [2]*/);
 int bcp_egocentric_costmaps(bcp_handle *h, const double *poses, int64_t n, const double *window_origin /*host*/,
                             const double *window_size /*host*/, uint8_t border_value, uint8_t *out, void *stream);
+/* Which kernel the last bcp_egocentric_costmaps call of this handle ran (no reference counterpart: measurement and tests
+ * name the route instead of guessing it).  info4 (host int32[4]): BCP_EGO_* kernel, largest number of non-zero cells of
+ * any map entry (-1: not counted), stride of the cell lists, the limit of cells the route decision compared it with. */
+enum { BCP_EGO_NONE = 0, BCP_EGO_SPARSE = 1 /* ego_sparse_kernel */, BCP_EGO_STAGED = 2 /* ego_costmap_kernel, shared map in LDS */,
+       BCP_EGO_BINNED = 3 /* ego_costmap_binned_kernel */, BCP_EGO_WINDOW = 4 /* ego_costmap_window_kernel */,
+       BCP_EGO_GLOBAL = 5 /* ego_costmap_kernel sampling global memory */ };
+int bcp_egocentric_route(bcp_handle *h, int32_t *info4 /*host*/);
 /* EgocentricCostmap.observation's `goal_n_state` (envs/egocentric.py:140-160) for all envs: the next way point in
  * the robot frame (from_global_to_egocentric, coordinate_transformations.py:341-362) with its position divided by
  * world_size (host double[2] = CostMap2D.world_size() of the egocentric map) and clipped to [-1, 1], followed by
@@ -386,8 +407,16 @@ int bcp_side_stream(bcp_handle *h, int32_t cu_percent, void **stream);
  * wait that runs into its limit gives up -- the step still finishes; an env whose verdict never arrived is finished as
  * "free" with BCP_ERR_INTERNAL in `err` -- and is counted here.  *count = waits that gave up since bcp_create (host
  * pointer; the call synchronises `stream`).  Anything but 0 means a defect of the library, never of the caller's data.
- * No counterpart in the reference. */
+ * bcp_step also watches this counter by itself, without ever waiting for the GPU: every 256 calls it copies the counter to
+ * pinned host memory behind the step it has just launched, and a later bcp_step that finds the copy landed and the counter
+ * grown returns BCP_E_INTERNAL (once per growth; the step of that call has been launched all the same).  Steps replayed
+ * from a captured hipGraph do not pass through bcp_step: such callers ask here.  No counterpart in the reference. */
 int bcp_expired_waits(bcp_handle *h, int64_t *count, void *stream);
+/* Poses the single-launch step (step_local_kernel) could not clear by its distance-field classification and handed to the
+ * exact footprint test (pose_collides proper, envs/base/env.py:464-489), summed over all steps since bcp_create: the
+ * "parked-pose fraction" of a workload is the growth of this counter over a run / (n_envs * steps).  Host pointer; the call
+ * synchronises `stream`.  The other step forms do not count.  No counterpart in the reference (measurement only). */
+int bcp_parked_poses(bcp_handle *h, int64_t *count, void *stream);
 
 /* The standard normals a step draws when bcp_step_io.noise_z is NULL (the stand-in for np.random.normal of
  * robot_models/differential_drive.py:43-52): out double [n_steps][n_envs][3] = the three slots of envs first_env ..

@@ -107,3 +107,42 @@ def test_bench_launcher_relays_a_failing_rank(tmp_path):
     t0 = time.time()
     rc = bench.spawn_ranks(argparse.Namespace(gpus=4), script=path, argv=[])
     assert rc == 7 and time.time() - t0 < 30
+
+
+def _geometry_worker(rank, world, port, out_dir, tamper):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from bc_gym_planning_env_amd import distributed as bdist
+    bdist.init_from_env(backend="gloo")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g8_traj_mini_00.npz"))
+    arrays = [g["costmap"].copy(), g["origin"].copy(), np.asarray(g["resolution"]), g["path"].copy()]
+    if rank == 1:
+        arrays[0][40, 41] ^= 254          # this rank read a different map ...
+        arrays[3][5, 0] += 1e-9           # ... and a path that differs in one bit pattern
+    caught = None
+    try:
+        bdist.check_same_geometry(bdist.geometry_digest(*arrays))
+    except RuntimeError as exc:
+        caught = str(exc)
+    assert caught is not None and "[1]" in caught, (rank, caught)     # raised on EVERY rank, naming the odd one
+    # rank 0's copy for everybody (one broadcast at set-up): afterwards the digests agree
+    if not tamper:
+        arrays = bdist.broadcast_geometry(arrays)
+    else:                                  # (the broadcast really comes from `src`: rank 1's tampered copy wins here)
+        arrays = bdist.broadcast_geometry(arrays, src=1)
+    bdist.check_same_geometry(bdist.geometry_digest(*arrays))
+    ref = [g["costmap"], g["origin"], np.asarray(g["resolution"]), g["path"]]
+    same = all(np.array_equal(np.asarray(a).reshape(-1), np.asarray(b).reshape(-1)) for a, b in zip(arrays, ref))
+    assert same == (not tamper), rank
+    np.save(os.path.join(out_dir, "geom_ok_%d_%d.npy" % (rank, int(tamper))), np.array([1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_with_different_geometry_are_caught(tmp_path):
+    """A sharded job replicates the shared costmap / path on every rank: check_same_geometry stops the job when a rank
+    holds a different copy, broadcast_geometry hands out rank 0's (world size 2, gloo)."""
+    for tamper in (False, True):
+        mp.spawn(_geometry_worker, args=(2, _free_port(), str(tmp_path), tamper), nprocs=2, join=True)
+        assert all(os.path.exists(os.path.join(str(tmp_path), "geom_ok_%d_%d.npy" % (r, int(tamper)))) for r in range(2))

@@ -187,17 +187,26 @@ def test_g12_colored_ego_observation(torch_cuda):
     np.testing.assert_allclose(vec[:, :, 0], g["goal"], rtol=0, atol=1e-9)
 
 
-@pytest.mark.parametrize("kind", ["shared", "private"])
-def test_sparse_maps_fill_and_patch_vs_oracle(torch_cuda, oracle, kind):
+def _route(env):
+    import ctypes as C
+    from bc_gym_planning_env_amd import _lib
+    info = (C.c_int32 * 4)()
+    _lib.check(env._lib.bcp_egocentric_route(env._h, info))
+    return _lib.EGO_KERNELS[int(info[0])], int(info[1]), int(info[2]), int(info[3])
+
+
+@pytest.mark.parametrize("kind,cells", [("shared", 60), ("private", 60), ("shared", 700), ("private", 1500), ("pooled", 2000)],
+                         ids=["shared", "private", "shared-700-cells", "private-1500-cells", "pooled-2000-cells"])
+def test_sparse_maps_fill_and_patch_vs_oracle(torch_cuda, oracle, kind, cells):
     """Sparse costmaps with border value 0 take the fill-and-patch kernel (ego_sparse_kernel): a zero fill plus one patch
     per non-zero source cell.  Random poses far in and out of the map, several windows, maps with thin walls, isolated
     cells, cells on the map's edges and arbitrary non-zero values -- against the oracle, and against the sampling kernels
-    (BCP_TUNE_EGO_SPARSE = 0) bit for bit.  A map with more non-zero cells than a list holds routes the call to the
-    sampling kernels (same images)."""
+    (BCP_TUNE_EGO_SPARSE = 0) bit for bit.  Lists of 60 to ~2200 cells (round 3 stopped at 512), shared, private and pooled
+    maps; a dense map routes the call to the sampling kernels (same images)."""
     torch = torch_cuda
     import ctypes as C
     from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams, _lib
-    rng = np.random.RandomState(21)
+    rng = np.random.RandomState(21 + cells)
     n = 192
     res = 0.05
 
@@ -209,17 +218,31 @@ def test_sparse_maps_fill_and_patch_vs_oracle(torch_cuda, oracle, kind):
         m[0, 0] = m[-1, -1] = m[0, -1] = m[-1, 0] = 200    # the corners
         m[0, 3:9] = 17                                     # on the edges
         m[5:11, -1] = 18
+        if cells > 512:                                    # a filled block: hundreds of cells inside one window
+            m[20:20 + 18, 30:30 + 22] = 77
         return m
 
+    big = cells > 512
     shapes = [(90, 70)] if kind == "shared" else [(90, 70), (64, 101), (183, 183)]
-    maps = [sparse_map(s, 60) for s in shapes]
+    if big and kind == "shared":
+        shapes = [(200, 240)]
+    maps = [sparse_map(s, cells if i == len(shapes) - 1 else min(cells, 300)) for i, s in enumerate(shapes)]
     orgs = [rng.uniform(-2, 0, 2) for _ in shapes]
     path = np.array([[0., 0., 0.], [1., 0., 0.], [2., 0., 0.]])
     params = EnvParams(resolution=res, refine_path=False)
     if kind == "shared":
         env = BatchedPlanEnv(CostMap2D(maps[0], res, orgs[0]), path, params, n_envs=n)
-    else:
+        map_of = lambda i: 0
+    elif kind == "private":
         env = BatchedPlanEnv([CostMap2D(maps[i % 3], res, orgs[i % 3]) for i in range(n)], [path] * n, params, n_envs=n)
+        map_of = lambda i: i % 3
+    else:   # a geometry pool: 3 entries, envs spread over them
+        geom = (np.arange(n) * 7 % 3).astype(np.int32)
+        env = BatchedPlanEnv([CostMap2D(m, res, o) for m, o in zip(maps, orgs)], [path] * 3, params, n_envs=n, geom_of_env=geom)
+        geom = env.geom_of_env.cpu().numpy()      # (the constructor's reset() moves nobody: no successor table)
+        map_of = lambda i: int(geom[i])
+    most = max(int((m != 0).sum()) for m in maps)
+    assert (most > 512) == big
     poses = np.stack([rng.uniform(-3, 7, n), rng.uniform(-3, 7, n), rng.uniform(-7, 7, n)], axis=1)
     poses[0] = (0., 0., 0.)
     poses[1] = (1.0, 1.0, np.pi)
@@ -229,40 +252,121 @@ def test_sparse_maps_fill_and_patch_vs_oracle(torch_cuda, oracle, kind):
     pt = torch.from_numpy(poses).cuda()
     f64p = C.POINTER(C.c_double)
 
-    def draw(o, s, border):
+    def draw(e, o, s, border):
         shape = (C.c_int32 * 2)()
-        _lib.check(env._lib.bcp_egocentric_shape(env._h, s.ctypes.data_as(f64p) if s is not None else None, shape))
+        _lib.check(e._lib.bcp_egocentric_shape(e._h, s.ctypes.data_as(f64p) if s is not None else None, shape))
         out = torch.full((n, shape[0], shape[1]), 99, dtype=torch.uint8, device="cuda")
-        _lib.check(env._lib.bcp_egocentric_costmaps(env._h, pt.data_ptr(), n, o.ctypes.data_as(f64p) if o is not None else None,
-                                                    s.ctypes.data_as(f64p) if s is not None else None, border,
-                                                    out.data_ptr(), None))
+        _lib.check(e._lib.bcp_egocentric_costmaps(e._h, pt.data_ptr(), n, o.ctypes.data_as(f64p) if o is not None else None,
+                                                  s.ctypes.data_as(f64p) if s is not None else None, border,
+                                                  out.data_ptr(), None))
         return out.cpu().numpy()
 
     nonzero = 0
     for org, size in (((-0.5, -2.0), (3.5, 4.0)), ((-1.0, -1.0), (2.0, 2.0)), ((-3.0, -0.7), (6.05, 1.45)), ((-0.1, -0.15), (0.3, 0.25))):
         o, s = np.array(org, dtype=np.float64), np.array(size, dtype=np.float64)
-        env.set_tuning(ego_sparse=1)
-        got = draw(o, s, 0)
+        env.set_tuning(ego_sparse=4096)      # an explicit limit: small windows would otherwise send 2000 cells to the samplers
+        got = draw(env, o, s, 0)
+        kernel, counted, stride, limit = _route(env)
+        assert kernel == "ego_sparse_kernel" and counted == most and stride >= max(512, most) and limit == 4096
         env.set_tuning(ego_sparse=0)
-        sampled = draw(o, s, 0)
+        sampled = draw(env, o, s, 0)
+        assert _route(env)[0] != "ego_sparse_kernel"
         assert (got == sampled).all()
         for i in range(n):
-            k = 0 if kind == "shared" else i % 3
+            k = map_of(i)
             ref = oracle.extract_egocentric(maps[k], orgs[k], res, poses[i], o, s, 0)
             assert ref.shape == got[i].shape and (ref == got[i]).all(), (org, size, i, int((ref != got[i]).sum()))
         nonzero += int((got != 0).sum())
     assert nonzero > 2000
-    # a dense map: more non-zero cells than a list holds -> the sampling kernels, same answers
+    # the cost model (BCP_TUNE_EGO_SPARSE = 1) on the reference's own window: these lists qualify
     env.set_tuning(ego_sparse=1)
+    o, s = np.array((-0.5, -2.0)), np.array((3.5, 4.0))
+    again = draw(env, o, s, 0)
+    assert _route(env)[0] == ("ego_sparse_kernel" if most <= _route(env)[3] else _route(env)[0])
+    env.set_tuning(ego_sparse=0)
+    assert (again == draw(env, o, s, 0)).all()
+    # a non-zero border value is not this kernel's business
+    env.set_tuning(ego_sparse=1)
+    draw(env, o, s, 9)
+    assert _route(env)[0] != "ego_sparse_kernel"
+    # a dense map: more non-zero cells than the cost model's limit -> the sampling kernels, same answers
     dense = rng.randint(0, 256, shapes[0]).astype(np.uint8)
     if kind == "shared":
         env2 = BatchedPlanEnv(CostMap2D(dense, res, orgs[0]), path, params, n_envs=n)
-        o, s = np.array((-0.5, -2.0)), np.array((3.5, 4.0))
-        shape = (C.c_int32 * 2)()
-        _lib.check(env2._lib.bcp_egocentric_shape(env2._h, s.ctypes.data_as(f64p), shape))
-        out = torch.zeros((n, shape[0], shape[1]), dtype=torch.uint8, device="cuda")
-        _lib.check(env2._lib.bcp_egocentric_costmaps(env2._h, pt.data_ptr(), n, o.ctypes.data_as(f64p), s.ctypes.data_as(f64p), 0,
-                                                     out.data_ptr(), None))
-        got = out.cpu().numpy()
+        got = draw(env2, o, s, 0)
+        kernel, counted, _stride, limit = _route(env2)
+        assert kernel == "ego_costmap_kernel<staged>" and counted > limit
         for i in range(0, n, 7):
             assert (oracle.extract_egocentric(dense, orgs[0], res, poses[i], o, s, 0) == got[i]).all()
+
+
+def test_sparse_window_overflow_streams_the_list(torch_cuda, oracle):
+    """More cells inside one window than a wave holds back in LDS (kEgoHeld = 256): the wave streams the list behind the
+    fill instead.  A filled 40 x 40 block under the robot."""
+    torch = torch_cuda
+    import ctypes as C
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams, _lib
+    rng = np.random.RandomState(5)
+    res = 0.05
+    m = np.zeros((150, 160), dtype=np.uint8)
+    m[60:100, 50:90] = rng.randint(1, 256, (40, 40))
+    m[10, 5:150] = 254
+    org = np.array([-1.0, -0.5])
+    path = np.array([[0., 0., 0.], [1., 0., 0.], [2., 0., 0.]])
+    n = 64
+    env = BatchedPlanEnv(CostMap2D(m, res, org), path, EnvParams(resolution=res, refine_path=False), n_envs=n)
+    poses = np.stack([rng.uniform(0.5, 4.5, n), rng.uniform(1.5, 5.0, n), rng.uniform(-7, 7, n)], axis=1)
+    pt = torch.from_numpy(poses).cuda()
+    f64p = C.POINTER(C.c_double)
+    o, s = np.array((-0.5, -2.0)), np.array((3.5, 4.0))
+    shape = (C.c_int32 * 2)()
+    _lib.check(env._lib.bcp_egocentric_shape(env._h, s.ctypes.data_as(f64p), shape))
+    out = torch.full((n, shape[0], shape[1]), 99, dtype=torch.uint8, device="cuda")
+    env.set_tuning(ego_sparse=4096)
+    _lib.check(env._lib.bcp_egocentric_costmaps(env._h, pt.data_ptr(), n, o.ctypes.data_as(f64p), s.ctypes.data_as(f64p), 0,
+                                                out.data_ptr(), None))
+    assert _route(env)[0] == "ego_sparse_kernel"
+    got = out.cpu().numpy()
+    crowded = 0
+    for i in range(n):
+        ref = oracle.extract_egocentric(m, org, res, poses[i], o, s, 0)
+        assert (ref == got[i]).all(), i
+        crowded += int((ref != 0).sum() > 400)
+    assert crowded > 10
+
+
+def test_observation_after_a_masked_stream_refresh(torch_cuda, oracle):
+    """bcp_egocentric_costmaps used to destroy the handle's CU-masked side stream when it (re)built its cell
+    lists.  An endless pool refreshes on the masked stream, then the first observation is drawn (lists built), then the pool
+    refreshes on the same stream again and the observation follows the re-sampled worlds."""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import EnvParams, mini_env
+    from bc_gym_planning_env_amd.egocentric import BatchedEgocentricCostmap
+    params = mini_env.RandomMiniEnvParams(env_params=EnvParams(goal_ang_dist=np.pi / 8., goal_spat_dist=0.2, iteration_timeout=6))
+    n = 32
+    env = mini_env.BatchedRandomMiniEnv(n, params, episodes=4, endless=True, auto_reset=True, seed=4)
+    env.side_cu_percent = 50
+    wrap = BatchedEgocentricCostmap(env)
+    rng = np.random.RandomState(3)
+    res = params.env_params.resolution
+
+    def check(t):
+        img = wrap.observation()['env'].cpu().numpy()[..., 0]
+        assert wrap.route()["kernel"] == "ego_sparse_kernel"
+        st = env.state.robot.cpu().numpy()
+        geom = env.geom_of_env.cpu().numpy()
+        maps = env.pool.maps.cpu().numpy()
+        for i in range(n):
+            ref = oracle.extract_egocentric(maps[geom[i]], env.pool.origin, res, st[:3, i], (-0.5, -2.0), (3.5, 4.0))
+            assert (ref == img[i]).all(), (t, i)
+
+    for t in range(40):
+        env.step(env.action_space.sample_batch(n, rng))
+        if t % 8 == 7:
+            env.refresh(overlap=True)
+        if t in (9, 10, 25, 39):
+            if t == 39:
+                env.finish_refresh()
+            torch.cuda.synchronize()
+            check(t)
+    assert (env.geom_of_env.cpu().numpy() != np.arange(n) * 4 + 1).any()

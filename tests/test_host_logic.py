@@ -52,6 +52,17 @@ def test_no_gpu_means_loud_failure():
     assert b"no CPU path" in lib.bcp_last_error()
 
 
+def test_diffdrive_noise_raises_like_the_reference():
+    """differential_drive.py:73: DiffDriveRobot.step with noise_parameters is an IndexError in the reference"""
+    import pytest
+    from bc_gym_planning_env_amd import EnvParams, _lib, robots
+    with pytest.raises(IndexError):
+        robots.make_bcp_params(EnvParams(), 'industrial_diffdrive_v1', dict(robots.PLANENV_NOISE))
+    p = robots.make_bcp_params(EnvParams(), 'industrial_diffdrive_v1', dict(robots.PLANENV_NOISE), unpinned_diffdrive_noise=True)
+    assert p.options == _lib.OPT_DIFFDRIVE_NOISE
+    assert robots.make_bcp_params(EnvParams(), 'industrial_diffdrive_v1', None).options == 0
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "bc_gym_planning_env_amd")
     for dirpath, _, files in os.walk(pkg):
