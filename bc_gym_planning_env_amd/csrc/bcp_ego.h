@@ -814,53 +814,72 @@ __device__ __forceinline__ void ego_image_slow(const EgoArgs& a, const EgoImage&
 
 typedef uint32_t EgoU32x4 __attribute__((ext_vector_type(4)));
 
-// the 3 x 3 candidates of one source cell: cv::hal::warpAffine's expression decides which of them copy the cell
-__device__ __forceinline__ void ego_patch_cell(const EgoArgs& a, const EgoImage& I, uint8_t* __restrict__ image, uint32_t cell,
-                                               double f0, double f1, double f2, double f3, double f4, double f5)
+constexpr int kEgoHeld = 512;   // cells a wave can hold back in LDS between the culling pass and the patches
+
+// LDS of ego_sparse_kernel, per wave: cv::hal::warpAffine's column terms {adelta, bdelta}(x) = {sat(M0 x 1024), sat(M3 x 1024)}
+// for every column of the window, its row terms {sat((M1 y + M2) 1024) + 512, sat((M4 y + M5) 1024) + 512} for every row,
+// and the list of cells held back.
+static size_t ego_sparse_lds_bytes(int drows, int dcols, int waves)
+{
+    return (size_t)waves * ((size_t)(drows + dcols) * 8 + (size_t)kEgoHeld * 4);
+}
+
+typedef int EgoI32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) EgoI32x2* LdsI32x2;
+
+// the 3 x 3 candidates of one source cell: warpAffine's expression, from the tables, decides which of them copy the cell.
+// The forward position only has to put the candidates inside the block: float32 is within 2e-3 px of the float64 value
+// (every term is below 6 000 px when the sum is anywhere near the window), and a pixel that samples the cell lies within
+// 0.71 + 2^-9 px of the true position, so within 1.22 < 1.5 px of its rounding.
+__device__ __forceinline__ void ego_patch_cell(const EgoArgs& a, LdsI32x2 col_tab, LdsI32x2 row_tab, uint8_t* __restrict__ image,
+                                               uint32_t cell, float f0, float f1, float f2, float f3, float f4, float f5)
 {
     const int sx = (int)(cell & 0xFFFu), sy = (int)((cell >> 12) & 0xFFFu);
     const uint8_t v = (uint8_t)(cell >> 24);
-    const double fx = f0 * sx + f1 * sy + f2, fy = f3 * sx + f4 * sy + f5;
-    const int xc = (int)rint(fx), yc = (int)rint(fy);
-    int cx[3], cy[3];
+    const float fx = f0 * (float)sx + f1 * (float)sy + f2, fy = f3 * (float)sx + f4 * (float)sy + f5;
+    const int xc = (int)rintf(fx), yc = (int)rintf(fy);
+    EgoI32x2 ct[3];
+    bool xin[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {   // adelta / bdelta of the three candidate columns
-        cx[j] = sat_int(I.m0 * (xc - 1 + j) * 1024);
-        cy[j] = sat_int(I.m3 * (xc - 1 + j) * 1024);
+    for (int j = 0; j < 3; ++j) {
+        const int x = xc - 1 + j;
+        xin[j] = (unsigned)x < (unsigned)a.dcols;
+        ct[j] = col_tab[xin[j] ? x : 0];
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int y = yc - 1 + r;
         if ((unsigned)y >= (unsigned)a.drows) continue;
-        const int rx = sat_int((I.m1 * y + I.m2) * 1024) + 512, ry = sat_int((I.m4 * y + I.m5) * 1024) + 512;
+        const EgoI32x2 rt = row_tab[y];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int x = xc - 1 + j;
-            if ((unsigned)x < (unsigned)a.dcols && ((rx + cx[j]) >> 10) == sx && ((ry + cy[j]) >> 10) == sy)
-                image[(int64_t)y * a.dcols + x] = v;
-        }
+        for (int j = 0; j < 3; ++j)
+            if (xin[j] && ((rt.x + ct[j].x) >> 10) == sx && ((rt.y + ct[j].y) >> 10) == sy)
+                image[(int64_t)y * a.dcols + (xc - 1 + j)] = v;
     }
 }
-
-constexpr int kEgoHeld = 256;   // cells a wave can hold back in LDS between the culling pass and the patches
 
 // One wavefront per image (border value 0, cell lists built).  Order of a wave's work, chosen for what it waits on:
 //   A. the cell list is read and culled FIRST (four loads in flight per lane; the cells whose forward image meets the window
 //      are compacted into the wave's LDS list) -- loads and stores retire through one in-order counter on this chip, so a
-//      list load issued behind the zero fill would wait for every store of the fill;
+//      list load issued behind the zero fill would wait for every store of the fill --, and the wave writes warpAffine's
+//      column and row terms of THIS image into its LDS tables (the float64 arithmetic of the exact test, (drows + dcols) x 2
+//      evaluations per image instead of 12 per cell: round 4, the patches were 4 k cycles per 64 cells without the tables);
 //   B. the zero fill (all the HBM traffic there is);
 //   C. s_waitcnt vmcnt(0) -- a patch must not be overtaken by the zeros: same wave, same addresses, no other ordering --,
-//      then the patches, a held cell per lane.
+//      then the patches, a held cell per lane: integer adds and compares on table entries.
 // More than kEgoHeld cells inside one window (a dense corner of an otherwise sparse map): the wave streams the whole list once
-// more behind the fill, culling and patching 64 cells at a time through the same LDS list.
+// more behind the fill, culling and patching 64 cells at a time through the same LDS list (slow: every list load then waits
+// for the patch stores before it; the host's limit on cells per map keeps such windows rare).
 __global__ void __launch_bounds__(64 * kEgoWaves) ego_sparse_kernel(const EgoArgs a, const uint32_t* __restrict__ cells,
                                                                      const int32_t* __restrict__ counts, int cap)
 {
-    __shared__ uint32_t near_cells[kEgoWaves][kEgoHeld];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const int64_t P = (int64_t)a.drows * a.dcols;
     const int64_t first = (int64_t)blockIdx.x * waves + wave, stride = (int64_t)gridDim.x * waves;
-    uint32_t* const mine_cells = near_cells[wave];
+    const int per_wave_words = (a.drows + a.dcols) * 2 + kEgoHeld;
+    const LdsI32x2 col_tab = (LdsI32x2)((__attribute__((address_space(3))) uint32_t*)ego_lds + wave * per_wave_words);
+    const LdsI32x2 row_tab = col_tab + a.dcols;
+    __attribute__((address_space(3))) uint32_t* const mine_cells = (__attribute__((address_space(3))) uint32_t*)(row_tab + a.drows);
     for (int64_t base = first; base < a.n_images; base += 64 * stride) {
         EgoXform T;
         memset(&T, 0, sizeof(T));
@@ -878,16 +897,24 @@ __global__ void __launch_bounds__(64 * kEgoWaves) ego_sparse_kernel(const EgoArg
                 continue;
             }
             // forward map of a source cell: the inverse of the dst -> src matrix
-            const double det = I.m0 * I.m4 - I.m1 * I.m3;
-            const double id = det != 0.0 ? 1.0 / det : 0.0;
-            const double f0 = I.m4 * id, f1 = -I.m1 * id, f3 = -I.m3 * id, f4 = I.m0 * id;
-            const double f2 = -(f0 * I.m2 + f1 * I.m5), f5 = -(f3 * I.m2 + f4 * I.m5);
-            const double x_hi = (double)a.dcols + 1.0, y_hi = (double)a.drows + 1.0;
+            float f0, f1, f2, f3, f4, f5;
+            {
+                const double det = I.m0 * I.m4 - I.m1 * I.m3;
+                const double id = det != 0.0 ? 1.0 / det : 0.0;
+                const double d0 = I.m4 * id, d1 = -I.m1 * id, d3 = -I.m3 * id, d4 = I.m0 * id;
+                f0 = (float)d0;
+                f1 = (float)d1;
+                f2 = (float)(-(d0 * I.m2 + d1 * I.m5));
+                f3 = (float)d3;
+                f4 = (float)d4;
+                f5 = (float)(-(d3 * I.m2 + d4 * I.m5));
+            }
+            const float x_hi = (float)a.dcols + 1.0f, y_hi = (float)a.drows + 1.0f;
             const uint32_t* const list = cells + I.g * (int64_t)cap;
             auto meets_window = [&](uint32_t cell) -> bool {
-                const int sx = (int)(cell & 0xFFFu), sy = (int)((cell >> 12) & 0xFFFu);
-                const double fx = f0 * sx + f1 * sy + f2, fy = f3 * sx + f4 * sy + f5;
-                return cell != 0u && fx > -2.0 && fx < x_hi && fy > -2.0 && fy < y_hi;   // (a listed cell has a non-zero value byte)
+                const float sx = (float)(cell & 0xFFFu), sy = (float)((cell >> 12) & 0xFFFu);
+                const float fx = f0 * sx + f1 * sy + f2, fy = f3 * sx + f4 * sy + f5;
+                return cell != 0u && fx > -2.0f && fx < x_hi && fy > -2.0f && fy < y_hi;   // (a listed cell has a non-zero value byte)
             };
             // ---- A. cull: which cells can reach the window at all
             int held = 0;            // cells in the wave's LDS list (uniform)
@@ -909,6 +936,21 @@ __global__ void __launch_bounds__(64 * kEgoWaves) ego_sparse_kernel(const EgoArg
                     held += more;
                 }
             }
+            // ... and, if anything is left, warpAffine's terms of this image
+            if (held > 0 || overflow) {
+                for (int t = lane; t < a.dcols + a.drows; t += 64) {
+                    EgoI32x2 e;
+                    if (t < a.dcols) {
+                        e.x = sat_int(I.m0 * t * 1024);
+                        e.y = sat_int(I.m3 * t * 1024);
+                    } else {
+                        const int y = t - a.dcols;
+                        e.x = sat_int((I.m1 * y + I.m2) * 1024) + 512;
+                        e.y = sat_int((I.m4 * y + I.m5) * 1024) + 512;
+                    }
+                    col_tab[t] = e;   // (row_tab follows col_tab)
+                }
+            }
             // ---- B. zeros: bytes up to the first 16-byte boundary, aligned 16-byte stores, the tail
             {
                 const int head = (int)((16u - (uint32_t)(uintptr_t)image) & 15u);
@@ -927,7 +969,7 @@ __global__ void __launch_bounds__(64 * kEgoWaves) ego_sparse_kernel(const EgoArg
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             if (!overflow) {
                 for (int c0 = 0; c0 < held; c0 += 64)
-                    if (c0 + lane < held) ego_patch_cell(a, I, image, mine_cells[c0 + lane], f0, f1, f2, f3, f4, f5);
+                    if (c0 + lane < held) ego_patch_cell(a, col_tab, row_tab, image, mine_cells[c0 + lane], f0, f1, f2, f3, f4, f5);
                 __builtin_amdgcn_wave_barrier();
                 continue;
             }
@@ -946,13 +988,13 @@ __global__ void __launch_bounds__(64 * kEgoWaves) ego_sparse_kernel(const EgoArg
                     __builtin_amdgcn_wave_barrier();
                     held -= 64;
                     if (lane < held) mine_cells[lane] = keep;
-                    ego_patch_cell(a, I, image, take, f0, f1, f2, f3, f4, f5);
+                    ego_patch_cell(a, col_tab, row_tab, image, take, f0, f1, f2, f3, f4, f5);
                     __builtin_amdgcn_wave_barrier();
                 }
             }
             if (held > 0) {
                 const uint32_t take = mine_cells[lane < held ? lane : 0];
-                if (lane < held) ego_patch_cell(a, I, image, take, f0, f1, f2, f3, f4, f5);
+                if (lane < held) ego_patch_cell(a, col_tab, row_tab, image, take, f0, f1, f2, f3, f4, f5);
             }
             __builtin_amdgcn_wave_barrier();
         }

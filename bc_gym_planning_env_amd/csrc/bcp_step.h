@@ -137,10 +137,14 @@ struct StepArgs {
     // single-kernel step.  Two-kernel step: kernel 1 copies tick[0] to tick[1], kernel 2 stores tick[1] + 1 to tick[0]
     // -- each word is only written while no kernel that reads it is running.  Single-kernel step: the last workgroup
     // to finish (ticket) advances tick[0].  tick[4] counts the bounded waits of step_local_kernel that gave up (bcp_expired_waits).
+    // step_local_kernel draws its ticket EARLY (tick[8], a cache line of its own; see there) -- tick has 16 words.
     uint64_t* tick;
     int32_t* pending_base;     // [2][kShards] or nullptr
     int32_t* adapt_base;       // [2] thresholds + [2][kShards] in-place counters, or nullptr (no adaptation)
+    uint64_t* parked_slots;    // [workgroups of step_local_kernel] parked poses so far, a word per workgroup (bcp_parked_poses)
 };
+constexpr int kTickWords = 16;
+constexpr int kTickLocalTicket = 8;   // step_local_kernel's ticket: not on the line the prologues read the counter and the seed from
 
 constexpr uint32_t kStepAdvances = 1u << 24;   // internal flag: this launch is the last kernel of its step
 
@@ -183,6 +187,12 @@ enum : uint32_t {
     kAblateNoPark = 1u << 21,        // kernel 1: do not park undecided envs
     kAblateNoClassify = 1u << 22     // kernel 1: skip the distance-field lookups
 };
+// The ablation switches exist in -DBCP_DIAG builds only (tools/libbcplan_diag.so): the shipping kernels neither fetch nor test them.
+#ifdef BCP_DIAG
+#define ABLATED(a, bits) (((a).flags & (bits)) != 0)
+#else
+#define ABLATED(a, bits) false
+#endif
 
 
 constexpr int kBlock = 64;  // one wavefront per workgroup
@@ -870,7 +880,7 @@ __device__ __forceinline__ void finalize_env_from(const A& a, SP S, int64_t i, P
             rew = score.rew;
             min_dist = score.min_dist;
             target = score.target;
-        } else if (!(a.flags & kAblateNoReward)) {
+        } else if (!ABLATED(a, kAblateNoReward)) {
             rew = reward_pure_pursuit(pts, m, seen[0], seen[1], collided, min_dist, target);
         }
         goal = hypot(pts[5 * (m - 1)] - seen[0], pts[5 * (m - 1) + 1] - seen[1]) < 1.0;   // done(), reward.py:141-150
@@ -881,7 +891,7 @@ __device__ __forceinline__ void finalize_env_from(const A& a, SP S, int64_t i, P
             rew = score.rew;
             min_dist = score.min_dist;
             target = score.target;
-        } else if (!(a.flags & kAblateNoReward)) {
+        } else if (!ABLATED(a, kAblateNoReward)) {
             // way-point window of the pose: the caller may have looked it up already for the un-rolled-back pose
             const double* bbox = S->path.bbox + (S->path.shared ? 0 : g * kBoxDoubles);
             const int16_t* index = S->path.index + (S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
@@ -1057,7 +1067,7 @@ __global__ void __launch_bounds__(kBlock) step_kernel(const StepArgs launch_args
     q.drawn = 0;
     q.err = robot_step(P, q.r, cmd0, cmd1, q.z, q.drawn);
     bool hit = false;
-    if (!(a.flags & kAblateNoCollision))
+    if (!ABLATED(a, kAblateNoCollision))
         hit = collides_wave(P, a.S->map, a.S->cull, L, a.S->exact_mode, a.S->dense_threshold, a.S->wide != 0, active,
                             slot_of(a.S, i, q), q.r.p.x, q.r.p.y, q.r.p.th);
     if (active) finalize_env<false>(a, i, q, hit);
@@ -1178,7 +1188,7 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
         const int64_t map_env = a.S->map.shared ? 0 : g;
         OuterLookups look;
         look.off_map = true;
-        if (!(a.flags & (kAblateNoCollision | kAblateNoClassify)))
+        if (!ABLATED(a, kAblateNoCollision | kAblateNoClassify))
             look = outer_lookups_issue(a.S->cull, map_env, a.S->map.rows, a.S->map.cols, px, py, c, s);
         const int cls = active ? outer_lookups_verdict(a.S->cull, look) : kFree;
         const uint64_t amb = __ballot(cls == kAmbiguous);
@@ -1199,7 +1209,7 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
                                                    bcast_i(py, src), words, a.S->map.rows, a.S->map.cols, a.S->map.wpr);
                 if (lane == src) hit = h;
             }
-        } else if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
+        } else if (cls == kAmbiguous && !ABLATED(a, kAblateNoPark)) {
             const int shard = (int)(blockIdx.x % kShards);
             const int slot = atomicAdd(a.pending_count + shard, 1);
             q.c = c;
@@ -1210,7 +1220,7 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
             q.env_hi = (int32_t)(i >> 32);
             a.S->pending[(int64_t)slot * kShards + shard] = q;  // interleaved: the used slots stay in a few pages
         }
-    } else if (!(a.flags & kAblateNoReward)) {
+    } else if (!ABLATED(a, kAblateNoReward)) {
         // (3b) scorer: ContinuousRewardProvider.reward for the pose as it stands if nothing collides
         const double x = hand_pose[lane], y = hand_pose[kBlock + lane], th = hand_pose[2 * kBlock + lane];
         const int64_t g = slot_of(a.S, i, q);
@@ -1242,7 +1252,7 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
         sc.rew = hand_score[lane];
         sc.min_dist = hand_score[kBlock + lane];
         sc.target = (int)hand_score[2 * kBlock + lane];
-        finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, !(a.flags & kAblateNoReward), sc);
+        finalize_env<PLAIN>(a, i, q, hit, lds_path, nullptr, !ABLATED(a, kAblateNoReward), sc);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) a.tick[1] = a.step_counter;   // for kernel 2 (see StepArgs::tick)
     advance_step_by_ticket(a);   // (only when no kernel 2 follows)
@@ -1290,7 +1300,7 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
             const int64_t g = a.hot.geom_of_env ? (int64_t)e->geom : i;
             const uint32_t* words = a.hot.map_bits + (a.hot.map_shared ? 0 : g * a.hot.map_env_stride);
             bool hit = false;
-            if (!(a.flags & kAblateNoCoop))
+            if (!ABLATED(a, kAblateNoCoop))
                 hit = coop_collides<WIDE>(P, vqx, vqy, e->c, e->s, e->px, e->py, words, a.hot.map_rows, a.hot.map_cols,
                                           a.hot.map_wpr);
             if (hit && lane == 0) {
@@ -1313,7 +1323,7 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
         //  round trip per pose and almost never spare the rasteriser)
         bool hit = false;
         DIAG_STAMP(2);
-        if (!(a.flags & kAblateNoCoop))
+        if (!ABLATED(a, kAblateNoCoop))
             hit = coop_collides_quad<WIDE>(P, vqx, vqy, c, s, px, py, words, a.hot.map_rows, a.hot.map_cols, a.hot.map_wpr, wave,
                                            (LdsU32)lds_dyn);
         DIAG_STAMP(3);
@@ -1351,9 +1361,14 @@ __global__ void __launch_bounds__(kBlock * kPendingWaves) step_pending_kernel(co
 //     classification, on a warm CU.
 // No queue, no atomic in global memory, no poll, no second launch; load balance comes from the workgroup being large
 // (the sum of 256 envs' luck) and from the helper waves.
-constexpr int kLocalPairs = 4;
-constexpr int kLocalWaves = 16;
-constexpr int kLocalEnvs = kLocalPairs * kBlock;
+// The workgroup comes in three sizes (template parameter PAIRS, BCP_TUNE_LOCAL_PAIRS): 4 pairs = 16 waves = 256 envs (one
+// workgroup per CU: rounds 2-3), 2 pairs = 8 waves = 128 envs (two co-resident per CU) and 1 pair = 4 waves = 64 envs (four).
+// Every form has the same four waves per 64 envs and the same four waves per SIMD when the chip is full; what changes is the
+// granule in which the CU's registers are handed out: a 16-wave workgroup shares a CU with NOTHING (112 VGPRs x 1024 threads),
+// so one workgroup more than the chip holds, a sampler or an RCCL kernel resident on some CUs, costs a whole further round
+// (profiles/r03_n_sweep.txt: 65 536 envs 11.8 us, 65 792 envs 17.8 us); an 8-wave one can start beside a leaving neighbour.
+constexpr int kLocalPairsMax = 4;
+constexpr int kLocalPairsDefault = 4;   // (bcplan.hip: local_pairs)
 
 typedef const __attribute__((address_space(4))) StepArgs& KernArgs;   // the launch arguments where they lie: scalar loads on
                                                                       // demand instead of ~500 bytes pinned in SGPRs
@@ -1365,8 +1380,9 @@ constexpr int kLocalMapWords = 4096;   // a shared lethal bitmap of up to 16 KB 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kStaticChunks = (int)((sizeof(StepStatic) + 15) / 16);   // *S in 16-byte pieces
 
-static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles, int staged_map_words, bool plain = true)
+static size_t local_step_lds_bytes(int n_verts, int lds_path_doubles, int staged_map_words, bool plain = true, int pairs = kLocalPairsMax)
 {
+    const int kLocalPairs = pairs, kLocalWaves = 4 * pairs, kLocalEnvs = pairs * kBlock;
     size_t bytes = ((size_t)2 * n_verts + lds_path_doubles + (size_t)kLocalPairs * kHandDoubles * kBlock + 8) * sizeof(double);
     bytes += 2 * kBlock * sizeof(uint32_t);          // bucket index of the shared path
     bytes += 16 * sizeof(int32_t);                   // parked count, ticket counter, movers parked, -, scans done per pair [4], scan lists ready per pair [4], - [4]
@@ -1423,7 +1439,7 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 
-static_assert(kStaticChunks <= 128, "*S is staged by the last two waves");
+static_assert(kStaticChunks <= 128, "*S is staged by the last two waves of a workgroup");
 // A spin on an LDS word another wave of the workgroup will set (`cond` true = keep waiting, wave-uniform).  Bounded: a wait
 // that the hand-off protocol guarantees to end within ~20 k cycles gives up after kPollLimit trips (~10^7 cycles) and sets
 // `expired`; the wave carries on with what it has and reports BCP_ERR_INTERNAL at the end.  (hipcc 7.2 has turned two
@@ -1432,9 +1448,16 @@ constexpr int kPollLimit = 1 << 16;
 #define BOUNDED_POLL(cond, expired) do { int trips_ = 0; while (cond) { __builtin_amdgcn_s_sleep(1); if (++trips_ > kPollLimit) { (expired) = true; break; } } } while (0)
 constexpr uint32_t kDiagWithholdVerdicts = 1u << 23;   // -DBCP_DIAG builds: parked poses are tested but their verdicts never posted
 
-template <bool WIDE, bool PLAIN>
-__global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const StepArgs launch_args)
+template <bool WIDE, bool PLAIN, int PAIRS>
+__global__ void __attribute__((amdgpu_flat_work_group_size(4 * PAIRS * kBlock, 4 * PAIRS * kBlock), amdgpu_waves_per_eu(4)))
+step_local_kernel(const StepArgs launch_args)
 {
+    static_assert(PAIRS == 1 || PAIRS == 2 || PAIRS == 4, "a workgroup holds 1, 2 or 4 (mover, scorer, helper, helper) quartets");
+    constexpr int kLocalPairs = PAIRS, kLocalWaves = 4 * PAIRS, kLocalEnvs = PAIRS * kBlock;
+    constexpr int kPairShift = PAIRS == 4 ? 2 : (PAIRS == 2 ? 1 : 0);
+    constexpr int kStaticFrom = (kLocalWaves - 2) * kBlock;   // *S is staged by the last two waves
+    constexpr int kCtlFrom = (kLocalWaves - 1) * kBlock;      // the control words are zeroed by the last wave
+    [[maybe_unused]] constexpr int kWScorer = PAIRS, kWHelper1 = 2 * PAIRS, kWHelper2 = 3 * PAIRS;   // pair 0's waves (stamps)
     KernArgs a = *(const __attribute__((address_space(4))) StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     DIAG_STAMP_WAVES(512);    // every wave: first instruction
     // (static issue priorities by role, s_setprio -- the movers above everybody else, or everybody else above the movers
@@ -1478,7 +1501,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     // candidate of the window each; contiguous thirds for paths in global memory); the mover takes the maximum and does
     // the rest of the provider itself.
     const bool scanner = PLAIN ? !mover : scorer;
-    const int member = (wave >> 2) - 1;   // 0 = scorer, 1 / 2 = helpers (PLAIN only)
+    const int member = (wave >> kPairShift) - 1;   // 0 = scorer, 1 / 2 = helpers (PLAIN only)
 
     // ---- LDS
     __attribute__((address_space(3))) double* qv = (__attribute__((address_space(3))) double*)lds_dyn;
@@ -1583,9 +1606,9 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
     //     loads per thread kept the SIMDs busy for 1 - 2 k cycles before the movers' own loads were even issued.
     //     (issued FIRST by those two waves it was measured slower, 11.75 against 11.70 us: it then competes with the movers' loads)
     u32x4 st_static = {0u, 0u, 0u, 0u};
-    if (tid >= 896 && tid < 896 + kStaticChunks) st_static = as_global(reinterpret_cast<const u32x4*>(a.S))[tid - 896];
+    if (tid >= kStaticFrom && tid < kStaticFrom + kStaticChunks) st_static = as_global(reinterpret_cast<const u32x4*>(a.S))[tid - kStaticFrom];
     DIAG_STAMP_U(0, 10);   // mover: own + staging loads issued
-    DIAG_STAMP_U(4, 11);   // scorer: the same
+    DIAG_STAMP_U(kWScorer, 11);   // scorer: the same
     DIAG_STAMP_WAVES(1280);   // every wave: prologue loads issued
     __builtin_amdgcn_sched_barrier(0);
     const uint64_t step_counter = mover ? 0 : uniform_u64(tick_counter), seed = mover ? 0 : uniform_u64(tick_seed);
@@ -1605,7 +1628,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         device_normals_12(seed, (uint64_t)(L.hot.env_id_base + i), step_counter, z1, z2);
         hand_score[kBlock + lane] = z1;
         hand_score[2 * kBlock + lane] = z2;
-        DIAG_STAMP_U(4, 1);   // scorer: noise drawn
+        DIAG_STAMP_U(kWScorer, 1);   // scorer: noise drawn
     }
     if (noise_by_waves && member == 2) hand_score[lane] = L.hot.noise_slot0 ? device_normal_0(seed, (uint64_t)(L.hot.env_id_base + i), step_counter) : 0.0;
     //     (the first helper's cos / sin of the OLD heading is needed behind barrier 1 only: it follows barrier 0)
@@ -1646,10 +1669,19 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         }
     }
     // (6) the parameter block into LDS
-    if (tid >= 960 && tid < 976) ctl[tid - 960] = 0;
-    if (tid >= 896 && tid < 896 + kStaticChunks) lds_static[tid - 896] = st_static;
+    if (tid >= kCtlFrom && tid < kCtlFrom + 16) ctl[tid - kCtlFrom] = 0;
+    if (tid >= kStaticFrom && tid < kStaticFrom + kStaticChunks) lds_static[tid - kStaticFrom] = st_static;
     DIAG_STAMP_WAVES(1024);
     __syncthreads();   // barrier 0: noise, old heading and the parameter block are in LDS
+    // The step counter moves on when every workgroup of the launch has READ it -- not when every workgroup is done: this
+    // workgroup's waves have all used their copy by now, so its ticket is drawn here, by a wave with time to spare, and only
+    // looked at in the wave's last instructions.  (Rounds 2-3 drew at the very end: 256 workgroups finishing together queue
+    // their returning atomics on one address at the memory side, ~10 ns each, behind the step's critical path -- a second
+    // atomic on that line per workgroup cost the metric step 2.5 us, tools/step_time.py with both builds, round 4.)
+    unsigned int ticket_drawn = 0u;
+    const bool draws = (L.flags & kStepAdvances) && tid == (kLocalWaves - 1) * kBlock;
+    if (draws)
+        ticket_drawn = __hip_atomic_fetch_add((GlobalPtr<unsigned int>)(L.tick + kTickLocalTicket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const DevParams& P = *(const DevParams*)&SL->P;
     const int map_rows = hot_map_rows, map_cols = hot_map_cols;
     const int my_len = hot_path_shared ? hot_max_len : (int)own_len;   // way points of this env's path
@@ -1680,12 +1712,14 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         cos_sin(old_angle, c0, s0);
         hand_heading[lane] = c0;
         hand_heading[kBlock + lane] = s0;
-        DIAG_STAMP_U(8, 2);   // helper: cos / sin of the old heading
+        DIAG_STAMP_U(kWHelper1, 2);   // helper: cos / sin of the old heading
     }
     // (7b) everybody else stages what is read behind barrier 1: loads first, all of them in flight together, then the stores
     if (!mover) {
-        constexpr int kStagers = (kLocalWaves - kLocalPairs) * kBlock;            // 768 threads
-        constexpr int kMapPerStager = (kLocalMapWords + kStagers - 1) / kStagers;   // 6 words each
+        constexpr int kStagers = (kLocalWaves - kLocalPairs) * kBlock;            // 768 / 384 / 192 threads
+        constexpr int kMapPerStager = (kLocalMapWords + kStagers - 1) / kStagers;   // 6 / 11 / 22 words each
+        constexpr int kBoxAt = kStagers >= 448 ? 256 : kStagers - 8;              // who fetches the path's box (8 doubles) ...
+        constexpr int kIndexAt = kStagers >= 448 ? 320 : kStagers - 136;          // ... and its bucket index (128 words)
         const int nm = tid - kLocalPairs * kBlock;
         double st_q = 0.0, st_path = 0.0, st_box = 0.0;
         uint32_t st_index = 0;
@@ -1693,8 +1727,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         if (nm < nq) st_q = as_global(L.hot.qverts)[nm];
         if (nm < npath) st_path = as_global(L.hot.path_pts)[nm];
         if (hot_path_shared) {
-            if (nm >= 256 && nm < 264) st_box = as_global(L.hot.path_bbox)[nm - 256];
-            if (nm >= 320 && nm < 320 + 128) st_index = as_global(reinterpret_cast<const uint32_t*>(L.hot.path_index))[nm - 320];
+            if (nm >= kBoxAt && nm < kBoxAt + 8) st_box = as_global(L.hot.path_bbox)[nm - kBoxAt];
+            if (nm >= kIndexAt && nm < kIndexAt + 128) st_index = as_global(reinterpret_cast<const uint32_t*>(L.hot.path_index))[nm - kIndexAt];
         }
 #pragma unroll
         for (int u = 0; u < kMapPerStager; ++u) {
@@ -1705,8 +1739,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         if (nm < npath) qv[nq + nm] = st_path;
         for (int k = kStagers + nm; k < npath; k += kStagers) qv[nq + k] = as_global(L.hot.path_pts)[k];   // (long paths)
         if (hot_path_shared) {
-            if (nm >= 256 && nm < 264) lds_box[nm - 256] = st_box;
-            if (nm >= 320 && nm < 320 + 128) lds_index[nm - 320] = st_index;
+            if (nm >= kBoxAt && nm < kBoxAt + 8) lds_box[nm - kBoxAt] = st_box;
+            if (nm >= kIndexAt && nm < kIndexAt + 128) lds_index[nm - kIndexAt] = st_index;
         }
 #pragma unroll
         for (int u = 0; u < kMapPerStager; ++u) {
@@ -1743,7 +1777,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         const int64_t map_env = a.hot.map_shared ? 0 : g;
         int cls = kFree;
 #ifdef BCP_DIAG
-        if (!(a.flags & (kAblateNoCollision | kAblateNoClassify)))
+        if (!ABLATED(a, kAblateNoCollision | kAblateNoClassify))
 #endif
         {
             // (a shared field is 18 KB for the 183 x 183 map and stays in the CU's L1: a copy in LDS measured no faster)
@@ -1756,7 +1790,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         }
         if (!active) cls = kFree;
         DIAG_STAMP_U(0, 5);    // mover: classified
-        if (cls == kAmbiguous && !(a.flags & kAblateNoPark)) {
+        if (cls == kAmbiguous && !ABLATED(a, kAblateNoPark)) {
             park = true;
             q.c = c;
             q.s = s;
@@ -1765,7 +1799,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             q.env_lo = (int32_t)(uint32_t)i;
             q.env_hi = (int32_t)(i >> 32);
         }
-    } else if (scanner && !(a.flags & kAblateNoReward)) {
+    } else if (scanner && !ABLATED(a, kAblateNoReward)) {
         // (3b) the reward provider for the pose as it stands if nothing collides
         const double x = hand_pose[lane], y = hand_pose[kBlock + lane], th = hand_pose[2 * kBlock + lane];
         const int64_t g = slot_of(SL, i, q);
@@ -1786,7 +1820,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             int total;
             if (member == 0) {
                 const PathWindow win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
-                DIAG_STAMP_U(4, 6);    // scorer: candidate window known
+                DIAG_STAMP_U(kWScorer, 6);    // scorer: candidate window known
                 const int lo = max(win.lo, q.target), hi = min(win.hi, m - 1);
                 const int cnt = max(hi - lo + 1, 0);
                 // inclusive prefix sum over the wave: four DPP row shifts inside every 16-lane row (lanes shifted in from
@@ -1837,16 +1871,16 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
                 const int last = last_reached_from(P, lds_path, part, m, q.target, x, y, th, 3);
                 if (last >= 0) __hip_atomic_fetch_max(&res[lane], last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            DIAG_STAMP_U(4, 14);    // scorer of pair 0: scanned
-            DIAG_STAMP_U(8, 7);     // helper 1 of pair 0: scanned
-            DIAG_STAMP_U(12, 8);    // helper 2 of pair 0: scanned
+            DIAG_STAMP_U(kWScorer, 14);    // scorer of pair 0: scanned
+            DIAG_STAMP_U(kWHelper1, 7);     // helper 1 of pair 0: scanned
+            DIAG_STAMP_U(kWHelper2, 8);    // helper 2 of pair 0: scanned
         } else {
         PathWindow win;
         if (SL->path.shared)
             win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
         else
             win = path_window(P, box, SL->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
-        DIAG_STAMP_U(4, 6);    // scorer: candidate window known
+        DIAG_STAMP_U(kWScorer, 6);    // scorer: candidate window known
         if (PLAIN) {
             // way points in memory: this member's share of the candidate window [max(lo, target), min(hi, m - 1)] is a
             // contiguous third, counted from the top (four neighbours per round trip)
@@ -1867,8 +1901,8 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
                 }
             }
             ((__attribute__((address_space(3))) int32_t*)hand_score)[member * kBlock + lane] = last;
-            DIAG_STAMP_U(8, 7);     // helper 1 of pair 0: scanned
-            DIAG_STAMP_U(12, 8);    // helper 2 of pair 0: scanned
+            DIAG_STAMP_U(kWHelper1, 7);     // helper 1 of pair 0: scanned
+            DIAG_STAMP_U(kWHelper2, 8);    // helper 2 of pair 0: scanned
             DIAG_MAX(9, max(hi - lo + 1, 0));   // longest candidate window among the lanes 0 of the workgroup's waves
         } else {
             double min_dist = q.min_dist;
@@ -1916,7 +1950,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         }
     }
     DIAG_STAMP(4);        // mover: classified and parked
-    DIAG_STAMP_W(4, 8);   // scorer of pair 0: scanned
+    DIAG_STAMP_W(kWScorer, 8);   // scorer of pair 0: scanned
     // "Barrier 2" is two counters in LDS instead of an s_barrier: a mover only needs the scan results of ITS pair, and the
     // other waves only need every mover's poses parked -- the waves that finish their scan first start on the parked
     // poses while the slowest scan of the workgroup is still running (release adds / acquire polls, workgroup scope).
@@ -1927,7 +1961,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         // memory by one lane at the very end of the step, with the rest of the workgroup idle (C4: the workgroups that
         // end last all hold such an env).  The mover has nothing to do until its pair's scans are in, so it works that
         // reward out now for every pose it parked; the verdict then only picks between two finished results.
-        if (PLAIN && !lds_path && !hot_path_shared && a.hot.path_pre && park && !(a.flags & kAblateNoReward)) {
+        if (PLAIN && !lds_path && !hot_path_shared && a.hot.path_pre && park && !ABLATED(a, kAblateNoReward)) {
             const int64_t g = slot_of(SL, i, q);
             const GlobalPtr<const double> bx = as_global(L.hot.path_bbox) + g * kBoxDoubles;
             double obox[8];
@@ -1988,10 +2022,10 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
 #pragma unroll
                 for (int k = 0; k < 7; ++k) q.popped_state[k] = fifo_stash[(3 + k) * kLocalEnvs];
             }
-            finalize_env_from<PLAIN>(a, SL, i, q, hit, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len);
+            finalize_env_from<PLAIN>(a, SL, i, q, hit, lds_path, nullptr, !ABLATED(a, kAblateNoReward), sc, my_len);
         }
     }
-    DIAG_STAMP_W(8, 9);   // helper: past the second barrier
+    DIAG_STAMP_W(kWHelper1, 9);   // helper: past the second barrier
     const double vqx = lane < P.n_verts ? qv[2 * lane] : 0.0, vqy = lane < P.n_verts ? qv[2 * lane + 1] : 0.0;   // (row-by-row fallback)
     // (6) every wave settles parked poses, a ticket at a time: exact test, verdict into the record.
     // (Control flow: a scalar loop condition and NO single-lane region around the draw.  With two `if (lane == 0)` regions
@@ -2010,7 +2044,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         lane == 0 ? (__attribute__((address_space(3))) int*)&ctl[1] : (__attribute__((address_space(3))) int*)(cell_list + lane);
     int ticket = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(ticket_word, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     while (ticket < n_parked) {
-        DIAG_STAMP_W(8, 10);   // helper: has a ticket
+        DIAG_STAMP_W(kWHelper1, 10);   // helper: has a ticket
         __attribute__((address_space(3))) ParkedPose* e = rec + ticket;
         const double c = e->c, s = e->s;
         const int px = e->px, py = e->py;
@@ -2020,7 +2054,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         bool h = false;
         [[maybe_unused]] const unsigned long long test_from = DIAG_NOW();
         [[maybe_unused]] int how = 0;
-        if (!(a.flags & kAblateNoCoop)) {
+        if (!ABLATED(a, kAblateNoCoop)) {
             // the lethal cells under the image tested one by one; a map too dense for that is rasterised row by row
 #ifdef BCP_DIAG
             unsigned long long phase[3] = {test_from, test_from, 0};
@@ -2035,7 +2069,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
                                              a.hot.map_wpr, cell_list, phases);
 #ifdef BCP_DIAG
             // wave 8's test: cycles for the edge set-up, for listing the cells, for the rest, and the list's length
-            if (threadIdx.x == 8 * 64 && blockIdx.x < 2048) {
+            if (threadIdx.x == kWHelper1 * 64 && blockIdx.x < 2048) {
                 const unsigned long long now = DIAG_NOW();
                 g_diag[(2048 + blockIdx.x) * 16 + 13] = ((phase[0] - test_from) << 40) | ((phase[1] - phase[0]) << 20) | (now - phase[1]);
                 g_diag[(2048 + blockIdx.x) * 16 + 15] = phase[2];
@@ -2047,14 +2081,14 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
             how = verdict;
         }
         DIAG_MAX(0, ((DIAG_NOW() - test_from) << 4) | (unsigned)how);   // the longest exact test of the workgroup, and its kind
-        DIAG_STAMP_W(8, 11);   // helper: verdict
+        DIAG_STAMP_W(kWHelper1, 11);   // helper: verdict
         bool post = lane == 0;
 #ifdef BCP_DIAG
         post = post && !(a.flags & kDiagWithholdVerdicts);
 #endif
         if (post) __hip_atomic_store(&e->verdict, h ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         ticket = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(ticket_word, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        DIAG_STAMP_W(8, 12);   // helper: verdict posted
+        DIAG_STAMP_W(kWHelper1, 12);   // helper: verdict posted
     }
     // (7) movers: the envs they parked are finished by the lane that holds their state, as soon as the verdicts are in
     //     (every parked pose has been claimed by now -- by this wave or by one that is working on it)
@@ -2079,7 +2113,7 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
         // reached way point by the whole wave, a candidate per lane (one lane walking the window alone took ~5 k cycles, and
         // the step ends with the workgroups that hold such an env).  Shared path in LDS, continuous provider without delays;
         // otherwise finalize_env_from computes it itself.
-        const bool hit_score = PLAIN && lds_path && a.hot.path_shared && !(a.flags & kAblateNoReward);
+        const bool hit_score = PLAIN && lds_path && a.hot.path_shared && !ABLATED(a, kAblateNoReward);
         int last_hit = -1;
         if (hit_score) {
             uint64_t hits = __ballot(park && verdict == 2);
@@ -2111,20 +2145,19 @@ __global__ void __launch_bounds__(kLocalWaves * kBlock) step_local_kernel(const 
 #pragma unroll
                 for (int k = 0; k < 7; ++k) q.popped_state[k] = fifo_stash[(3 + k) * kLocalEnvs];
             }
-            finalize_env_from<PLAIN>(a, SL, i, q, verdict == 2, lds_path, nullptr, !(a.flags & kAblateNoReward), sc, my_len, fits);
+            finalize_env_from<PLAIN>(a, SL, i, q, verdict == 2, lds_path, nullptr, !ABLATED(a, kAblateNoReward), sc, my_len, fits);
         }
     }
     DIAG_STAMP(13);            // mover: out of tickets
-    DIAG_STAMP_W(8, 14);       // helper: out of tickets
+    DIAG_STAMP_W(kWHelper1, 14);       // helper: out of tickets
 #ifdef BCP_DIAG
     if (tid == 0 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 16 + 15] = (unsigned long long)n_parked;
 #endif
     if (poll_expired && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 4), 1ull);   // (bcp_expired_waits)
-    if ((a.flags & kStepAdvances) && tid == (kLocalWaves - 1) * kBlock) {   // the last workgroup to get here moves the step counter on
-        if (n_parked) atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 5), (unsigned long long)n_parked);   // (bcp_parked_poses; no return value: not waited for)
-        unsigned int* ticket = reinterpret_cast<unsigned int*>(a.tick + 3);
-        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
-            *ticket = 0u;
+    if (draws) {
+        if (n_parked) a.parked_slots[blockIdx.x] += (uint64_t)n_parked;   // (this workgroup's word: no atomic; bcp_parked_poses adds them up)
+        if (ticket_drawn == gridDim.x - 1) {   // every workgroup of this launch has read the counter: it moves on
+            *reinterpret_cast<unsigned int*>(a.tick + kTickLocalTicket) = 0u;
             a.tick[0] = step_counter + 1;
         }
     }

@@ -130,6 +130,9 @@ struct bcp_handle {
     int32_t edt_in_lds;       // distance transform of maps that fit: the LDS-resident kernel (BCP_TUNE_EDT_LDS)
     int32_t last_step_form;   // 0 none yet, 1 single-kernel step, 2 two-kernel step (parking counters in use)
     int32_t fused;            // settle parked poses inside the step launch (step_local_kernel) instead of a second launch
+    uint64_t* parked_slots;   // owned: a word per workgroup of step_local_kernel, its parked poses so far (bcp_parked_poses)
+    int64_t parked_cap;
+    int32_t local_pairs;      // BCP_TUNE_LOCAL_PAIRS: workgroup size of step_local_kernel (0 = default, 1, 2, 4 x 64 envs)
     // near_dilate_kernel: 1-bit tiles without the uint8 field (pool refresh under the single-launch step)
     int32_t near_dilate;      // BCP_TUNE_NEAR_DILATE: 0 never, 1 pool refreshes (default), 2 every build (after the field: tests)
     uint8_t* edt_stale;       // owned: [entries] 1 = the entry's uint8 field does not describe its map (tiles do)
@@ -1044,8 +1047,12 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->ego_sparse = 1;
     h->ego_cells_max = -1;
     h->static_dirty = true;
+    if (const char* e = getenv("BCP_LOCAL_PAIRS")) {   // (default of BCP_TUNE_LOCAL_PAIRS for every handle of the process)
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) h->local_pairs = v;
+    }
     fill_dev_params(h);
-    if (hipMalloc((void**)&h->tick, 8 * sizeof(uint64_t)) != hipSuccess || hipMemset(h->tick, 0, 8 * sizeof(uint64_t)) != hipSuccess) {
+    if (hipMalloc((void**)&h->tick, kTickWords * sizeof(uint64_t)) != hipSuccess || hipMemset(h->tick, 0, kTickWords * sizeof(uint64_t)) != hipSuccess) {
         if (h->tick) (void)hipFree(h->tick);
         delete h;
         return fail(BCP_E_HIP, "bcp_create: cannot allocate device memory");
@@ -1078,6 +1085,7 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->ego_cells) (void)hipFree(h->ego_cells);
     if (h->ego_cell_counts) (void)hipFree(h->ego_cell_counts);
+    if (h->parked_slots) (void)hipFree(h->parked_slots);
     if (h->refresh_done) (void)hipEventDestroy(h->refresh_done);
     if (h->waits_event) (void)hipEventDestroy(h->waits_event);
     if (h->waits_host) (void)hipHostFree(h->waits_host);
@@ -1096,6 +1104,7 @@ extern "C" int bcp_seed(bcp_handle* h, uint64_t seed)
     HIP_TRY(hipDeviceSynchronize());
     const uint64_t tick[4] = {0, 0, seed, 0};
     HIP_TRY(hipMemcpy(h->tick, tick, sizeof(tick), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->tick + kTickLocalTicket, 0, sizeof(uint64_t)));
     if (h->pending_count) HIP_TRY(hipMemset(h->pending_count, 0, 2 * kShards * sizeof(int32_t)));
     if (h->adapt) {
         HIP_TRY(hipMemset(h->adapt, 0, (2 + 2 * kShards) * sizeof(int32_t)));
@@ -1151,6 +1160,11 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
             return BCP_OK;
         case BCP_TUNE_FUSED:
             h->fused = value ? 1 : 0;
+            return BCP_OK;
+        case BCP_TUNE_LOCAL_PAIRS:
+            if (value != 0 && value != 1 && value != 2 && value != 4)
+                return fail(BCP_E_INVALID, "bcp_set_tuning: BCP_TUNE_LOCAL_PAIRS takes 0 (default), 1, 2 or 4");
+            h->local_pairs = value;
             return BCP_OK;
         case BCP_TUNE_CULL:
             h->cull_enabled = value ? 1 : 0;
@@ -1638,6 +1652,27 @@ static int rearm_parking(bcp_handle* h, hipStream_t s)
     return BCP_OK;
 }
 
+// step_local_kernel<WIDE, PLAIN, PAIRS>: variant = WIDE << 1 | PLAIN
+static const void* local_step_fn(int variant, int pairs)
+{
+#define BCP_LOCAL_FN(W, P) (pairs == 4 ? (const void*)step_local_kernel<W, P, 4> : pairs == 2 ? (const void*)step_local_kernel<W, P, 2> \
+                                                                                              : (const void*)step_local_kernel<W, P, 1>)
+    switch (variant) {
+        case 3: return BCP_LOCAL_FN(true, true);
+        case 2: return BCP_LOCAL_FN(true, false);
+        case 1: return BCP_LOCAL_FN(false, true);
+        default: return BCP_LOCAL_FN(false, false);
+    }
+#undef BCP_LOCAL_FN
+}
+
+// Size of step_local_kernel's workgroups for this handle: BCP_TUNE_LOCAL_PAIRS, or (0) the default of the configuration.
+static int local_pairs(const bcp_handle* h)
+{
+    if (h->local_pairs == 1 || h->local_pairs == 2 || h->local_pairs == 4) return h->local_pairs;
+    return kLocalPairsDefault;
+}
+
 static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hipStream_t s, bool first_only = false)
 {
     if (h->static_dirty) {
@@ -1708,6 +1743,7 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     a.threshold_next = a.inplace_count = a.inplace_next = nullptr;
     const bool adapt = h->adaptive && h->adapt && S.pending && S.dense_threshold >= 0;
     a.tick = h->tick;
+    a.parked_slots = nullptr;
     a.pending_base = h->pending_count;
     a.adapt_base = adapt ? h->adapt : nullptr;
     const int blocks = (int)((h->n + kBlock - 1) / kBlock);
@@ -1715,21 +1751,20 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
         // the whole step as one launch: 256 envs per workgroup of 16 waves; undecided poses are handed over in LDS and
         // settled by all the workgroup's waves (step_local_kernel)
         const int variant = (S.wide ? 2 : 0) | (step_is_plain(h) ? 1 : 0);
-        const void* fn = variant == 3 ? (const void*)step_local_kernel<true, true>
-                       : variant == 2 ? (const void*)step_local_kernel<true, false>
-                       : variant == 1 ? (const void*)step_local_kernel<false, true>
-                                      : (const void*)step_local_kernel<false, false>;
+        const int pairs = local_pairs(h);
+        const int pslot = pairs == 4 ? 2 : (pairs == 2 ? 1 : 0);
+        const void* fn = local_step_fn(variant, pairs);
         const int64_t bitmap_words = (int64_t)S.map.rows * S.map.wpr;
         const size_t lds = local_step_lds_bytes(h->params.n_verts, S.lds_path_doubles,
                                                 (S.map.shared && bitmap_words <= kLocalMapWords) ? (int)bitmap_words : 0,
-                                                step_is_plain(h));
+                                                step_is_plain(h), pairs);
         // The attribute belongs to the FUNCTION on a device, not to a handle: the largest size any handle of this process
         // has asked for stays set (two live handles with different staging sizes would otherwise lower it under each other).
         {
             static std::mutex lds_mutex;
-            static int32_t lds_max[64][4];   // [device][variant], zero-initialised
+            static int32_t lds_max[64][4][3];   // [device][variant][workgroup size], zero-initialised
             std::lock_guard<std::mutex> lock(lds_mutex);
-            int32_t& cur = lds_max[h->device & 63][variant];
+            int32_t& cur = lds_max[h->device & 63][variant][pslot];
             if ((int32_t)lds > cur) {
                 HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 cur = (int32_t)lds;
@@ -1740,13 +1775,16 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
         hot.io_actions = a.actions;
         hot.io_noise_z = a.noise_z;
         hot.io_tick = a.tick;
-        const dim3 grid((unsigned)((h->n + kLocalEnvs - 1) / kLocalEnvs)), block(kLocalWaves * kBlock);
-        switch (variant) {
-            case 3: hipLaunchKernelGGL((step_local_kernel<true, true>), grid, block, lds, s, a); break;
-            case 2: hipLaunchKernelGGL((step_local_kernel<true, false>), grid, block, lds, s, a); break;
-            case 1: hipLaunchKernelGGL((step_local_kernel<false, true>), grid, block, lds, s, a); break;
-            default: hipLaunchKernelGGL((step_local_kernel<false, false>), grid, block, lds, s, a); break;
+        const int envs_per_group = pairs * kBlock;
+        const dim3 grid((unsigned)((h->n + envs_per_group - 1) / envs_per_group)), block(4 * pairs * kBlock);
+        if (!h->parked_slots) {   // (sized for the smallest workgroup: the size may change between steps)
+            h->parked_cap = (h->n + kBlock - 1) / kBlock;
+            HIP_TRY(hipMalloc((void**)&h->parked_slots, (size_t)h->parked_cap * sizeof(uint64_t)));
+            HIP_TRY(hipMemsetAsync(h->parked_slots, 0, (size_t)h->parked_cap * sizeof(uint64_t), s));
         }
+        a.parked_slots = h->parked_slots;
+        void* kargs[] = {(void*)&a};
+        HIP_TRY(hipLaunchKernel(fn, grid, block, kargs, lds, s));
     } else if (S.pending) {
         // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest
         const size_t lds1 = ((size_t)h->params.n_verts * 2 + S.lds_path_doubles) * sizeof(double);
@@ -1911,10 +1949,14 @@ extern "C" int bcp_parked_poses(bcp_handle* h, int64_t* count, void* stream)
 {
     if (!h || !count) return fail(BCP_E_INVALID, "bcp_parked_poses: null argument");
     HIP_TRY(hipSetDevice(h->device));
-    uint64_t v = 0;
-    HIP_TRY(hipMemcpyAsync(&v, h->tick + 5, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    *count = 0;
+    if (!h->parked_slots) return BCP_OK;
+    std::vector<uint64_t> slots((size_t)h->parked_cap);
+    HIP_TRY(hipMemcpyAsync(slots.data(), h->parked_slots, slots.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    *count = (int64_t)v;
+    uint64_t sum = 0;
+    for (uint64_t v : slots) sum += v;
+    *count = (int64_t)sum;
     return BCP_OK;
 }
 
@@ -2300,7 +2342,8 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
     // non-zero border) keep the sampling kernels below.
     const bool fits_lds = map_bytes + 4 * row_bytes <= 150 * 1024;
     h->ego_route[0] = h->ego_route[1] = h->ego_route[2] = h->ego_route[3] = 0;
-    if (border_value == 0 && a.rows <= 4095 && a.cols <= 4095 && !h->ego_cells_refused && h->ego_sparse) {
+    if (border_value == 0 && a.rows <= 4095 && a.cols <= 4095 && !h->ego_cells_refused && h->ego_sparse &&
+        ego_sparse_lds_bytes(a.drows, a.dcols, kEgoWaves) <= 64 * 1024) {
         const int64_t entries = a.shared ? 1 : n_slots(h);
         const int32_t limit = ego_sparse_limit(h->ego_sparse, (int64_t)a.drows * a.dcols, fits_lds);
         if (h->refresh_recorded && (!h->ego_cells_built || h->ego_cells_max < 0))
@@ -2366,7 +2409,8 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
             // 48 instead of 83 registers (3 - 8 % slower), fewer workgroups per CU by way of unused LDS (within the noise).)
             const dim3 wide(64 * kEgoWaves);
             const dim3 grid((unsigned)((n + kEgoWaves - 1) / kEgoWaves));
-            hipLaunchKernelGGL(ego_sparse_kernel, grid, wide, 0, st, a, h->ego_cells, h->ego_cell_counts, h->ego_cell_cap);
+            const size_t lds = ego_sparse_lds_bytes(a.drows, a.dcols, kEgoWaves);   // (<= 64 KB: checked above)
+            hipLaunchKernelGGL(ego_sparse_kernel, grid, wide, lds, st, a, h->ego_cells, h->ego_cell_counts, h->ego_cell_cap);
             HIP_TRY(hipGetLastError());
             h->ego_route[0] = BCP_EGO_SPARSE;
             return BCP_OK;

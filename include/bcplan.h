@@ -181,9 +181,14 @@ int bcp_seed(bcp_handle *h, uint64_t seed);
  *                             single-launch step dilates the lethal mask by the sample disc instead and leaves the uint8
  *                             fields of those entries to be computed when something asks for them (the other step forms,
  *                             bcp_pose_collides, bcp_get_distance_field); 2 = bcp_set_costmaps also overwrites its
- *                             thresholded tiles with dilated ones (tests: the two must agree bit for bit) */
+ *                             thresholded tiles with dilated ones (tests: the two must agree bit for bit)
+ *   BCP_TUNE_LOCAL_PAIRS      workgroup size of the single-launch step: 4 = 16 wavefronts / 256 envs (one workgroup per CU),
+ *                             2 = 8 wavefronts / 128 envs (two per CU), 1 = 4 wavefronts / 64 envs (four per CU); 0 (default)
+ *                             = the library's choice for the configuration.  Same results bit for bit in every size.
+ *                             (The environment variable BCP_LOCAL_PAIRS = 1 | 2 | 4, read by bcp_create, sets this knob's
+ *                             initial value for every handle of the process: the whole test suite runs under each size.) */
 enum { BCP_TUNE_EXACT_MODE = 0, BCP_TUNE_DENSE_THRESHOLD = 1, BCP_TUNE_CULL = 2, BCP_TUNE_DEFER = 3, BCP_TUNE_EDT_LDS = 4,
-       BCP_TUNE_FUSED = 5, BCP_TUNE_EGO_SPARSE = 6, BCP_TUNE_NEAR_DILATE = 7 };
+       BCP_TUNE_FUSED = 5, BCP_TUNE_EGO_SPARSE = 6, BCP_TUNE_NEAR_DILATE = 7, BCP_TUNE_LOCAL_PAIRS = 8 };
 int bcp_set_tuning(bcp_handle *h, int32_t key, int32_t value);
 
 /* ---- static per-episode inputs ------------------------------------------------------------------------ */

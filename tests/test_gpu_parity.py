@@ -277,7 +277,7 @@ def _random_batch(oracle, rng, n, g, name):
 
 STEP_MODES = [dict(), dict(fused=0), dict(defer=0), dict(exact_mode=1), dict(exact_mode=2), dict(exact_mode=3), dict(cull=0, exact_mode=1),
               dict(cull=0, exact_mode=2), dict(defer=0, dense_threshold=0), dict(dense_threshold=0),
-              dict(dense_threshold=64)]
+              dict(dense_threshold=64), dict(local_pairs=2), dict(local_pairs=1)]
 
 
 @pytest.mark.parametrize("fixture,mode", [("g8_traj_mini_00.npz", m) for m in STEP_MODES] +

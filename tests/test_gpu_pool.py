@@ -10,7 +10,7 @@ from util import ATOL, GOLDEN, z_in
 pytestmark = pytest.mark.gpu
 
 MODES = [dict(), dict(defer=0), dict(cull=0, exact_mode=1), dict(cull=0, exact_mode=2), dict(dense_threshold=0),
-         dict(dense_threshold=64)]
+         dict(dense_threshold=64), dict(local_pairs=2), dict(local_pairs=1)]
 
 
 def _ids(m):

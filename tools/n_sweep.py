@@ -4,13 +4,17 @@ the latency of a single workgroup?  HIP-event timing of 4 x 100 back-to-back ste
 python tools/n_sweep.py [lib] > gpurun_out/n_sweep.txt"""
 import os, sys
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
 from bc_gym_planning_env_amd import _lib
-if len(sys.argv) > 1 and sys.argv[1] not in ('', '-'):
-    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+from _variant import use_lib
+use_lib(sys.argv[1] if len(sys.argv) > 1 else '')
 import numpy as np, torch
 import bench
+pairs = os.environ.get("BCP_PAIRS")
 for n in (16384, 32768, 65536, 65536 + 256, 98304, 131072, 196608, 262144, 524288, 1048576):
     env, g = bench.make_env(n, 0, 0, 2024)
+    if pairs is not None:
+        env.set_tuning(local_pairs=int(pairs))
     rng = np.random.RandomState(1234)
     pool = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(4)])).cuda()
     bench.steady_state(env, pool, rng)

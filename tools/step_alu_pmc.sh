@@ -7,6 +7,8 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 TAG=""; RUN=tools/pmc_run.py
 if [ "$1" = "c4" ]; then TAG="_c4"; RUN=tools/pmc_run_c4.py; fi
+# BCP_LOCAL_PAIRS=1|2|4 in the environment: the same counters for another workgroup size of step_local_kernel (bcp_create reads it)
+if [ -n "$BCP_LOCAL_PAIRS" ]; then TAG="${TAG}_p${BCP_LOCAL_PAIRS}"; fi
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \

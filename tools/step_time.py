@@ -2,9 +2,10 @@
 python tools/step_time.py [path/to/libbcplan_variant.so] [n_envs] -- HIP-event timing of 5 x 200 back-to-back steps."""
 import os, sys
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
 from bc_gym_planning_env_amd import _lib
-if len(sys.argv) > 1 and sys.argv[1] not in ('', '-'):
-    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+from _variant import use_lib
+use_lib(sys.argv[1] if len(sys.argv) > 1 else '')
 import numpy as np, torch
 import bench
 n = int(sys.argv[2]) if len(sys.argv) > 2 else bench.ENVS_PER_GPU
@@ -12,6 +13,8 @@ env, g = bench.make_env(n, 0, 0, 2024)
 rng = np.random.RandomState(1234)
 pool = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(16)])).cuda()
 bench.steady_state(env, pool, rng)
+if os.environ.get("BCP_PAIRS") is not None:
+    env.set_tuning(local_pairs=int(os.environ["BCP_PAIRS"]))
 if os.environ.get("BCP_FUSED") is not None:
     env.set_tuning(fused=int(os.environ["BCP_FUSED"]))
 ms = [env.time_steps(pool[0], 200) for _ in range(5)]
