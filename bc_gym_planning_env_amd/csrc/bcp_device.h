@@ -55,6 +55,12 @@ __device__ __forceinline__ double py_mod(double a, double b)
     return r;
 }
 
+// fmod(a, 2 pi) for far-out arguments (|a| >= 4 pi: an angle that went through normalize_angle once never gets here).
+// ONE copy per kernel instead of one per use: ocml's fmod is a loop of ~100 instructions, normalize_angle is inlined two
+// dozen times into the step kernels, and their code (74 KB) is larger than the instruction cache (64 KB).  Measured in
+// round 4 (same box, builds side by side): 11.77 against 11.95 us per step, no register or spill changes.
+__device__ __attribute__((noinline)) double fmod_two_pi_far(double a) { return fmod(a, kTwoPi); }
+
 // a % (2 pi) with numpy semantics.  fmod is exact (a - k*b is representable); for |a| < 2b it is a itself or one
 // exact subtraction / addition (Sterbenz), so the library call is only needed for far-out arguments.
 __device__ __forceinline__ double py_mod_two_pi(double a)
@@ -62,9 +68,9 @@ __device__ __forceinline__ double py_mod_two_pi(double a)
     const double b = kTwoPi;
     double r;
     if (a >= 0.0) {
-        r = a < b ? a : (a < 2.0 * b ? a - b : fmod(a, b));
+        r = a < b ? a : (a < 2.0 * b ? a - b : fmod_two_pi_far(a));
     } else {
-        r = a > -b ? a : (a > -2.0 * b ? a + b : fmod(a, b));
+        r = a > -b ? a : (a > -2.0 * b ? a + b : fmod_two_pi_far(a));
     }
     if (r != 0.0) {
         if (r < 0.0) r += b;

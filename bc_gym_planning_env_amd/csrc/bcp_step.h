@@ -137,7 +137,7 @@ struct StepArgs {
     // single-kernel step.  Two-kernel step: kernel 1 copies tick[0] to tick[1], kernel 2 stores tick[1] + 1 to tick[0]
     // -- each word is only written while no kernel that reads it is running.  Single-kernel step: the last workgroup
     // to finish (ticket) advances tick[0].  tick[4] counts the bounded waits of step_local_kernel that gave up (bcp_expired_waits).
-    // step_local_kernel draws its ticket EARLY (tick[8], a cache line of its own; see there) -- tick has 16 words.
+    // step_local_kernel draws its ticket from tick[8], a cache line of its own (see there) -- tick has 16 words.
     uint64_t* tick;
     int32_t* pending_base;     // [2][kShards] or nullptr
     int32_t* adapt_base;       // [2] thresholds + [2][kShards] in-place counters, or nullptr (no adaptation)
@@ -633,7 +633,7 @@ __device__ unsigned long long g_diag[kDiagBlocks * 16];
 #define DIAG_STAMP_U(w, k) do { if (threadIdx.x == (w) * 64 && blockIdx.x < 2048) g_diag[(2048 + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define DIAG_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // lane 0 of EVERY wave: row (base + workgroup), slot = wave number (base = 1024, 1536: arrival at barrier 0 / 1)
-#define DIAG_STAMP_WAVES(base) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) g_diag[((base) + blockIdx.x) * 16 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DIAG_STAMP_WAVES(base) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_diag[((base) + blockIdx.x) * 16 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); } while (0)
 // maximum over ALL lanes of the workgroup (not only lane 0 of each wave)
 #define DIAG_MAX_ALL(k, v) do { if (blockIdx.x < 2048) atomicMax(&g_diag[(2048 + blockIdx.x) * 16 + (k)], (unsigned long long)(v)); } while (0)
 extern "C" int bcp_diag_read(unsigned long long* out)
@@ -1673,15 +1673,6 @@ step_local_kernel(const StepArgs launch_args)
     if (tid >= kStaticFrom && tid < kStaticFrom + kStaticChunks) lds_static[tid - kStaticFrom] = st_static;
     DIAG_STAMP_WAVES(1024);
     __syncthreads();   // barrier 0: noise, old heading and the parameter block are in LDS
-    // The step counter moves on when every workgroup of the launch has READ it -- not when every workgroup is done: this
-    // workgroup's waves have all used their copy by now, so its ticket is drawn here, by a wave with time to spare, and only
-    // looked at in the wave's last instructions.  (Rounds 2-3 drew at the very end: 256 workgroups finishing together queue
-    // their returning atomics on one address at the memory side, ~10 ns each, behind the step's critical path -- a second
-    // atomic on that line per workgroup cost the metric step 2.5 us, tools/step_time.py with both builds, round 4.)
-    unsigned int ticket_drawn = 0u;
-    const bool draws = (L.flags & kStepAdvances) && tid == (kLocalWaves - 1) * kBlock;
-    if (draws)
-        ticket_drawn = __hip_atomic_fetch_add((GlobalPtr<unsigned int>)(L.tick + kTickLocalTicket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const DevParams& P = *(const DevParams*)&SL->P;
     const int map_rows = hot_map_rows, map_cols = hot_map_cols;
     const int my_len = hot_path_shared ? hot_max_len : (int)own_len;   // way points of this env's path
@@ -2154,9 +2145,19 @@ step_local_kernel(const StepArgs launch_args)
     if (tid == 0 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 16 + 15] = (unsigned long long)n_parked;
 #endif
     if (poll_expired && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 4), 1ull);   // (bcp_expired_waits)
-    if (draws) {
+    // The last workgroup to get here moves the step counter on (every workgroup has read it long before it draws).  The ticket
+    // has a cache line of its own, and it is drawn HERE, in the last instructions of a wave that is done before the movers are:
+    // measured in round 4 (tools/step_time.py, builds side by side on one box) -- no ticket at all, workgroup 0 moving the
+    // counter on: 11.7 us against 11.8 with the ticket, i.e. it hides behind the movers; the ticket drawn early (behind barrier
+    // 0 or barrier 1, looked at here): 13.3 - 13.8 us -- 256 workgroups draw at the same moment, the returning atomics queue
+    // at the memory side (~10 ns each on one address), and the drawing wave waits for its ticket at its next wait of any kind,
+    // which holds up its share of the way-point scan and with it its pair's mover; a second atomic per workgroup on the
+    // ticket's line (the parked-pose count, first form): 14.3 us.  The parked poses are counted in a word per workgroup instead.
+    if ((a.flags & kStepAdvances) && tid == (kLocalWaves - 1) * kBlock) {
+        const unsigned int ticket_drawn =
+            __hip_atomic_fetch_add((GlobalPtr<unsigned int>)(a.tick + kTickLocalTicket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (n_parked) a.parked_slots[blockIdx.x] += (uint64_t)n_parked;   // (this workgroup's word: no atomic; bcp_parked_poses adds them up)
-        if (ticket_drawn == gridDim.x - 1) {   // every workgroup of this launch has read the counter: it moves on
+        if (ticket_drawn == gridDim.x - 1) {
             *reinterpret_cast<unsigned int*>(a.tick + kTickLocalTicket) = 0u;
             a.tick[0] = step_counter + 1;
         }

@@ -6,6 +6,8 @@ from bc_gym_planning_env_amd import _lib
 _lib.LIB_PATH = os.path.join('tools', 'libbcplan_diag.so')
 import bench
 n = 65536
+pairs = int(os.environ.get("BCP_LOCAL_PAIRS", "4"))   # workgroup size of step_local_kernel (bcp_create reads the same variable)
+groups = n // (64 * pairs)
 rng = np.random.RandomState(0)
 if "c4" in sys.argv[1:]:   # BASELINE configs[3]: private AisleTurn costmaps and paths
     env = bench.make_c4_env(n, 0)
@@ -26,8 +28,9 @@ buf = (C.c_ulonglong * (4096 * 16))()
 L.bcp_diag_read.argtypes = [C.c_void_p]
 L.bcp_diag_read(buf)
 raw = np.array(buf[:]).reshape(4096, 16).astype(np.int64)
-a = raw[:n // 256]
-upper = raw[2048:2048 + n // 256]   # maxima over the waves of a workgroup (DIAG_MAX)
+G = min(groups, 512)                # (stamps of the first 512 workgroups: the per-wave tables below start at row 512)
+a = raw[:G]
+upper = raw[2048:2048 + G]   # maxima over the waves of a workgroup (DIAG_MAX)
 t0 = a[:, 0].min()
 names = {1: "mover: loads issued .. robot model starts", 2: "mover: robot model done", 3: "mover: past barrier 1",
          4: "mover: classified and parked", 5: "mover: past barrier 2", 6: "mover: reward provider done", 7: "mover: decided envs finished",
@@ -50,10 +53,11 @@ for k in sorted(unames):
     print("  %-45s since kernel entry: median %6d  p90 %6d  max %6d" % (unames[k], np.median(d), np.percentile(d, 90), d.max()))
 print("  longest candidate window among the lanes 0 of a workgroup's waves: median %d  p90 %d  max %d way points" % (
     np.median(upper[:, 9]), np.percentile(upper[:, 9], 90), upper[:, 9].max()))
-first = raw[512:512 + n // 256].min(axis=1, keepdims=True)   # the first instruction of the workgroup's earliest wave
-print("  stamp 0 (wave 0, arguments fetched) since the workgroup's first instruction: median %d" % np.median(a[:, 0] - first[:, 0]))
+W = min(groups, 256)                # (per-wave stamps: the first 256 workgroups)
+first = raw[512:512 + W, :4 * pairs].min(axis=1, keepdims=True)   # the first instruction of the workgroup's earliest wave
+print("  stamp 0 (wave 0, arguments fetched) since the workgroup's first instruction: median %d" % np.median(a[:W, 0] - first[:, 0]))
 for base, what in ((512, "first instruction"), (768, "launch arguments fetched"), (1280, "prologue loads issued"), (1024, "arrival at barrier 0"), (1536, "arrival at barrier 1")):
-    w = raw[base:base + n // 256] - first
+    w = raw[base:base + W, :4 * pairs] - first
     print("  %-26s by wave (median cycles since the workgroup's first instruction): %s" % (what, " ".join("%5d" % v for v in np.median(w, axis=0))))
 end = np.maximum(a[:, 13], a[:, 14]) - t0
 print("workgroup end since the earliest start: median %d  p90 %d  max %d cycles" % (np.median(end), np.percentile(end, 90), end.max()))
