@@ -623,12 +623,16 @@ constexpr int kWavePerPoseFrom = 1;   // step_pending_kernel: more than this man
 #ifdef BCP_DIAG
 constexpr int kDiagBlocks = 4096;   // stamps of the first kDiagBlocks workgroups of a step kernel, 16 slots each
 __device__ unsigned long long g_diag[kDiagBlocks * 16];
-#define DIAG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DIAG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_diag[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)   /* (rows 512 .. 2047 hold the per-wave tables) */
 // lane 0 of wave `w` of the workgroup
 #define DIAG_STAMP_W(w, k) do { if (threadIdx.x == (w) * 64 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 // maxima over the waves of a workgroup live in the upper half of the array (slot k of workgroup b: (2048 + b) * 16 + k)
 #define DIAG_MAX(k, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) atomicMax(&g_diag[(2048 + blockIdx.x) * 16 + (k)], (unsigned long long)(v)); } while (0)
 #define DIAG_NOW() __builtin_amdgcn_s_memtime()
+// wall-clock stamps (s_memrealtime: 100 MHz, the same counter chip-wide -- s_memtime is not comparable between compute units):
+// rows 3072 + workgroup (grids of up to 1024 workgroups), slot 0 = earliest entry of a wave, slot 1 = latest exit
+#define DIAG_REAL_ENTRY() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) atomicMax(&g_diag[(3072 + blockIdx.x) * 16 + 0], ~(unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)   /* (the complement: bcp_diag_clear zeroes) */
+#define DIAG_REAL_EXIT() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) atomicMax(&g_diag[(3072 + blockIdx.x) * 16 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
 // further stamps of lane 0 of wave `w`, in the upper half next to the maxima: slot k = 1 .. 15 of workgroup b at (2048 + b) * 16 + k
 #define DIAG_STAMP_U(w, k) do { if (threadIdx.x == (w) * 64 && blockIdx.x < 2048) g_diag[(2048 + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define DIAG_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -652,6 +656,8 @@ extern "C" int bcp_diag_clear()
 #define DIAG_STAMP_W(w, k) do { } while (0)
 #define DIAG_MAX(k, v) do { } while (0)
 #define DIAG_NOW() 0ull
+#define DIAG_REAL_ENTRY() do { } while (0)
+#define DIAG_REAL_EXIT() do { } while (0)
 #define DIAG_STAMP_U(w, k) do { } while (0)
 #define DIAG_WAIT_VMEM() do { } while (0)
 #define DIAG_STAMP_WAVES(base) do { } while (0)
@@ -1460,6 +1466,7 @@ step_local_kernel(const StepArgs launch_args)
     [[maybe_unused]] constexpr int kWScorer = PAIRS, kWHelper1 = 2 * PAIRS, kWHelper2 = 3 * PAIRS;   // pair 0's waves (stamps)
     KernArgs a = *(const __attribute__((address_space(4))) StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     DIAG_STAMP_WAVES(512);    // every wave: first instruction
+    DIAG_REAL_ENTRY();
     // (static issue priorities by role, s_setprio -- the movers above everybody else, or everybody else above the movers
     //  until barrier 0, or behind barrier 1 -- change nothing: +-0.5 % in every form tried)
     // The prologue is ONE memory round trip.  Everything a wave asks for first -- the mover's state, action and robot
@@ -2145,6 +2152,7 @@ step_local_kernel(const StepArgs launch_args)
     if (tid == 0 && blockIdx.x < kDiagBlocks) g_diag[blockIdx.x * 16 + 15] = (unsigned long long)n_parked;
 #endif
     if (poll_expired && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.tick + 4), 1ull);   // (bcp_expired_waits)
+    DIAG_REAL_EXIT();
     // The last workgroup to get here moves the step counter on (every workgroup has read it long before it draws).  The ticket
     // has a cache line of its own, and it is drawn HERE, in the last instructions of a wave that is done before the movers are:
     // measured in round 4 (tools/step_time.py, builds side by side on one box) -- no ticket at all, workgroup 0 moving the

@@ -27,7 +27,8 @@ torch.cuda.synchronize()
 buf = (C.c_ulonglong * (4096 * 16))()
 L.bcp_diag_read.argtypes = [C.c_void_p]
 L.bcp_diag_read(buf)
-raw = np.array(buf[:]).reshape(4096, 16).astype(np.int64)
+raw_u = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 16).copy()   # (the wall-clock rows hold complements: keep them unsigned)
+raw = raw_u.astype(np.int64)
 G = min(groups, 512)                # (stamps of the first 512 workgroups: the per-wave tables below start at row 512)
 a = raw[:G]
 upper = raw[2048:2048 + G]   # maxima over the waves of a workgroup (DIAG_MAX)
@@ -59,6 +60,21 @@ print("  stamp 0 (wave 0, arguments fetched) since the workgroup's first instruc
 for base, what in ((512, "first instruction"), (768, "launch arguments fetched"), (1280, "prologue loads issued"), (1024, "arrival at barrier 0"), (1536, "arrival at barrier 1")):
     w = raw[base:base + W, :4 * pairs] - first
     print("  %-26s by wave (median cycles since the workgroup's first instruction): %s" % (what, " ".join("%5d" % v for v in np.median(w, axis=0))))
+# wall clock (s_memrealtime, 100 MHz, one counter chip-wide): when does a workgroup enter and leave, against the first entry of the launch
+real = raw_u[3072:3072 + min(groups, 1024)]
+entry = (~real[:, 0]).astype(np.int64)
+leave = real[:, 1].astype(np.int64)
+ok = real[:, 1] > 0
+t_first = entry[ok].min()
+print("wall clock, microseconds since the first workgroup's entry (%d workgroups):" % ok.sum())
+print("   entry: median %.2f  p90 %.2f  max %.2f   exit: median %.2f  p90 %.2f  max %.2f   life: median %.2f p90 %.2f max %.2f" % (
+    np.median(entry[ok] - t_first) / 100.0, np.percentile(entry[ok] - t_first, 90) / 100.0, (entry[ok] - t_first).max() / 100.0,
+    np.median(leave[ok] - t_first) / 100.0, np.percentile(leave[ok] - t_first, 90) / 100.0, (leave[ok] - t_first).max() / 100.0,
+    np.median((leave - entry)[ok]) / 100.0, np.percentile((leave - entry)[ok], 90) / 100.0, (leave - entry)[ok].max() / 100.0))
+for k in range(0, len(entry), 256):   # (round-4 probe: workgroups b, b + 256, ... share a compute unit)
+    sel = ok[k:k + 256]
+    e, l = entry[k:k + 256][sel] - t_first, leave[k:k + 256][sel] - t_first
+    print("   workgroups %4d .. %4d: entry median %.2f max %.2f, exit median %.2f max %.2f" % (k, k + 255, np.median(e) / 100.0, e.max() / 100.0, np.median(l) / 100.0, l.max() / 100.0))
 end = np.maximum(a[:, 13], a[:, 14]) - t0
 print("workgroup end since the earliest start: median %d  p90 %d  max %d cycles" % (np.median(end), np.percentile(end, 90), end.max()))
 
