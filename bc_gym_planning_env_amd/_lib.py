@@ -82,6 +82,7 @@ SYMBOLS = {
     "bcp_reset_masked": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "bcp_broadcast_state": (C.c_int, [_H, C.c_int64, C.c_void_p, C.c_void_p]),
     "bcp_step": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_uint32, C.c_void_p]),
+    "bcp_rollout": (C.c_int, [_H, C.POINTER(BcpStepIO), C.c_int32, C.c_uint32, C.c_void_p]),
     "bcp_expired_waits": (C.c_int, [_H, C.POINTER(C.c_int64), C.c_void_p]),
     "bcp_parked_poses": (C.c_int, [_H, C.POINTER(C.c_int64), C.c_void_p]),
     "bcp_side_stream": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p)]),

@@ -712,6 +712,54 @@ class BatchedPlanEnv(object):
         self._last_inputs = (actions, z, done)  # keep inputs alive until the stream has consumed them
         return self._obs, self.reward, done, self._info
 
+    def rollout(self, actions, noise_z=None, noise_z_out=None, collided_out=None, err_out=None):
+        """K ticks for every env in one library call (bcp_rollout): actions [K, N, 2] float32 / float64 on the device (or
+        anything torch can put there).  Returns (reward float64 [K, N], done uint8 [K, N]) device tensors, no sync; the
+        state ends where K calls of step() with actions[k] would leave it, bit for bit (auto-reset and the on-device
+        noise stream included).  noise_z / noise_z_out: optional [K, N, 3]; collided_out uint8 / err_out int32: optional
+        [K, N] (without them only the last step's collided_now / err are kept).  With the single-launch step form the K
+        steps are ONE kernel launch -- open-loop Monte-Carlo rollouts from one state (the reference's README) pay launch,
+        argument fetch and staging once, and no workgroup waits for the chip's slowest one between steps."""
+        if not isinstance(actions, torch.Tensor):
+            actions = torch.from_numpy(np.ascontiguousarray(actions))
+        if actions.dtype not in (torch.float32, torch.float64):
+            actions = actions.to(torch.float64)
+        actions = actions.to(self.device).contiguous()
+        k, n = int(actions.shape[0]), self.n_envs
+        assert tuple(actions.shape) == (k, n, 2) and k >= 1
+        io = _lib.BcpStepIO()
+        io.actions = actions.data_ptr()
+        flags = self._flags_f32 if actions.dtype == torch.float32 else self._flags_f64
+        keep = [actions]
+        if noise_z is not None:
+            z = noise_z if isinstance(noise_z, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(noise_z))
+            z = z.to(self.device, torch.float64).contiguous()
+            assert tuple(z.shape) == (k, n, 3)
+            io.noise_z = z.data_ptr()
+            keep.append(z)
+        if noise_z_out is not None:
+            assert noise_z_out.dtype == torch.float64 and tuple(noise_z_out.shape) == (k, n, 3) and noise_z_out.is_contiguous()
+            io.noise_z_out = noise_z_out.data_ptr()
+        reward = torch.empty((k, n), dtype=torch.float64, device=self.device)
+        done = torch.empty((k, n), dtype=torch.uint8, device=self.device)
+        io.reward, io.done = reward.data_ptr(), done.data_ptr()
+        if collided_out is not None:
+            assert collided_out.dtype == torch.uint8 and tuple(collided_out.shape) == (k, n) and collided_out.is_contiguous()
+            io.collided_now = collided_out.data_ptr()
+        if err_out is not None:
+            assert err_out.dtype == torch.int32 and tuple(err_out.shape) == (k, n) and err_out.is_contiguous()
+            io.err = err_out.data_ptr()
+        _lib.check(self._lib.bcp_rollout(self._h, C.byref(io), k, flags, self._stream()))
+        # the per-step views of step() show the last row
+        self.reward.copy_(reward[-1])
+        self.done.copy_(done[-1])
+        if collided_out is not None:
+            self.collided_now.copy_(collided_out[-1])
+        if err_out is not None:
+            self.err.copy_(err_out[-1])
+        self._last_inputs = tuple(keep)
+        return reward, done
+
     def check_errors(self):
         """Raise what the reference would have raised during the last step (synchronises); and a RuntimeError if a
         wait inside the step kernel ever gave up (bcp_expired_waits: a defect of the library, not of the data)."""

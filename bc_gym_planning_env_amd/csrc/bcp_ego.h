@@ -814,7 +814,7 @@ __device__ __forceinline__ void ego_image_slow(const EgoArgs& a, const EgoImage&
 
 typedef uint32_t EgoU32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kEgoHeld = 512;   // cells a wave can hold back in LDS between the culling pass and the patches
+constexpr int kEgoHeld = 768;   // cells a wave can hold back in LDS between the culling pass and the patches
 
 // LDS of ego_sparse_kernel, per wave: cv::hal::warpAffine's column terms {adelta, bdelta}(x) = {sat(M0 x 1024), sat(M3 x 1024)}
 // for every column of the window, its row terms {sat((M1 y + M2) 1024) + 512, sat((M4 y + M5) 1024) + 512} for every row,
@@ -867,9 +867,7 @@ __device__ __forceinline__ void ego_patch_cell(const EgoArgs& a, LdsI32x2 col_ta
 //   B. the zero fill (all the HBM traffic there is);
 //   C. s_waitcnt vmcnt(0) -- a patch must not be overtaken by the zeros: same wave, same addresses, no other ordering --,
 //      then the patches, a held cell per lane: integer adds and compares on table entries.
-// More than kEgoHeld cells inside one window (a dense corner of an otherwise sparse map): the wave streams the whole list once
-// more behind the fill, culling and patching 64 cells at a time through the same LDS list (slow: every list load then waits
-// for the patch stores before it; the host's limit on cells per map keeps such windows rare).
+// More than kEgoHeld cells inside one window (a dense corner of an otherwise sparse map): further passes of A and C.
 __global__ void __launch_bounds__(64 * kEgoWaves) ego_sparse_kernel(const EgoArgs a, const uint32_t* __restrict__ cells,
                                                                      const int32_t* __restrict__ counts, int cap)
 {
@@ -916,87 +914,73 @@ __global__ void __launch_bounds__(64 * kEgoWaves) ego_sparse_kernel(const EgoArg
                 const float fx = f0 * sx + f1 * sy + f2, fy = f3 * sx + f4 * sy + f5;
                 return cell != 0u && fx > -2.0f && fx < x_hi && fy > -2.0f && fy < y_hi;   // (a listed cell has a non-zero value byte)
             };
-            // ---- A. cull: which cells can reach the window at all
-            int held = 0;            // cells in the wave's LDS list (uniform)
-            bool overflow = false;
-            for (int c0 = 0; c0 < n_cells && !overflow; c0 += 256) {
-                uint32_t cell[4];
+            // ---- A / B / C, in passes: cull list cells into the wave's LDS list until the list is read or the LDS list is
+            // full; (first pass only: this image's tables, the zero fill, the wait for it); patch what is held.  One pass
+            // unless a window holds more than kEgoHeld cells (a dense corner of an otherwise sparse map): a later pass's list
+            // loads wait for the patch stores before them -- once per pass, not once per 64 cells (round 4's first form
+            // streamed the list 64 cells at a time behind the fill: 3.4 ms per call on the 350 x 512 AisleTurn map, where a
+            // third of the windows hold more than 256 cells).
+            int next = 0;            // first list cell not culled yet (uniform)
+            bool filled = false;
+            do {
+                int held = 0;        // cells in the wave's LDS list (uniform)
+                bool full = false;
+                for (int c0 = next; c0 < n_cells && !full; c0 += 256) {
+                    uint32_t cell[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) cell[u] = c0 + 64 * u + lane < n_cells ? list[c0 + 64 * u + lane] : 0u;
+                    for (int u = 0; u < 4; ++u) cell[u] = c0 + 64 * u + lane < n_cells ? list[c0 + 64 * u + lane] : 0u;
+                    next = c0 + 256;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool in = meets_window(cell[u]);
-                    const uint64_t hits = __ballot(in);
-                    const int more = __builtin_popcountll(hits);
-                    if (held + more > kEgoHeld) {
-                        overflow = true;
-                        break;
+                    for (int u = 0; u < 4; ++u) {
+                        const bool in = meets_window(cell[u]);
+                        const uint64_t hits = __ballot(in);
+                        const int more = __builtin_popcountll(hits);
+                        if (held + more > kEgoHeld) {   // (this chunk of 64 starts the next pass)
+                            full = true;
+                            next = c0 + 64 * u;
+                            break;
+                        }
+                        if (in) mine_cells[held + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u))] = cell[u];
+                        held += more;
                     }
-                    if (in) mine_cells[held + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u))] = cell[u];
-                    held += more;
                 }
-            }
-            // ... and, if anything is left, warpAffine's terms of this image
-            if (held > 0 || overflow) {
-                for (int t = lane; t < a.dcols + a.drows; t += 64) {
-                    EgoI32x2 e;
-                    if (t < a.dcols) {
-                        e.x = sat_int(I.m0 * t * 1024);
-                        e.y = sat_int(I.m3 * t * 1024);
-                    } else {
-                        const int y = t - a.dcols;
-                        e.x = sat_int((I.m1 * y + I.m2) * 1024) + 512;
-                        e.y = sat_int((I.m4 * y + I.m5) * 1024) + 512;
+                if (!filled) {
+                    // warpAffine's terms of this image, if anything is to be patched
+                    if (held > 0) {
+                        for (int t = lane; t < a.dcols + a.drows; t += 64) {
+                            EgoI32x2 e;
+                            if (t < a.dcols) {
+                                e.x = sat_int(I.m0 * t * 1024);
+                                e.y = sat_int(I.m3 * t * 1024);
+                            } else {
+                                const int y = t - a.dcols;
+                                e.x = sat_int((I.m1 * y + I.m2) * 1024) + 512;
+                                e.y = sat_int((I.m4 * y + I.m5) * 1024) + 512;
+                            }
+                            col_tab[t] = e;   // (row_tab follows col_tab)
+                        }
                     }
-                    col_tab[t] = e;   // (row_tab follows col_tab)
+                    // zeros: bytes up to the first 16-byte boundary, aligned 16-byte stores, the tail
+                    const int head = (int)((16u - (uint32_t)(uintptr_t)image) & 15u);
+                    const int64_t body = (P - head) >> 4;           // whole 16-byte pieces
+                    const int tail = (int)(P - head - (body << 4));
+                    if (lane < head) image[lane] = 0;
+                    EgoU32x4* const q = reinterpret_cast<EgoU32x4*>(image + head);
+                    const EgoU32x4 zero = {0u, 0u, 0u, 0u};
+                    for (int64_t c = lane; c < body; c += 64) q[c] = zero;   // (non-temporal stores: 7 % slower)
+                    if (lane < tail) image[head + (body << 4) + lane] = 0;
+                    filled = true;
+                    if (held == 0) break;   // (nothing in the window; a list that fills LDS holds something)
+                    // the patches go behind the zeros (measured alternatives to this wait, round 3: all the fills of a batch
+                    // of images first 0.32 against 0.20 ms; a two-stage pipeline with s_waitcnt vmcnt(16) 0.27 ms)
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
                 }
-            }
-            // ---- B. zeros: bytes up to the first 16-byte boundary, aligned 16-byte stores, the tail
-            {
-                const int head = (int)((16u - (uint32_t)(uintptr_t)image) & 15u);
-                const int64_t body = (P - head) >> 4;           // whole 16-byte pieces
-                const int tail = (int)(P - head - (body << 4));
-                if (lane < head) image[lane] = 0;
-                EgoU32x4* const q = reinterpret_cast<EgoU32x4*>(image + head);
-                const EgoU32x4 zero = {0u, 0u, 0u, 0u};
-                for (int64_t c = lane; c < body; c += 64) q[c] = zero;   // (non-temporal stores: 7 % slower)
-                if (lane < tail) image[head + (body << 4) + lane] = 0;
-            }
-            if (held == 0 && !overflow) continue;
-            // ---- C. the patches, behind the zeros (measured alternatives to this wait, round 3: all the fills of a batch of
-            // images first 0.32 against 0.20 ms; a two-stage pipeline with s_waitcnt vmcnt(16) 0.27 ms)
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-            if (!overflow) {
+                __builtin_amdgcn_wave_barrier();
                 for (int c0 = 0; c0 < held; c0 += 64)
                     if (c0 + lane < held) ego_patch_cell(a, col_tab, row_tab, image, mine_cells[c0 + lane], f0, f1, f2, f3, f4, f5);
                 __builtin_amdgcn_wave_barrier();
-                continue;
-            }
-            held = 0;
-            for (int c0 = 0; c0 < n_cells; c0 += 64) {
-                const uint32_t cell = c0 + lane < n_cells ? list[c0 + lane] : 0u;
-                const bool in = meets_window(cell);
-                const uint64_t hits = __ballot(in);
-                if (hits == 0) continue;
-                if (in) mine_cells[held + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u))] = cell;
-                held += __builtin_popcountll(hits);
-                __builtin_amdgcn_wave_barrier();
-                if (held >= 64) {
-                    const uint32_t take = mine_cells[lane];
-                    const uint32_t keep = mine_cells[64 + lane];
-                    __builtin_amdgcn_wave_barrier();
-                    held -= 64;
-                    if (lane < held) mine_cells[lane] = keep;
-                    ego_patch_cell(a, col_tab, row_tab, image, take, f0, f1, f2, f3, f4, f5);
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            if (held > 0) {
-                const uint32_t take = mine_cells[lane < held ? lane : 0];
-                if (lane < held) ego_patch_cell(a, col_tab, row_tab, image, take, f0, f1, f2, f3, f4, f5);
-            }
-            __builtin_amdgcn_wave_barrier();
+            } while (next < n_cells);
         }
     }
 }

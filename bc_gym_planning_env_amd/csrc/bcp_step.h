@@ -142,6 +142,7 @@ struct StepArgs {
     int32_t* pending_base;     // [2][kShards] or nullptr
     int32_t* adapt_base;       // [2] thresholds + [2][kShards] in-place counters, or nullptr (no adaptation)
     uint64_t* parked_slots;    // [workgroups of step_local_kernel] parked poses so far, a word per workgroup (bcp_parked_poses)
+    int32_t rollout_steps;     // step_local_kernel<.., ROLL = true> (bcp_rollout): steps per launch; actions / noise_z / outputs are [steps][N]..
 };
 constexpr int kTickWords = 16;
 constexpr int kTickLocalTicket = 8;   // step_local_kernel's ticket: not on the line the prologues read the counter and the seed from
@@ -849,8 +850,10 @@ __device__ __forceinline__ int64_t slot_of(SP S, int64_t i, const Pending& q)
 template <bool PLAIN, typename A, typename SP>
 __device__ __forceinline__ void finalize_env_from(const A& a, SP S, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
                                              const PathWindow* free_window = nullptr, bool have_score = false,
-                                             ScoredFree score = ScoredFree(), int known_len = -1, bool score_fits_hit = false)
+                                             ScoredFree score = ScoredFree(), int known_len = -1, bool score_fits_hit = false,
+                                             int64_t out_base = 0)
 {   // (the score travels by value: a pointer to a local made the compiler keep it in scratch memory;
+    //  out_base: element offset of this step's rows in the output arrays -- step k of a rollout writes row k, bcp_rollout --;
     //  known_len >= 0: the caller already holds the length of this env's path;
     //  score_fits_hit: `score` was computed for the rolled-back pose of a colliding env -- continuous provider only)
     const DevParams& P = *(const DevParams*)&S->P;   // (S may point into LDS: step_local_kernel)
@@ -912,15 +915,16 @@ __device__ __forceinline__ void finalize_env_from(const A& a, SP S, int64_t i, P
     }
     const bool done = goal || (iter >= P.iteration_timeout) || collided;
 
-    as_global(a.reward)[i] = rew;
-    as_global(a.done)[i] = (uint8_t)done;
-    if (a.collided_now) as_global(a.collided_now)[i] = (uint8_t)hit;
-    if (a.err) as_global(a.err)[i] = q.err;
+    const int64_t o = out_base + i;
+    as_global(a.reward)[o] = rew;
+    as_global(a.done)[o] = (uint8_t)done;
+    if (a.collided_now) as_global(a.collided_now)[o] = (uint8_t)hit;
+    if (a.err) as_global(a.err)[o] = q.err;
     if (a.noise_z_out) {
         const double nan = __builtin_nan("");
-        as_global(a.noise_z_out)[3 * i + 0] = (q.drawn & 1) ? q.z[0] : nan;
-        as_global(a.noise_z_out)[3 * i + 1] = (q.drawn & 2) ? q.z[1] : nan;
-        as_global(a.noise_z_out)[3 * i + 2] = (q.drawn & 4) ? q.z[2] : nan;
+        as_global(a.noise_z_out)[3 * o + 0] = (q.drawn & 1) ? q.z[0] : nan;
+        as_global(a.noise_z_out)[3 * o + 1] = (q.drawn & 2) ? q.z[1] : nan;
+        as_global(a.noise_z_out)[3 * o + 2] = (q.drawn & 4) ? q.z[2] : nan;
     }
 
     if (done && (a.flags & BCP_STEP_AUTO_RESET)) {  // PlanEnv.reset(): set_state(initial_state) (env.py:293-303)
@@ -1454,9 +1458,19 @@ constexpr int kPollLimit = 1 << 16;
 #define BOUNDED_POLL(cond, expired) do { int trips_ = 0; while (cond) { __builtin_amdgcn_s_sleep(1); if (++trips_ > kPollLimit) { (expired) = true; break; } } } while (0)
 constexpr uint32_t kDiagWithholdVerdicts = 1u << 23;   // -DBCP_DIAG builds: parked poses are tested but their verdicts never posted
 
-template <bool WIDE, bool PLAIN, int PAIRS>
-__global__ void __attribute__((amdgpu_flat_work_group_size(4 * PAIRS * kBlock, 4 * PAIRS * kBlock), amdgpu_waves_per_eu(4)))
-step_local_kernel(const StepArgs launch_args)
+// ROLL (bcp_rollout): the workgroup takes its envs through StepArgs::rollout_steps steps inside ONE launch -- actions,
+// optional normals and the outputs are [steps][N] arrays, the state goes through its usual arrays between steps.  The launch
+// and the staging of footprint / path / lethal map / parameter block happen once, and -- the larger part -- a workgroup
+// starts its next step when IT is done, not when the slowest workgroup of the chip is (envs are independent,
+// envs/base/env.py:334-361: there is nothing to wait for).  Every trip fetches its launch arguments again (scalar-cache hits
+// from the second on): carried across the loop the ~60 pinned words did not fit the scalar registers (600 spills).  Bit for
+// bit the same states and outputs as that many launches of the one-step form (tests/test_gpu_rollout.py).  The one-step
+// form is this code with the loop folded away.
+typedef const __attribute__((address_space(4))) StepArgs* KernArgPtr;
+
+// one step of the workgroup's envs: the whole of the one-step kernel, and one trip (`rs`) of a rollout
+template <bool WIDE, bool PLAIN, int PAIRS, bool ROLL>
+__device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs)
 {
     static_assert(PAIRS == 1 || PAIRS == 2 || PAIRS == 4, "a workgroup holds 1, 2 or 4 (mover, scorer, helper, helper) quartets");
     constexpr int kLocalPairs = PAIRS, kLocalWaves = 4 * PAIRS, kLocalEnvs = PAIRS * kBlock;
@@ -1464,7 +1478,6 @@ step_local_kernel(const StepArgs launch_args)
     constexpr int kStaticFrom = (kLocalWaves - 2) * kBlock;   // *S is staged by the last two waves
     constexpr int kCtlFrom = (kLocalWaves - 1) * kBlock;      // the control words are zeroed by the last wave
     [[maybe_unused]] constexpr int kWScorer = PAIRS, kWHelper1 = 2 * PAIRS, kWHelper2 = 3 * PAIRS;   // pair 0's waves (stamps)
-    KernArgs a = *(const __attribute__((address_space(4))) StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     DIAG_STAMP_WAVES(512);    // every wave: first instruction
     DIAG_REAL_ENTRY();
     // (static issue priorities by role, s_setprio -- the movers above everybody else, or everybody else above the movers
@@ -1481,6 +1494,7 @@ step_local_kernel(const StepArgs launch_args)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool mover = wave < kLocalPairs, scorer = wave >= kLocalPairs && wave < 2 * kLocalPairs;
     const int pair = wave & (kLocalPairs - 1);
+    KernArgs a = *kernarg;
     // (the launch arguments the prologue uses, fetched together before the first branch: pin_sgpr)
     PrologueArgs L;
     {
@@ -1498,7 +1512,13 @@ step_local_kernel(const StepArgs launch_args)
         L.tick = L.hot.io_tick;
         L.flags = L.hot.io_flags;
         L.S = a.S;   // (not pinned: a pointer that went through the asm is no longer known to be uniform, nor global)
+        if (ROLL) {   // this step's rows of the [steps][N].. inputs
+            const int64_t row = (int64_t)rs * L.hot.n;
+            L.actions = (const char*)L.actions + row * ((L.flags & BCP_STEP_ACTIONS_F32) ? 8 : 16);
+            L.noise_z = L.noise_z ? L.noise_z + 3 * row : nullptr;
+        }
     }
+    const int64_t out_base = ROLL ? (int64_t)rs * L.hot.n : 0;
     const int hot_n_verts = L.hot.n_verts, hot_npath = L.hot.lds_path_doubles, hot_path_shared = L.hot.path_shared;
     const int hot_map_rows = L.hot.map_rows, hot_map_cols = L.hot.map_cols, hot_map_wpr = L.hot.map_wpr;
     const int hot_map_shared = L.hot.map_shared, hot_noise_on = L.hot.noise_on, hot_max_len = L.hot.path_max_len;
@@ -1599,7 +1619,7 @@ step_local_kernel(const StepArgs launch_args)
     //     vector loads of a uniform address: they arrive with the state, in vector registers, and scalar registers stay free
     //     (PLAIN only: with delay queues the first half runs behind barrier 0, on the constants in LDS)
     double rc[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (PLAIN && mover) {
+    if (PLAIN && mover) {   // (a rollout fetches them in every trip: seven loads, nothing to carry across the loop)
         int zero;
         asm("v_mov_b32 %0, 0" : "=v"(zero));   // (opaque: keeps these loads on the vector side)
         const GlobalPtr<const double> pc = as_global(&a.S->P.dt) + zero;
@@ -1613,12 +1633,14 @@ step_local_kernel(const StepArgs launch_args)
     //     loads per thread kept the SIMDs busy for 1 - 2 k cycles before the movers' own loads were even issued.
     //     (issued FIRST by those two waves it was measured slower, 11.75 against 11.70 us: it then competes with the movers' loads)
     u32x4 st_static = {0u, 0u, 0u, 0u};
-    if (tid >= kStaticFrom && tid < kStaticFrom + kStaticChunks) st_static = as_global(reinterpret_cast<const u32x4*>(a.S))[tid - kStaticFrom];
+    const bool first_trip = !ROLL || rs == 0;   // the staging data is copied into LDS once per launch
+    if (first_trip && tid >= kStaticFrom && tid < kStaticFrom + kStaticChunks) st_static = as_global(reinterpret_cast<const u32x4*>(a.S))[tid - kStaticFrom];
     DIAG_STAMP_U(0, 10);   // mover: own + staging loads issued
     DIAG_STAMP_U(kWScorer, 11);   // scorer: the same
     DIAG_STAMP_WAVES(1280);   // every wave: prologue loads issued
     __builtin_amdgcn_sched_barrier(0);
-    const uint64_t step_counter = mover ? 0 : uniform_u64(tick_counter), seed = mover ? 0 : uniform_u64(tick_seed);
+    // (a rollout: the counter in memory stands still until the launch's last trip has drawn its ticket)
+    const uint64_t step_counter = mover ? 0 : uniform_u64(tick_counter) + (ROLL ? (uint64_t)rs : 0ull), seed = mover ? 0 : uniform_u64(tick_seed);
     // (5) what needs no pose.  The odometry noise of this step needs nothing but seed, env id and step counter: Philox +
     //     float64 Box-Muller.  Slots 1 and 2 -- the ones PlanEnv's noise model draws -- are the two halves of one pair
     //     (device_normals): the scorer draws them; slot 0, when the model can consume it at all, the pair's second helper;
@@ -1677,7 +1699,7 @@ step_local_kernel(const StepArgs launch_args)
     }
     // (6) the parameter block into LDS
     if (tid >= kCtlFrom && tid < kCtlFrom + 16) ctl[tid - kCtlFrom] = 0;
-    if (tid >= kStaticFrom && tid < kStaticFrom + kStaticChunks) lds_static[tid - kStaticFrom] = st_static;
+    if (first_trip && tid >= kStaticFrom && tid < kStaticFrom + kStaticChunks) lds_static[tid - kStaticFrom] = st_static;
     DIAG_STAMP_WAVES(1024);
     __syncthreads();   // barrier 0: noise, old heading and the parameter block are in LDS
     const DevParams& P = *(const DevParams*)&SL->P;
@@ -1713,7 +1735,7 @@ step_local_kernel(const StepArgs launch_args)
         DIAG_STAMP_U(kWHelper1, 2);   // helper: cos / sin of the old heading
     }
     // (7b) everybody else stages what is read behind barrier 1: loads first, all of them in flight together, then the stores
-    if (!mover) {
+    if (!mover && first_trip) {
         constexpr int kStagers = (kLocalWaves - kLocalPairs) * kBlock;            // 768 / 384 / 192 threads
         constexpr int kMapPerStager = (kLocalMapWords + kStagers - 1) / kStagers;   // 6 / 11 / 22 words each
         constexpr int kBoxAt = kStagers >= 448 ? 256 : kStagers - 8;              // who fetches the path's box (8 doubles) ...
@@ -2020,7 +2042,7 @@ step_local_kernel(const StepArgs launch_args)
 #pragma unroll
                 for (int k = 0; k < 7; ++k) q.popped_state[k] = fifo_stash[(3 + k) * kLocalEnvs];
             }
-            finalize_env_from<PLAIN>(a, SL, i, q, hit, lds_path, nullptr, !ABLATED(a, kAblateNoReward), sc, my_len);
+            finalize_env_from<PLAIN>(a, SL, i, q, hit, lds_path, nullptr, !ABLATED(a, kAblateNoReward), sc, my_len, false, out_base);
         }
     }
     DIAG_STAMP_W(kWHelper1, 9);   // helper: past the second barrier
@@ -2143,7 +2165,7 @@ step_local_kernel(const StepArgs launch_args)
 #pragma unroll
                 for (int k = 0; k < 7; ++k) q.popped_state[k] = fifo_stash[(3 + k) * kLocalEnvs];
             }
-            finalize_env_from<PLAIN>(a, SL, i, q, verdict == 2, lds_path, nullptr, !ABLATED(a, kAblateNoReward), sc, my_len, fits);
+            finalize_env_from<PLAIN>(a, SL, i, q, verdict == 2, lds_path, nullptr, !ABLATED(a, kAblateNoReward), sc, my_len, fits, out_base);
         }
     }
     DIAG_STAMP(13);            // mover: out of tickets
@@ -2162,12 +2184,47 @@ step_local_kernel(const StepArgs launch_args)
     // which holds up its share of the way-point scan and with it its pair's mover; a second atomic per workgroup on the
     // ticket's line (the parked-pose count, first form): 14.3 us.  The parked poses are counted in a word per workgroup instead.
     if ((a.flags & kStepAdvances) && tid == (kLocalWaves - 1) * kBlock) {
-        const unsigned int ticket_drawn =
-            __hip_atomic_fetch_add((GlobalPtr<unsigned int>)(a.tick + kTickLocalTicket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (n_parked) a.parked_slots[blockIdx.x] += (uint64_t)n_parked;   // (this workgroup's word: no atomic; bcp_parked_poses adds them up)
-        if (ticket_drawn == gridDim.x - 1) {
-            *reinterpret_cast<unsigned int*>(a.tick + kTickLocalTicket) = 0u;
-            a.tick[0] = step_counter + 1;
+        if (!ROLL || rs == a.rollout_steps - 1) {
+            const unsigned int ticket_drawn =
+                __hip_atomic_fetch_add((GlobalPtr<unsigned int>)(a.tick + kTickLocalTicket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket_drawn == gridDim.x - 1) {
+                *reinterpret_cast<unsigned int*>(a.tick + kTickLocalTicket) = 0u;
+                a.tick[0] = step_counter + 1;
+            }
+        }
+    }
+}
+
+// A rollout's trips are CALLS of one out-of-line copy of the step: written as a loop around the inlined body the compiler
+// hoisted the body's loop-invariant values -- launch arguments, addresses, the few hundred float64 constants of its
+// transcendental functions -- in front of the loop and carried them across it (300 - 500 scalar and ~100 vector spills,
+// 300 bytes of scratch per lane); a call boundary keeps every trip's code what the one-step kernel's is.
+template <bool WIDE, bool PLAIN, int PAIRS>
+__device__ __attribute__((noinline)) void step_local_trip(uint64_t kernarg_bits, int rs)
+{
+    // (arguments of a device function arrive in vector registers: the address of the launch arguments and the trip number are
+    //  made scalar again.  The kernarg-segment builtin is no way to the arguments from inside a callee: the first form of
+    //  this function used it and read address 0.)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kernarg_bits);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(kernarg_bits >> 32));
+    step_local_body<WIDE, PLAIN, PAIRS, true>((KernArgPtr)(uintptr_t)(((uint64_t)hi << 32) | lo), __builtin_amdgcn_readfirstlane(rs));
+}
+
+template <bool WIDE, bool PLAIN, int PAIRS, bool ROLL = false>
+__global__ void __attribute__((amdgpu_flat_work_group_size(4 * PAIRS * kBlock, 4 * PAIRS * kBlock), amdgpu_waves_per_eu(4)))
+step_local_kernel(const StepArgs launch_args)
+{
+    KernArgPtr kernarg = (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    if constexpr (!ROLL) {
+        step_local_body<WIDE, PLAIN, PAIRS, false>(kernarg, 0);
+    } else {
+        const int n_steps = kernarg->rollout_steps;
+        for (int rs = 0; rs < n_steps; ++rs) {
+            step_local_trip<WIDE, PLAIN, PAIRS>((uint64_t)(uintptr_t)kernarg, rs);
+            // the next step: the control words, the hand-over buffers and the parked records are rewritten from here on, and the
+            // scanners read what this step's movers have just stored (workgroup scope: the waves share the compute unit's L1)
+            __syncthreads();
         }
     }
 }

@@ -1652,9 +1652,17 @@ static int rearm_parking(bcp_handle* h, hipStream_t s)
     return BCP_OK;
 }
 
-// step_local_kernel<WIDE, PLAIN, PAIRS>: variant = WIDE << 1 | PLAIN
-static const void* local_step_fn(int variant, int pairs)
+// step_local_kernel<WIDE, PLAIN, PAIRS, ROLL>: variant = WIDE << 1 | PLAIN; the rollout form exists for the 16-wave workgroup
+static const void* local_step_fn(int variant, int pairs, bool roll = false)
 {
+    if (roll) {
+        switch (variant) {
+            case 3: return (const void*)step_local_kernel<true, true, 4, true>;
+            case 2: return (const void*)step_local_kernel<true, false, 4, true>;
+            case 1: return (const void*)step_local_kernel<false, true, 4, true>;
+            default: return (const void*)step_local_kernel<false, false, 4, true>;
+        }
+    }
 #define BCP_LOCAL_FN(W, P) (pairs == 4 ? (const void*)step_local_kernel<W, P, 4> : pairs == 2 ? (const void*)step_local_kernel<W, P, 2> \
                                                                                               : (const void*)step_local_kernel<W, P, 1>)
     switch (variant) {
@@ -1673,7 +1681,10 @@ static int local_pairs(const bcp_handle* h)
     return kLocalPairsDefault;
 }
 
-static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hipStream_t s, bool first_only = false)
+// rollout_steps > 1: only the single-launch form (step_local_kernel<.., ROLL = true>) takes several steps per launch; the
+// caller (bcp_rollout) steps the other forms one launch at a time.
+static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hipStream_t s, bool first_only = false,
+                       int32_t rollout_steps = 1)
 {
     if (h->static_dirty) {
         const int rc = upload_step_static(h, s);
@@ -1744,6 +1755,7 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     const bool adapt = h->adaptive && h->adapt && S.pending && S.dense_threshold >= 0;
     a.tick = h->tick;
     a.parked_slots = nullptr;
+    a.rollout_steps = 1;
     a.pending_base = h->pending_count;
     a.adapt_base = adapt ? h->adapt : nullptr;
     const int blocks = (int)((h->n + kBlock - 1) / kBlock);
@@ -1751,9 +1763,11 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
         // the whole step as one launch: 256 envs per workgroup of 16 waves; undecided poses are handed over in LDS and
         // settled by all the workgroup's waves (step_local_kernel)
         const int variant = (S.wide ? 2 : 0) | (step_is_plain(h) ? 1 : 0);
-        const int pairs = local_pairs(h);
-        const int pslot = pairs == 4 ? 2 : (pairs == 2 ? 1 : 0);
-        const void* fn = local_step_fn(variant, pairs);
+        const bool roll = rollout_steps > 1;
+        const int pairs = roll ? 4 : local_pairs(h);
+        const int pslot = roll ? 3 : (pairs == 4 ? 2 : (pairs == 2 ? 1 : 0));
+        const void* fn = local_step_fn(variant, pairs, roll);
+        a.rollout_steps = rollout_steps;
         const int64_t bitmap_words = (int64_t)S.map.rows * S.map.wpr;
         const size_t lds = local_step_lds_bytes(h->params.n_verts, S.lds_path_doubles,
                                                 (S.map.shared && bitmap_words <= kLocalMapWords) ? (int)bitmap_words : 0,
@@ -1762,7 +1776,7 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
         // has asked for stays set (two live handles with different staging sizes would otherwise lower it under each other).
         {
             static std::mutex lds_mutex;
-            static int32_t lds_max[64][4][3];   // [device][variant][workgroup size], zero-initialised
+            static int32_t lds_max[64][4][4];   // [device][variant][workgroup size | rollout form], zero-initialised
             std::lock_guard<std::mutex> lock(lds_mutex);
             int32_t& cur = lds_max[h->device & 63][variant][pslot];
             if ((int32_t)lds > cur) {
@@ -1785,6 +1799,8 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
         a.parked_slots = h->parked_slots;
         void* kargs[] = {(void*)&a};
         HIP_TRY(hipLaunchKernel(fn, grid, block, kargs, lds, s));
+    } else if (rollout_steps > 1) {
+        return fail(BCP_E_STATE, "launch_step: only the single-launch step form takes several steps per launch");
     } else if (S.pending) {
         // kernel 1 settles every env the distance field decides; kernel 2 rasterises the parked rest
         const size_t lds1 = ((size_t)h->params.n_verts * 2 + S.lds_path_doubles) * sizeof(double);
@@ -1896,6 +1912,47 @@ extern "C" int bcp_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, vo
     if (rc != BCP_OK) return rc;
     HIP_TRY(hipGetLastError());
     return step_watchdog(h, (hipStream_t)stream);
+}
+
+// K steps per call for callers that hold the actions of a whole rollout (Monte-Carlo rollouts from one state, the use the
+// reference documents: /root/reference/README.md "many rollouts from one state"; StepEnvRoller's 128-step rollouts once the
+// policy is open-loop).  With the single-launch step form the K steps are ONE launch of step_local_kernel<.., ROLL = true>;
+// otherwise K launches.  Either way: the states and outputs of K calls of bcp_step with row k of the arrays, bit for bit.
+extern "C" int bcp_rollout(bcp_handle* h, const bcp_step_io* io, int32_t n_steps, uint32_t flags, void* stream)
+{
+    int rc = check_step(h, io, flags, "bcp_rollout");
+    if (rc != BCP_OK) return rc;
+    if (n_steps <= 0) return fail(BCP_E_INVALID, "bcp_rollout: n_steps must be positive");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (h->static_dirty) {
+        rc = upload_step_static(h, s);
+        if (rc != BCP_OK) return rc;
+    }
+    const StepStatic& S = h->host_static;
+    const bool fused = S.pending && h->fused && h->adaptive;
+    if (fused && n_steps > 1) {
+        rc = launch_step(h, io, flags, s, false, n_steps);
+        if (rc != BCP_OK) return rc;
+        HIP_TRY(hipGetLastError());
+        return BCP_OK;
+    }
+    const int64_t n = h->n;
+    const size_t act = (flags & BCP_STEP_ACTIONS_F32) ? 8 : 16;
+    for (int32_t k = 0; k < n_steps; ++k) {
+        bcp_step_io row = *io;
+        row.actions = (const char*)io->actions + (size_t)k * n * act;
+        if (io->noise_z) row.noise_z = io->noise_z + (size_t)k * n * 3;
+        if (io->noise_z_out) row.noise_z_out = io->noise_z_out + (size_t)k * n * 3;
+        row.reward = io->reward + (size_t)k * n;
+        row.done = io->done + (size_t)k * n;
+        if (io->collided_now) row.collided_now = io->collided_now + (size_t)k * n;
+        if (io->err) row.err = io->err + (size_t)k * n;
+        rc = launch_step(h, &row, flags, s);
+        if (rc != BCP_OK) return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    return BCP_OK;
 }
 
 extern "C" int bcp_side_stream(bcp_handle* h, int32_t cu_percent, void** stream)

@@ -407,6 +407,16 @@ int bcp_release_mini_worlds(bcp_handle *h, void *stream);
  * ordinary stream.  No counterpart in the reference. */
 int bcp_side_stream(bcp_handle *h, int32_t cu_percent, void **stream);
 
+/* n_steps steps in one call, for callers that hold the actions of a whole rollout (open-loop Monte-Carlo rollouts from one
+ * state, the use the reference documents in its README; no counterpart function in the reference, whose PlanEnv.step takes
+ * one action).  Every array of bcp_step_io has a leading [n_steps] dimension: actions [n_steps][N][2], noise_z /
+ * noise_z_out [n_steps][N][3], reward / done / collided_now / err [n_steps][N]; row k is what the k-th of n_steps calls of
+ * bcp_step would read and write, and the state ends where those calls would leave it -- bit for bit, in-kernel resets and
+ * the on-device noise stream included.  With the single-launch step form (bcp_step_form() == 3) the steps are ONE launch:
+ * the workgroups advance independently and launch, argument fetch and staging are paid once; other forms are stepped one
+ * launch at a time. */
+int bcp_rollout(bcp_handle *h, const bcp_step_io *io, int32_t n_steps, uint32_t flags, void *stream);
+
 /* Health of the step kernel's internal hand-offs.  The single-launch step passes undecided poses between the wavefronts of a
  * workgroup through LDS; every wait on such a hand-off is bounded (~10^7 cycles against the ~2 * 10^4 a step lasts).  A
  * wait that runs into its limit gives up -- the step still finishes; an env whose verdict never arrived is finished as

@@ -12,9 +12,8 @@ env = BatchedPlanEnv(CostMap2D(g['costmap'], res, g['origin']), g['path'], EnvPa
 wrap = (BatchedEgocentricCostmap if len(sys.argv) > 1 else BatchedColoredEgoCostmap)(env)
 rng = np.random.RandomState(0)
 acts = torch.from_numpy(np.stack([env.action_space.sample_batch(n, rng) for _ in range(8)])).cuda()
-env.state.current_iter.copy_(torch.from_numpy(rng.randint(0, 1200, n).astype(np.int32)).cuda())
-for k in range(300):
-    env.step(acts[k % 8])
+import bench
+bench.steady_state(env, acts, rng)   # (random episode phases + one full timeout of pre-roll, as bench.py's legs)
 for k in range(3):
     wrap.observation()
 torch.cuda.synchronize()
@@ -24,6 +23,8 @@ for k in range(20):
     wrap.observation()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
-print("aisle map %s, window %s: %.4f ms -> %.1f GB/s written, lethal fraction %.4f" % (g['costmap'].shape, wrap.image_shape, ms, wrap.images.numel() / ms / 1e6, float((wrap.images == 254).float().mean())))
+print("aisle map %s, window %s: %.4f ms -> %.1f GB/s written, lethal fraction %.4f, %s" % (g['costmap'].shape, wrap.image_shape, ms, wrap.images.numel() / ms / 1e6, float((wrap.images == 254).float().mean()), wrap.route()))
+lit = (wrap.images != 0).flatten(1).sum(1).float()
+print("lit pixels per image: median %d  p90 %d  max %d" % (lit.median(), lit.quantile(0.9), lit.max()))
 ms2 = env.time_steps(acts[0], 50)
 print("step alone %.4f ms" % ms2)
