@@ -1276,7 +1276,7 @@ static int ensure_fields(bcp_handle* h, hipStream_t s)
     if (!h->edt_lazy || !h->cull.edt || !h->edt_stale) return BCP_OK;
     // Has every tiles-only refresh issued so far finished?  Then this pass leaves no stale field behind and later calls can
     // skip their three launches until the next such refresh (which raises the flag again).
-    bool settled = false;
+    bool settled = true;   // (no refresh ever issued: the stale marks come from bcp_set_costmaps, in stream order)
     if (h->refresh_recorded) {
         settled = hipEventQuery(h->refresh_done) == hipSuccess;
         if (!settled) (void)hipGetLastError();   // (hipErrorNotReady)
@@ -1419,7 +1419,14 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
             h->edt_stale_cap = n_maps;
         }
         if (h->edt_stale) HIP_TRY(hipMemsetAsync(h->edt_stale, 0, (size_t)h->edt_stale_cap, s));
-        { const int rc = launch_distance_field(h, all_maps, n_maps, s); if (rc != BCP_OK) return rc; }
+        {
+            // Many private maps under the single-launch step: only the 1-bit tiles are read, so they are made directly from the
+            // lethal masks (near_dilate_kernel) and the uint8 fields are left to whoever asks for them (ensure_fields) -- what a
+            // pool refresh has done since round 3.  65 536 maps of 256 x 256: 75 ms of edt_lds_kernel -> a few ms (round 4).
+            const bool tiles_only = !shared && n_maps >= 32 && h->fused && h->adaptive && C.on && h->near_dilate == 1;
+            const int rc = launch_distance_field(h, all_maps, n_maps, s, tiles_only);
+            if (rc != BCP_OK) return rc;
+        }
         HIP_TRY(hipGetLastError());
         if (!h->pending) {
             const int64_t blocks = (h->n + kBlock - 1) / kBlock;

@@ -332,7 +332,8 @@ def aux_other_configs(device):
     torch.cuda.synchronize()
     rebuild_ms = e0.elapsed_time(e1)
     setup = {"derived_map_data_rebuild_ms": rebuild_ms, "per_map_us": rebuild_ms * 1e3 / n,
-             "what": "bcp_set_costmaps on the resident [N, 256, 256] maps: pack_bitmap_kernel + edt_lds_kernel + near_tiles_kernel"}
+             "what": "bcp_set_costmaps on the resident [N, 256, 256] maps: pack_bitmap_kernel + near_dilate_kernel (1-bit tiles straight from "
+                     "the lethal masks; the uint8 fields follow on demand: round 3 built them here with edt_lds_kernel, 75 ms)"}
     out["c4_aisle_private_maps"] = {
         "what": "BASELINE configs[3]: AisleTurnEnv at 10 m / 256 px, 65536 envs, private costmaps stored uint8 "
                 "[N, 256, 256] (valid 256 x 141, 4 templates x flips) + private 130-point paths, tricycle + noise",
@@ -448,6 +449,24 @@ def aux_measurements(env, pool, n):
                      "frac": img_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "step_plus_observation_ms": ms_both, "env_steps_per_s_with_observation": n / (ms_both * 1e-3)}
     del wrap
+    # K steps per launch for callers that hold a whole rollout's actions (bcp_rollout): NOT the metric -- the metric is
+    # one launch per step, PlanEnv.step's contract
+    k_roll = 128
+    acts = pool[torch.arange(k_roll, device=pool.device) % 16].contiguous()
+    for _ in range(2):
+        env.rollout(acts)
+    e0.record(stream)
+    for _ in range(8):
+        env.rollout(acts)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms_roll = e0.elapsed_time(e1) / (8 * k_roll)
+    out["rollout_128_steps_per_launch"] = {
+        "what": "bcp_rollout: %d steps of the metric workload per call = ONE launch of step_local_kernel<.., ROLL>, the workgroups "
+                "advancing independently (open-loop Monte-Carlo rollouts, the reference's README use case); bit for bit %d calls "
+                "of bcp_step (tests/test_gpu_rollout.py)" % (k_roll, k_roll),
+        "ms_per_step": ms_roll, "env_steps_per_s": n / (ms_roll * 1e-3)}
+    del acts
     # a fresh world per episode: RandomMiniEnv.reset() as a device-side walk through a pool of pre-sampled geometries
     from bc_gym_planning_env_amd import mini_env
     torch.cuda.synchronize()
@@ -706,11 +725,15 @@ def run_rank(args):
             out["cpu_baseline"] = cpu_baseline(g)
         if world == 1 and not args.no_aux:
             try:  # informational only: never let it cost the metric line
-                aux = aux_measurements(env, pool, n)
+                # (the observation legs on the AisleTurn maps come first: measured behind the pool legs -- tens of GB of
+                #  buffers allocated and freed -- the 1.16 GB image buffer of the 133 x 133 window was written 15 x slower,
+                #  3.4 - 4.0 ms per call in three runs against 0.265 - 0.27 ms in every run without that history, whatever
+                #  the kernel version: the mapping of a fresh allocation, not the kernel)
+                aux = aux_ego_aisle(device)
+                aux.update(aux_measurements(env, pool, n))
                 env.close()
                 del env
                 torch.cuda.empty_cache()
-                aux.update(aux_ego_aisle(device))
                 aux.update(aux_other_configs(device))
                 out["aux"] = aux
             except Exception as exc:  # noqa: BLE001
