@@ -2035,15 +2035,10 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
             sc.target = (int)hand_score[2 * kBlock + lane];
         }
         DIAG_STAMP(6);    // mover: reward provider done
-        if (active && !park) {
-            if (!PLAIN) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) q.popped_pose[k] = fifo_stash[k * kLocalEnvs];
-#pragma unroll
-                for (int k = 0; k < 7; ++k) q.popped_state[k] = fifo_stash[(3 + k) * kLocalEnvs];
-            }
-            finalize_env_from<PLAIN>(a, SL, i, q, hit, lds_path, nullptr, !ABLATED(a, kAblateNoReward), sc, my_len, false, out_base);
-        }
+        // (Round 4: the envs are finished in ONE pass at the end, the decided ones together with the parked ones.  Rounds 2-3
+        //  finished the decided lanes here and the parked ones behind their verdicts: two passes of the same ~2.5 k-cycle
+        //  latency chain -- stores, the reset loads of lanes whose episode ends -- in the waves that end the step, and two
+        //  inlined copies of finalize_env_from in a kernel larger than the instruction cache.)
     }
     DIAG_STAMP_W(kWHelper1, 9);   // helper: past the second barrier
     const double vqx = lane < P.n_verts ? qv[2 * lane] : 0.0, vqy = lane < P.n_verts ? qv[2 * lane + 1] : 0.0;   // (row-by-row fallback)
@@ -2112,7 +2107,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
     }
     // (7) movers: the envs they parked are finished by the lane that holds their state, as soon as the verdicts are in
     //     (every parked pose has been claimed by now -- by this wave or by one that is working on it)
-    if (mover && __ballot(park)) {
+    if (mover) {
         int verdict = park ? 0 : 1;
         {
             int trips = 0;
@@ -2147,13 +2142,14 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
                 if (lane == src) last_hit = found;
             }
         }
-        if (park) {
-            bool fits = hit_score && verdict == 2;
+        if (active) {
+            const bool hit_now = park && verdict == 2;
+            bool fits = hit_score && hit_now;
             if (fits) {
                 sc.min_dist = q.min_dist;
                 sc.target = q.target;
                 sc.rew = reward_from_last(P, lds_path, my_len, last_hit, q.old.x, q.old.y, sc.min_dist, sc.target);
-            } else if (PLAIN && verdict == 2 && my_rec->spec_ok) {   // (private path: worked out ahead, see above)
+            } else if (PLAIN && hit_now && my_rec->spec_ok) {   // (private path: worked out ahead, see above)
                 sc.rew = my_rec->spec_rew;
                 sc.min_dist = my_rec->spec_min;
                 sc.target = my_rec->spec_target;
@@ -2165,7 +2161,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
 #pragma unroll
                 for (int k = 0; k < 7; ++k) q.popped_state[k] = fifo_stash[(3 + k) * kLocalEnvs];
             }
-            finalize_env_from<PLAIN>(a, SL, i, q, verdict == 2, lds_path, nullptr, !ABLATED(a, kAblateNoReward), sc, my_len, fits, out_base);
+            finalize_env_from<PLAIN>(a, SL, i, q, hit_now, lds_path, nullptr, !ABLATED(a, kAblateNoReward), sc, my_len, fits, out_base);
         }
     }
     DIAG_STAMP(13);            // mover: out of tickets

@@ -104,6 +104,7 @@ struct bcp_handle {
     bool ego_cells_refused;   // allocation failed once: the sampling kernels serve this handle
     int32_t ego_cells_max;    // host copy of the maximum count, -1 = not fetched since the last (re)build
     int32_t ego_sparse;       // BCP_TUNE_EGO_SPARSE: 0 never, 1 cost model, >= 2 explicit limit of cells per map
+    int32_t ego_stride;       // BCP_TUNE_EGO_LIST_STRIDE: 0 = lists sized from the counts, else this many cells per entry (tests)
     int32_t ego_route[4];     // what the last bcp_egocentric_costmaps call ran: kernel, largest count, list stride, limit
     // watchdog of the step kernel's bounded waits: every kWatchdogSteps calls bcp_step copies tick[4] to pinned host memory
     // behind the step (no synchronisation) and a later call looks at what arrived
@@ -1157,6 +1158,11 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
             if (value < 0) return fail(BCP_E_INVALID, "bcp_set_tuning: BCP_TUNE_EGO_SPARSE takes 0, 1 or a limit of cells per map");
             if (value != h->ego_sparse) h->ego_cells_built = false;   // (the lists are sized for the limit in force)
             h->ego_sparse = value;
+            return BCP_OK;
+        case BCP_TUNE_EGO_LIST_STRIDE:
+            if (value < 0 || (value & 63)) return fail(BCP_E_INVALID, "bcp_set_tuning: BCP_TUNE_EGO_LIST_STRIDE takes 0 or a multiple of 64");
+            if (value != h->ego_stride) h->ego_cells_built = false;
+            h->ego_stride = value;
             return BCP_OK;
         case BCP_TUNE_FUSED:
             h->fused = value ? 1 : 0;
@@ -2444,6 +2450,7 @@ extern "C" int bcp_egocentric_costmaps(bcp_handle* h, const double* poses, int64
                 int64_t cap = std::max<int64_t>(kEgoCellCapMin, ((int64_t)h->ego_cells_max + 63) & ~(int64_t)63);
                 const int64_t budget = (int64_t)1 << 30;   // bytes of lists per handle
                 if (entries * cap * 4 > budget) cap = ((int64_t)h->ego_cells_max + 63) & ~(int64_t)63;
+                if (h->ego_stride > 0) cap = h->ego_stride;   // (tests: entries with more cells than this are drawn pixel by pixel)
                 if (cap > 0 && entries * cap * 4 <= budget &&
                     hipMalloc((void**)&h->ego_cells, (size_t)entries * cap * sizeof(uint32_t)) == hipSuccess) {
                     h->ego_cell_cap = (int32_t)cap;

@@ -186,9 +186,14 @@ int bcp_seed(bcp_handle *h, uint64_t seed);
  *                             2 = 8 wavefronts / 128 envs (two per CU), 1 = 4 wavefronts / 64 envs (four per CU); 0 (default)
  *                             = the library's choice for the configuration.  Same results bit for bit in every size.
  *                             (The environment variable BCP_LOCAL_PAIRS = 1 | 2 | 4, read by bcp_create, sets this knob's
- *                             initial value for every handle of the process: the whole test suite runs under each size.) */
+ *                             initial value for every handle of the process: the whole test suite runs under each size.)
+ *   BCP_TUNE_EGO_LIST_STRIDE  0 (default) = the cell lists of the sparse egocentric route are sized from the counted cells;
+ *                             a multiple of 64 = this many cells per map entry: an entry with more is drawn pixel by pixel
+ *                             inside the same launch (what happens to a pool entry that is re-sampled with more cells than
+ *                             the lists were sized for; the knob lets tests reach that path) */
 enum { BCP_TUNE_EXACT_MODE = 0, BCP_TUNE_DENSE_THRESHOLD = 1, BCP_TUNE_CULL = 2, BCP_TUNE_DEFER = 3, BCP_TUNE_EDT_LDS = 4,
-       BCP_TUNE_FUSED = 5, BCP_TUNE_EGO_SPARSE = 6, BCP_TUNE_NEAR_DILATE = 7, BCP_TUNE_LOCAL_PAIRS = 8 };
+       BCP_TUNE_FUSED = 5, BCP_TUNE_EGO_SPARSE = 6, BCP_TUNE_NEAR_DILATE = 7, BCP_TUNE_LOCAL_PAIRS = 8,
+       BCP_TUNE_EGO_LIST_STRIDE = 9 };
 int bcp_set_tuning(bcp_handle *h, int32_t key, int32_t value);
 
 /* ---- static per-episode inputs ------------------------------------------------------------------------ */

@@ -300,6 +300,47 @@ def test_sparse_maps_fill_and_patch_vs_oracle(torch_cuda, oracle, kind, cells):
             assert (oracle.extract_egocentric(dense, orgs[0], res, poses[i], o, s, 0) == got[i]).all()
 
 
+def test_entry_with_more_cells_than_its_list_is_drawn_pixel_by_pixel(torch_cuda, oracle):
+    """a map entry whose non-zero cells do not fit its list (a pool entry re-sampled with more cells than the
+    lists were sized for) is drawn inside the same launch, pixel by pixel (ego_image_slow), the other entries from their
+    lists.  BCP_TUNE_EGO_LIST_STRIDE pins the lists at 128 cells; one of three private maps has ~700."""
+    torch = torch_cuda
+    import ctypes as C
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams, _lib
+    rng = np.random.RandomState(11)
+    res, n = 0.05, 96
+    shapes = [(90, 70), (64, 101), (120, 120)]
+    maps = []
+    for k, shp in enumerate(shapes):
+        m = np.zeros(shp, dtype=np.uint8)
+        cells = 60 if k < 2 else 700
+        m[rng.randint(0, shp[0], cells), rng.randint(0, shp[1], cells)] = rng.randint(1, 256, cells)
+        maps.append(m)
+    orgs = [rng.uniform(-2, 0, 2) for _ in shapes]
+    path = np.array([[0., 0., 0.], [1., 0., 0.], [2., 0., 0.]])
+    env = BatchedPlanEnv([CostMap2D(maps[i % 3], res, orgs[i % 3]) for i in range(n)], [path] * n,
+                         EnvParams(resolution=res, refine_path=False), n_envs=n)
+    env.set_tuning(ego_sparse=4096, ego_list_stride=128)
+    poses = np.stack([rng.uniform(-1, 5, n), rng.uniform(-1, 5, n), rng.uniform(-7, 7, n)], axis=1)
+    pt = torch.from_numpy(poses).cuda()
+    f64p = C.POINTER(C.c_double)
+    o, s = np.array((-0.5, -2.0)), np.array((3.5, 4.0))
+    shape = (C.c_int32 * 2)()
+    _lib.check(env._lib.bcp_egocentric_shape(env._h, s.ctypes.data_as(f64p), shape))
+    out = torch.full((n, shape[0], shape[1]), 99, dtype=torch.uint8, device="cuda")
+    _lib.check(env._lib.bcp_egocentric_costmaps(env._h, pt.data_ptr(), n, o.ctypes.data_as(f64p), s.ctypes.data_as(f64p), 0,
+                                                out.data_ptr(), None))
+    kernel, counted, stride, _limit = _route(env)
+    assert kernel == "ego_sparse_kernel" and stride == 128 and counted > 500
+    got = out.cpu().numpy()
+    lit = 0
+    for i in range(n):
+        ref = oracle.extract_egocentric(maps[i % 3], orgs[i % 3], res, poses[i], o, s, 0)
+        assert (ref == got[i]).all(), i
+        lit += int((ref != 0).sum()) if i % 3 == 2 else 0
+    assert lit > 300
+
+
 def test_sparse_window_overflow_streams_the_list(torch_cuda, oracle):
     """More cells inside one window than a wave holds back in LDS (kEgoHeld = 256): the wave streams the list behind the
     fill instead.  A filled 40 x 40 block under the robot."""

@@ -1,0 +1,7 @@
+#!/bin/bash
+O=gpurun_out/r4r; mkdir -p $O; rm -f $O/*
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_c4_full.py tests/test_gpu_delays.py tests/test_gpu_pool.py tests/test_gpu_rollout.py tests/test_gpu_egocentric.py tests/test_gpu_errors.py -m gpu -x -q --timeout 300 > $O/tests.log 2>&1; echo "tests rc=$?" > $O/rc.txt
+if grep -q "Memory access fault" $O/tests.log; then echo FAULT; tail -n 20 $O/tests.log; exit 1; fi
+for rep in 1 2; do for lib in tools/libbcplan_base.so -; do python tools/step_time.py $lib 2>&1 | grep n=65536 >> $O/step_time.txt; done; done
+for lib in tools/libbcplan_base.so bc_gym_planning_env_amd/libbcplan.so; do BCP_LIB=$lib python tools/bench_configs.py 2>&1 | grep -v amdgpu >> $O/configs.txt; done
+cat $O/rc.txt; tail -n 3 $O/tests.log; cat $O/step_time.txt $O/configs.txt

@@ -13,7 +13,7 @@ cd $GRAFT_REPO_ROOT
 KEEP='^"Name"|step_|ego_|goal_n|mini_world|edt_|pack_bitmap|path_|calib_'
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/step_trace -o p -- python3 bench.py --no-cpu-baseline --no-aux > gpurun_out/step_trace.log 2>&1
 grep -E "$KEEP" gpurun_out/step_trace/p_kernel_stats.csv > gpurun_out/step_kernel_stats.csv
-tail -1 gpurun_out/step_trace.log > gpurun_out/step_trace_bench_line.json || true
+grep "^{\"metric" gpurun_out/step_trace.log > gpurun_out/step_trace_bench_line.json || true
 if [ "$1" != "--no-aux" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/aux_trace -o p -- python3 bench.py --no-cpu-baseline > gpurun_out/aux_trace.log 2>&1
   grep -E "$KEEP" gpurun_out/aux_trace/p_kernel_stats.csv > gpurun_out/aux_kernel_stats.csv
