@@ -1778,7 +1778,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
         old_heading.known = true;
         q.err = robot_step_measure(P, r, new_pose, old_heading);
     }
-    bool hit = false, park = false;
+    bool park = false;
     bool poll_expired = false;   // (wave-uniform) one of the bounded waits below gave up
     if (mover) {
         // (3a) collision: distance-field classification; an undecided env is parked below
