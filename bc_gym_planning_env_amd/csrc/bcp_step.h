@@ -37,8 +37,8 @@ struct PathDesc {
     const double* pts;   // [len][5] = x, y, theta, cos(theta), sin(theta); shared or [N][max_len][5]
     const float* pre;    // private paths: [N][max_len][4] = x, y, cos(theta), sin(theta) in float32 -- the prefilter record of
                          // the way-point scan (16 bytes: four way points per 64-byte sector); nullptr for a shared path
-    const double* bbox;  // [kBoxDoubles] per path: xmin, xmax, ymin, ymax of the way points, the bucket grid x0, 1/wx, y0,
-                         // 1/wy, then (private paths) the costmap origin and the path length of the entry -- see kBoxOrigin
+    const double* bbox;  // [kBoxDoubles] per path, one 64-byte record: box of the way points and bucket grid as eight f32,
+                         // then the costmap origin and the path length of the entry as doubles -- see kBoxDoubles
     const int16_t* index; // [2 axes][kPathBuckets][2] = first / last way point index that can be reached from a bucket
     const int32_t* lens;
     int32_t max_len, shared;
@@ -257,11 +257,30 @@ __global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restr
 }
 
 constexpr int kPathBuckets = 64;
-// One 128-byte record per path entry.  With private paths an env needs a handful of small per-entry values every step --
-// bounding box, costmap origin, path length -- that would each cost a memory sector of their own: they share a line.
-constexpr int kBoxDoubles = 16;
-constexpr int kBoxOrigin = 8;   // [8], [9]: origin of the entry's costmap (world_record_kernel)
-constexpr int kBoxLen = 10;     // [10]: number of way points, as a double
+// One 64-byte record per path entry -- one memory sector.  With private paths an env needs a handful of small per-entry
+// values every step that would each cost a sector of their own, so they share one:
+//   floats  [0..3]  xmin, xmax, ymin, ymax of the way points, rounded OUTWARD to f32 (the box only ever prunes: a wider one
+//                   hands a few more poses to the bucket tables, whose windows the exact test then walks)
+//   floats  [4..7]  the bucket grid x0, 1/wx, y0, 1/wy, as f32 (the tables are built from these very values, below, so a
+//                   look-up and the table it reads agree whatever their rounding)
+//   doubles [4],[5] origin of the entry's costmap (world_record_kernel)
+//   double  [6]     number of way points, as a double;  [7] spare
+// (two sectors until round 4: box and grid as doubles in the first, origin and length in the second)
+constexpr int kBoxDoubles = 8;
+constexpr int kBoxOrigin = 4;
+constexpr int kBoxLen = 6;
+
+__device__ __forceinline__ float f32_below(double v)
+{
+    float f = (float)v;
+    return (double)f > v ? nextafterf(f, -INFINITY) : f;
+}
+
+__device__ __forceinline__ float f32_above(double v)
+{
+    float f = (float)v;
+    return (double)f < v ? nextafterf(f, INFINITY) : f;
+}
 
 // Per path: bounding box of the way points and a 1-D bucket grid per axis over [min - sp, max + sp].
 __device__ __forceinline__ void path_bbox_one(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
@@ -276,17 +295,17 @@ __device__ __forceinline__ void path_bbox_one(const double* __restrict__ xyt, co
         y0 = fmin(y0, q[3 * j + 1]);
         y1 = fmax(y1, q[3 * j + 1]);
     }
-    double* o = bbox + kBoxDoubles * p;
-    o[0] = x0;
-    o[1] = x1;
-    o[2] = y0;
-    o[3] = y1;
+    float* o = reinterpret_cast<float*>(bbox + kBoxDoubles * p);
+    o[0] = f32_below(x0);
+    o[1] = f32_above(x1);
+    o[2] = f32_below(y0);
+    o[3] = f32_above(y1);
     const double wx = fmax((x1 - x0 + 2.0 * sp_prune) / kPathBuckets, 1e-9);
     const double wy = fmax((y1 - y0 + 2.0 * sp_prune) / kPathBuckets, 1e-9);
-    o[4] = x0 - sp_prune;
-    o[5] = 1.0 / wx;
-    o[6] = y0 - sp_prune;
-    o[7] = 1.0 / wy;
+    o[4] = (float)(x0 - sp_prune);
+    o[5] = (float)(1.0 / wx);
+    o[6] = (float)(y0 - sp_prune);
+    o[7] = (float)(1.0 / wy);
 }
 
 __global__ void path_bbox_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
@@ -323,7 +342,8 @@ __device__ __forceinline__ void path_index_one(const double* __restrict__ xyt, c
     const int64_t p = t / (2 * kPathBuckets);
     const int m = lens ? lens[p] : max_len;
     const double* q = xyt + p * (int64_t)max_len * 3;
-    const double o = bbox[kBoxDoubles * p + 4 + 2 * axis], w = 1.0 / bbox[kBoxDoubles * p + 5 + 2 * axis];
+    const float* grid = reinterpret_cast<const float*>(bbox + kBoxDoubles * p) + 4;
+    const double o = (double)grid[2 * axis], w = 1.0 / (double)grid[2 * axis + 1];
     const double guard = 1e-6 * w + 1e-12;
     const double lo = o + b * w - sp_prune - guard, hi = o + (b + 1) * w + sp_prune + guard;
     int first = 32767, last = -1;
@@ -357,16 +377,19 @@ struct PathWindow {
     int lo, hi;
 };
 
+// bbox: the eight leading values of a path record -- the f32 words of the record itself, or a copy widened to doubles
+// (the LDS copy of a shared path); either way the arithmetic below is on the same doubles
 template <typename BoxPtr, typename IndexPtr>
 __device__ __forceinline__ PathWindow path_window(const DevParams& P, BoxPtr bbox, IndexPtr index, double x, double y)
 {
     PathWindow w;
     w.lo = 0;
     w.hi = -1;
-    if (x < bbox[0] - P.sp_prune || x > bbox[1] + P.sp_prune || y < bbox[2] - P.sp_prune || y > bbox[3] + P.sp_prune)
+    if (x < (double)bbox[0] - P.sp_prune || x > (double)bbox[1] + P.sp_prune || y < (double)bbox[2] - P.sp_prune ||
+        y > (double)bbox[3] + P.sp_prune)
         return w;  // farther than spatial_precision from the bounding box of the whole path
-    const int bx = min(max((int)floor((x - bbox[4]) * bbox[5]), 0), kPathBuckets - 1);
-    const int by = min(max((int)floor((y - bbox[6]) * bbox[7]), 0), kPathBuckets - 1);
+    const int bx = min(max((int)floor((x - (double)bbox[4]) * (double)bbox[5]), 0), kPathBuckets - 1);
+    const int by = min(max((int)floor((y - (double)bbox[6]) * (double)bbox[7]), 0), kPathBuckets - 1);
     const IndexPtr ix = index + 2 * bx;
     const IndexPtr iy = index + 2 * (kPathBuckets + by);
     w.lo = max((int)ix[0], (int)iy[0]);
@@ -902,7 +925,7 @@ __device__ __forceinline__ void finalize_env_from(const A& a, SP S, int64_t i, P
             target = score.target;
         } else if (!ABLATED(a, kAblateNoReward)) {
             // way-point window of the pose: the caller may have looked it up already for the un-rolled-back pose
-            const double* bbox = S->path.bbox + (S->path.shared ? 0 : g * kBoxDoubles);
+            const float* bbox = reinterpret_cast<const float*>(S->path.bbox + (S->path.shared ? 0 : g * kBoxDoubles));
             const int16_t* index = S->path.index + (S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
             const PathWindow w =
                 (free_window && !hit && !pose_delay) ? *free_window : path_window(P, bbox, index, seen[0], seen[1]);
@@ -1136,18 +1159,18 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
     // the scorer also brings the bounding box and the bucket index of a shared path into LDS while the mover is busy
     // with the robot model (its window look-up then needs no global round trip); a private path's box is fetched now
     // as well -- it does not depend on the pose
-    double box[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float box[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t index_words[2] = {0, 0};
     if (!mover) {
         if (a.hot.path_shared) {
-            if (lane < 8) box[0] = a.hot.path_bbox[lane];
+            if (lane < 8) box[0] = reinterpret_cast<const float*>(a.hot.path_bbox)[lane];
             const uint32_t* iw = reinterpret_cast<const uint32_t*>(a.hot.path_index);   // [2][kPathBuckets][2] int16
             index_words[0] = iw[lane];
             index_words[1] = iw[kBlock + lane];
         } else {
             const int64_t g = a.hot.geom_of_env ? (int64_t)q.geom : i;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) box[k] = a.hot.path_bbox[g * kBoxDoubles + k];
+            for (int k = 0; k < 8; ++k) box[k] = reinterpret_cast<const float*>(a.hot.path_bbox + g * kBoxDoubles)[k];
         }
     }
     if (tid < nq) qv[tid] = my_q;
@@ -1163,7 +1186,7 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
     __attribute__((address_space(3))) double* lds_box = hand_score + 3 * kBlock;                    // [8]
     __attribute__((address_space(3))) uint32_t* lds_index = (__attribute__((address_space(3))) uint32_t*)(lds_box + 8);  // [128]
     if (!mover && a.hot.path_shared) {
-        if (lane < 8) lds_box[lane] = box[0];
+        if (lane < 8) lds_box[lane] = (double)box[0];
         lds_index[lane] = index_words[0];
         lds_index[kBlock + lane] = index_words[1];
     }
@@ -1583,7 +1606,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
     //     helper that takes its cos / sin
     Pending q;
     double cmd0 = 0.0, cmd1 = 0.0;
-    double box[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float box[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (a private path's box and bucket grid: the f32 words of its record)
     double old_angle = 0.0;
     double own_org_x = 0.0, own_org_y = 0.0, own_len = 0.0;   // (only ever written by the loads below: a later assignment
                                                                //  to a register a load is in flight to would wait for it)
@@ -1609,7 +1632,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
             if (!hot_path_shared) {
                 const int64_t g = L.hot.geom_of_env ? (int64_t)q.geom : i;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) box[k] = as_global(L.hot.path_bbox)[g * kBoxDoubles + k];
+                for (int k = 0; k < 8; ++k) box[k] = as_global(reinterpret_cast<const float*>(L.hot.path_bbox + g * kBoxDoubles))[k];
                 own_len = as_global(L.hot.path_bbox)[g * kBoxDoubles + kBoxLen];
             }
         }
@@ -1741,13 +1764,14 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
         constexpr int kBoxAt = kStagers >= 448 ? 256 : kStagers - 8;              // who fetches the path's box (8 doubles) ...
         constexpr int kIndexAt = kStagers >= 448 ? 320 : kStagers - 136;          // ... and its bucket index (128 words)
         const int nm = tid - kLocalPairs * kBlock;
-        double st_q = 0.0, st_path = 0.0, st_box = 0.0;
+        double st_q = 0.0, st_path = 0.0;
+        float st_box = 0.0f;
         uint32_t st_index = 0;
         uint32_t st_map[kMapPerStager] = {};
         if (nm < nq) st_q = as_global(L.hot.qverts)[nm];
         if (nm < npath) st_path = as_global(L.hot.path_pts)[nm];
         if (hot_path_shared) {
-            if (nm >= kBoxAt && nm < kBoxAt + 8) st_box = as_global(L.hot.path_bbox)[nm - kBoxAt];
+            if (nm >= kBoxAt && nm < kBoxAt + 8) st_box = as_global(reinterpret_cast<const float*>(L.hot.path_bbox))[nm - kBoxAt];
             if (nm >= kIndexAt && nm < kIndexAt + 128) st_index = as_global(reinterpret_cast<const uint32_t*>(L.hot.path_index))[nm - kIndexAt];
         }
 #pragma unroll
@@ -1759,7 +1783,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
         if (nm < npath) qv[nq + nm] = st_path;
         for (int k = kStagers + nm; k < npath; k += kStagers) qv[nq + k] = as_global(L.hot.path_pts)[k];   // (long paths)
         if (hot_path_shared) {
-            if (nm >= kBoxAt && nm < kBoxAt + 8) lds_box[nm - kBoxAt] = st_box;
+            if (nm >= kBoxAt && nm < kBoxAt + 8) lds_box[nm - kBoxAt] = (double)st_box;
             if (nm >= kIndexAt && nm < kIndexAt + 128) lds_index[nm - kIndexAt] = st_index;
         }
 #pragma unroll
@@ -1913,7 +1937,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
                 part.lo = max(lo, part.hi - third + 1);
                 if (a.hot.path_pre) {
                     // (private paths: float32 prefilter records; `reach` = largest coordinate magnitude of this path's box)
-                    const double reach = fmax(fmax(fabs(box[0]), fabs(box[1])), fmax(fabs(box[2]), fabs(box[3]))) + P.sp;
+                    const double reach = (double)fmaxf(fmaxf(fabsf(box[0]), fabsf(box[1])), fmaxf(fabsf(box[2]), fabsf(box[3]))) + P.sp;
                     last = last_reached_prefiltered(P, gpath, a.hot.path_pre + g * (int64_t)a.hot.path_max_len * 4, part, m,
                                                     q.target, x, y, th, reach);
                 } else {
@@ -1983,13 +2007,13 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
         // reward out now for every pose it parked; the verdict then only picks between two finished results.
         if (PLAIN && !lds_path && !hot_path_shared && a.hot.path_pre && park && !ABLATED(a, kAblateNoReward)) {
             const int64_t g = slot_of(SL, i, q);
-            const GlobalPtr<const double> bx = as_global(L.hot.path_bbox) + g * kBoxDoubles;
-            double obox[8];
+            const GlobalPtr<const float> bx = as_global(reinterpret_cast<const float*>(L.hot.path_bbox + g * kBoxDoubles));
+            float obox[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) obox[k] = bx[k];
             const PathWindow ow = path_window(P, obox, SL->path.index + g * (int64_t)(4 * kPathBuckets), q.old.x, q.old.y);
             const double* opath = SL->path.pts + g * (int64_t)SL->path.max_len * 5;
-            const double reach = fmax(fmax(fabs(obox[0]), fabs(obox[1])), fmax(fabs(obox[2]), fabs(obox[3]))) + P.sp;
+            const double reach = (double)fmaxf(fmaxf(fabsf(obox[0]), fabsf(obox[1])), fmaxf(fabsf(obox[2]), fabsf(obox[3]))) + P.sp;
             const int olast = last_reached_prefiltered(P, opath, a.hot.path_pre + g * (int64_t)a.hot.path_max_len * 4, ow, my_len,
                                                        q.target, q.old.x, q.old.y, q.old.th, reach);
             double omin = q.min_dist;

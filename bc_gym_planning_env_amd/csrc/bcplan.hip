@@ -765,7 +765,7 @@ __global__ void reward_kernel(const StepStatic* __restrict__ S, const double* __
         rew = reward_pure_pursuit(pts, m, x, y, collided && collided[i], min_dist, target);
         reached = hypot(pts[5 * (m - 1)] - x, pts[5 * (m - 1) + 1] - y) < 1.0;   // reward.py:141-150
     } else {
-        const PathWindow w = path_window(P, S->path.bbox + g * kBoxDoubles, S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+        const PathWindow w = path_window(P, reinterpret_cast<const float*>(S->path.bbox + g * kBoxDoubles), S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
         rew = reward_step(P, pts, w, m, x, y, th, min_dist, target);
         reached = target > m - 1;                                                 // reward.py:66-69
     }
@@ -787,7 +787,7 @@ __global__ void find_last_reached_kernel(const StepStatic* __restrict__ S, const
     const double* pts = S->path.pts + g * (int64_t)S->path.max_len * 5;
     const int m = S->path.shared ? S->path.max_len : S->path.lens[g];
     const double x = poses[3 * i], y = poses[3 * i + 1], th = poses[3 * i + 2];
-    const PathWindow w = path_window(S->P, S->path.bbox + g * kBoxDoubles, S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+    const PathWindow w = path_window(S->P, reinterpret_cast<const float*>(S->path.bbox + g * kBoxDoubles), S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
     out[i] = last_reached_from(S->P, pts, w, m, 0, x, y, th);
 }
 
