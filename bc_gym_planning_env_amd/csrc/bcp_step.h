@@ -35,7 +35,8 @@ struct MapDesc {
 
 struct PathDesc {
     const double* pts;   // [len][5] = x, y, theta, cos(theta), sin(theta); shared or [N][max_len][5]
-    const float* pre;    // private paths: [N][max_len][4] = x, y, cos(theta), sin(theta) in float32 -- the prefilter record of
+    const uint32_t* pre; // private paths: [N][max_len][2] = x, y (uint16 each, in steps from the box corner) and cos, sin of theta
+                         // (int16, / 32767) -- the 8-byte prefilter record of
                          // the way-point scan (16 bytes: four way points per 64-byte sector); nullptr for a shared path
     const double* bbox;  // [kBoxDoubles] per path, one 64-byte record: box of the way points and bucket grid as eight f32,
                          // then the costmap origin and the path length of the entry as doubles -- see kBoxDoubles
@@ -77,7 +78,7 @@ struct StepHot {
     int64_t env_id_base;
     int32_t* geom_of_env;
     const double* path_pts;
-    const float* path_pre;
+    const uint32_t* path_pre;
     const double* path_bbox;
     const int16_t* path_index;
     const uint32_t* map_bits;
@@ -233,9 +234,29 @@ __global__ void pack_bitmap_kernel(const uint8_t* __restrict__ data, uint32_t* _
     }
 }
 
+constexpr int kPathBuckets = 64;
+// One 64-byte record per path entry -- one memory sector.  With private paths an env needs a handful of small per-entry
+// values every step that would each cost a sector of their own, so they share one:
+//   floats  [0..3]  xmin, xmax, ymin, ymax of the way points, rounded OUTWARD to f32 (the box only ever prunes: a wider one
+//                   hands a few more poses to the bucket tables, whose windows the exact test then walks)
+//   floats  [4..7]  the bucket grid x0, 1/wx, y0, 1/wy, as f32 (the tables are built from these very values, below, so a
+//                   look-up and the table it reads agree whatever their rounding)
+//   doubles [4],[5] origin of the entry's costmap (world_record_kernel)
+//   double  [6]     number of way points, as a double
+//   floats  [14],[15] step of the quantised prefilter records (path_trig_kernel) and its reciprocal
+// (two sectors until round 4: box and grid as doubles in the first, origin and length in the second)
+constexpr int kBoxDoubles = 8;
+constexpr int kBoxOrigin = 4;
+constexpr int kBoxLen = 6;
+constexpr int kBoxQuantStep = 14;    // (float index)
+constexpr int kQuantSteps = 65000;   // the longer side of the box in steps (uint16 coordinates)
+constexpr int kQuantReach = 16384;   // spatial precision in steps, at most: poses the window lets through stay below 2^17 steps
+
 // path [.,3] -> [.,5] with cos/sin of the heading (utilities/path_tools.py:405)
-__global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restrict__ out, float* __restrict__ pre,
-                                 EntrySelect sel, int max_len)
+// (pre: the quantised prefilter record of private paths, last_reached_prefiltered -- needs the entry's record, `bbox`,
+//  which path_bbox_kernel writes: launched behind it)
+__global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restrict__ out, uint32_t* __restrict__ pre,
+                                 const double* __restrict__ bbox, EntrySelect sel, int max_len)
 {
     const int64_t total = sel.size() * max_len;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
@@ -247,28 +268,17 @@ __global__ void path_trig_kernel(const double* __restrict__ xyt, double* __restr
         const double c = cos(th), sn = sin(th);
         out[5 * i + 3] = c;
         out[5 * i + 4] = sn;
-        if (pre) {   // (private paths: the float32 prefilter record, last_reached_prefiltered)
-            pre[4 * i + 0] = (float)xyt[3 * i + 0];
-            pre[4 * i + 1] = (float)xyt[3 * i + 1];
-            pre[4 * i + 2] = (float)c;
-            pre[4 * i + 3] = (float)sn;
+        if (pre) {
+            const float* rec = reinterpret_cast<const float*>(bbox + (i / max_len) * kBoxDoubles);
+            const double ox = (double)rec[0], oy = (double)rec[2], step = (double)rec[kBoxQuantStep];
+            const uint32_t qx = (uint32_t)fmin(fmax(rint((xyt[3 * i + 0] - ox) / step), 0.0), 65535.0);
+            const uint32_t qy = (uint32_t)fmin(fmax(rint((xyt[3 * i + 1] - oy) / step), 0.0), 65535.0);
+            const int32_t qc = (int32_t)rint(c * 32767.0), qs = (int32_t)rint(sn * 32767.0);
+            pre[2 * i + 0] = qx | (qy << 16);
+            pre[2 * i + 1] = ((uint32_t)qc & 0xFFFFu) | ((uint32_t)qs << 16);
         }
     }
 }
-
-constexpr int kPathBuckets = 64;
-// One 64-byte record per path entry -- one memory sector.  With private paths an env needs a handful of small per-entry
-// values every step that would each cost a sector of their own, so they share one:
-//   floats  [0..3]  xmin, xmax, ymin, ymax of the way points, rounded OUTWARD to f32 (the box only ever prunes: a wider one
-//                   hands a few more poses to the bucket tables, whose windows the exact test then walks)
-//   floats  [4..7]  the bucket grid x0, 1/wx, y0, 1/wy, as f32 (the tables are built from these very values, below, so a
-//                   look-up and the table it reads agree whatever their rounding)
-//   doubles [4],[5] origin of the entry's costmap (world_record_kernel)
-//   double  [6]     number of way points, as a double;  [7] spare
-// (two sectors until round 4: box and grid as doubles in the first, origin and length in the second)
-constexpr int kBoxDoubles = 8;
-constexpr int kBoxOrigin = 4;
-constexpr int kBoxLen = 6;
 
 __device__ __forceinline__ float f32_below(double v)
 {
@@ -306,6 +316,12 @@ __device__ __forceinline__ void path_bbox_one(const double* __restrict__ xyt, co
     o[5] = (float)(1.0 / wx);
     o[6] = (float)(y0 - sp_prune);
     o[7] = (float)(1.0 / wy);
+    // prefilter records: way points as uint16 steps from the (rounded-down) lower corner of the box
+    double extent = fmax(x1 - (double)o[0], y1 - (double)o[2]);
+    if (!(extent >= 0.0) || extent > 3e38) extent = 0.0;   // (no way points)
+    const float step = (float)fmax(extent / kQuantSteps, sp_prune / kQuantReach);
+    o[kBoxQuantStep] = step;
+    o[kBoxQuantStep + 1] = 1.0f / step;
 }
 
 __global__ void path_bbox_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
@@ -476,34 +492,51 @@ __device__ __forceinline__ int coop_last_reached(const DevParams& P, LdsF64 path
     return -1;
 }
 
-// way points in global memory with the float32 prefilter record of private paths (PathDesc::pre: x, y, cos, sin, 16 bytes):
-// four candidates per trip cost four 16-byte loads out of one or two 64-byte sectors instead of twenty 8-byte loads out
-// of three, and float32 arithmetic; only a candidate the prefilter cannot rule out fetches its float64 record for the
-// exact test.  The prefilter rejects on position and on the "not behind the way point" condition with a guard `g` that
-// covers everything float32 can get wrong on coordinates up to `reach` in magnitude (conversion of both points 2^-24
-// relative each, the difference, two products and a sum: < 5e-7 (reach + sp); g = 2e-6 (reach + 1)), so whatever it
-// rejects fails the float64 test too -- the result is the exact scan's, bit for bit.
+// way points in global memory with the quantised prefilter record of private paths (PathDesc::pre, 8 bytes: x, y as uint16
+// steps from the corner of the path's box, cos / sin of the heading as int16 / 32767; path_trig_kernel): eight candidates per
+// trip cost eight 8-byte loads out of one or two 64-byte sectors (float32 records of 16 bytes until round 4: four per trip
+// out of the same sectors; float64 before that: twenty 8-byte loads out of three per four candidates), and float32
+// arithmetic; only a candidate the prefilter cannot rule out fetches its float64 record for the exact test.
+// The prefilter works in steps: xr = (x - corner) / step is below 2^17 in magnitude for every pose whose window is not empty
+// (the box test of path_window, step >= sp_prune / kQuantReach), so xr as a float32 is good to 2^-8 step and qx - xr to as much again;
+// the reciprocal of the step as float32 adds 6e-8 * 2^17 < 0.01 step, the way point's own rounding 0.5: each coordinate
+// difference is within 0.52 step of the true one, the distance within 0.74 -- the position limits carry +1.  "Not behind the
+// way point" (path_tools.py:405): cos and sin are off by 1.53e-5 each, times a difference of at most kQuantReach + 1 steps =
+// 0.25 step per term, plus 0.52 (|cos| + |sin|) <= 0.74 for the differences and ~0.002 of float32 rounding: below 1.3 -- the
+// limit carries -2.  So whatever the prefilter rejects fails the float64 test too: the result is the exact scan's, bit for bit.
+#ifndef BCP_PREFILTER_TRIP
+#define BCP_PREFILTER_TRIP 8
+#endif
 __device__ __forceinline__ int last_reached_prefiltered(const DevParams& P, const double* __restrict__ path,
-                                                        const float* __restrict__ pre, PathWindow w, int m, int target,
-                                                        double x, double y, double th, double reach)
+                                                        const uint32_t* __restrict__ pre, PathWindow w, int m, int target,
+                                                        double x, double y, double th, double ox, double oy, float inv_step)
 {
     if (target > m - 1) return -1;
     const int lo = max(w.lo, target);
     const int hi = min(w.hi, m - 1);
-    const float g = 2e-6f * ((float)reach + 1.0f);
-    const float xf = (float)x, yf = (float)y, spg = (float)P.sp + g, par_min = (float)P.par_thr - g;
-    const float q_max = spg * spg * 1.000001f;
-    for (int j = hi; j >= lo; j -= 4) {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        f32x4 p[4];
+    const double inv = (double)inv_step;
+    const float xr = (float)((x - ox) * inv), yr = (float)((y - oy) * inv);
+    const float lim = (float)(P.sp * inv) + 1.0f, par_min = (float)(P.par_thr * inv) - 2.0f;
+    const float q_max = lim * lim * 1.000001f;
+    constexpr int TRIP = BCP_PREFILTER_TRIP;
+    for (int j = hi; j >= lo; j -= TRIP) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 p[TRIP];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] = as_global(reinterpret_cast<const f32x4*>(pre))[max(j - u, lo)];   // (below lo: a repeat of lo)
+        for (int u = 0; u < TRIP; ++u) p[u] = as_global(reinterpret_cast<const u32x2*>(pre))[max(j - u, lo)];   // (below lo: a repeat of lo)
+        // the candidates the prefilter lets through, as a bit mask (straight-line code), then the exact test from the top
+        uint32_t maybe = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (j - u < lo) break;
-            const float dx = p[u].x - xf, dy = p[u].y - yf;
-            const float par = p[u].z * (xf - p[u].x) + p[u].w * (yf - p[u].y);
-            if (fabsf(dx) > spg || fabsf(dy) > spg || dx * dx + dy * dy > q_max || par < par_min) continue;
+        for (int u = 0; u < TRIP; ++u) {
+            const float dx = (float)(p[u].x & 0xFFFFu) - xr, dy = (float)(p[u].x >> 16) - yr;
+            const float qc = (float)(int16_t)(p[u].y & 0xFFFFu), qs = (float)((int32_t)p[u].y >> 16);
+            const float par = -(qc * dx + qs * dy) * (1.0f / 32767.0f);
+            const bool out = fabsf(dx) > lim || fabsf(dy) > lim || dx * dx + dy * dy > q_max || par < par_min || j - u < lo;
+            maybe |= (uint32_t)!out << u;
+        }
+        while (maybe) {
+            const int u = (int)__builtin_ctz(maybe);
+            maybe &= maybe - 1;
             const double* s = path + 5 * (j - u);
             if (way_point_reached(P, s[0], s[1], s[2], s[3], s[4], x, y, th)) return j - u;
         }
@@ -1607,6 +1640,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
     Pending q;
     double cmd0 = 0.0, cmd1 = 0.0;
     float box[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (a private path's box and bucket grid: the f32 words of its record)
+    float quant_inv = 0.0f;                    // (... and the reciprocal step of its prefilter records)
     double old_angle = 0.0;
     double own_org_x = 0.0, own_org_y = 0.0, own_len = 0.0;   // (only ever written by the loads below: a later assignment
                                                                //  to a register a load is in flight to would wait for it)
@@ -1633,6 +1667,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
                 const int64_t g = L.hot.geom_of_env ? (int64_t)q.geom : i;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) box[k] = as_global(reinterpret_cast<const float*>(L.hot.path_bbox + g * kBoxDoubles))[k];
+                quant_inv = as_global(reinterpret_cast<const float*>(L.hot.path_bbox + g * kBoxDoubles))[kBoxQuantStep + 1];
                 own_len = as_global(L.hot.path_bbox)[g * kBoxDoubles + kBoxLen];
             }
         }
@@ -1936,10 +1971,9 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
                 part.hi = hi - member * third;
                 part.lo = max(lo, part.hi - third + 1);
                 if (a.hot.path_pre) {
-                    // (private paths: float32 prefilter records; `reach` = largest coordinate magnitude of this path's box)
-                    const double reach = (double)fmaxf(fmaxf(fabsf(box[0]), fabsf(box[1])), fmaxf(fabsf(box[2]), fabsf(box[3]))) + P.sp;
-                    last = last_reached_prefiltered(P, gpath, a.hot.path_pre + g * (int64_t)a.hot.path_max_len * 4, part, m,
-                                                    q.target, x, y, th, reach);
+                    // (private paths: quantised prefilter records, in steps from the corner of this path's box)
+                    last = last_reached_prefiltered(P, gpath, a.hot.path_pre + g * (int64_t)a.hot.path_max_len * 2, part, m,
+                                                    q.target, x, y, th, (double)box[0], (double)box[2], quant_inv);
                 } else {
                     last = last_reached_from(P, gpath, part, m, q.target, x, y, th);
                 }
@@ -2013,9 +2047,9 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
             for (int k = 0; k < 8; ++k) obox[k] = bx[k];
             const PathWindow ow = path_window(P, obox, SL->path.index + g * (int64_t)(4 * kPathBuckets), q.old.x, q.old.y);
             const double* opath = SL->path.pts + g * (int64_t)SL->path.max_len * 5;
-            const double reach = (double)fmaxf(fmaxf(fabsf(obox[0]), fabsf(obox[1])), fmaxf(fabsf(obox[2]), fabsf(obox[3]))) + P.sp;
-            const int olast = last_reached_prefiltered(P, opath, a.hot.path_pre + g * (int64_t)a.hot.path_max_len * 4, ow, my_len,
-                                                       q.target, q.old.x, q.old.y, q.old.th, reach);
+            const int olast = last_reached_prefiltered(P, opath, a.hot.path_pre + g * (int64_t)a.hot.path_max_len * 2, ow, my_len,
+                                                       q.target, q.old.x, q.old.y, q.old.th, (double)obox[0], (double)obox[2],
+                                                       bx[kBoxQuantStep + 1]);
             double omin = q.min_dist;
             int otarget = q.target;
             my_rec->spec_rew = reward_from_last(P, opath, my_len, olast, q.old.x, q.old.y, omin, otarget);

@@ -62,7 +62,7 @@ struct bcp_handle {
     size_t bitmap_bytes;
     double* path5;         // owned
     size_t path5_bytes;
-    float* path_pre;       // owned: [paths][max_len][4] float32 {x, y, cos, sin}: the prefilter record of private paths
+    uint32_t* path_pre;    // owned: [paths][max_len][2] {x, y as uint16 steps | cos, sin as int16}: the prefilter record of private paths
     size_t path_pre_bytes;
     double* path_bbox;     // owned
     size_t path_bbox_bytes;
@@ -1310,10 +1310,10 @@ static void launch_world_records(bcp_handle* h, EntrySelect sel, int64_t max_ent
 static void launch_path_data(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
 {
     const PathDesc& p = h->path;
-    hipLaunchKernelGGL(path_trig_kernel, dim3(stride_grid(max_entries * p.max_len, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src, h->path5,
-                       p.shared ? nullptr : h->path_pre, sel, p.max_len);
     hipLaunchKernelGGL(path_bbox_kernel, dim3(stride_grid(max_entries, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src, p.lens, p.max_len,
                        sel, h->dev.sp_prune, h->path_bbox);
+    hipLaunchKernelGGL(path_trig_kernel, dim3(stride_grid(max_entries * p.max_len, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src, h->path5,
+                       p.shared ? nullptr : h->path_pre, h->path_bbox, sel, p.max_len);
     hipLaunchKernelGGL(path_index_kernel, dim3(stride_grid(max_entries * 2 * kPathBuckets, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src,
                        p.lens, p.max_len, sel, h->dev.sp_prune, h->path_bbox, h->path_index);
     launch_world_records(h, sel, max_entries, s);
@@ -1517,7 +1517,7 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
         HIP_TRY(hipMalloc((void**)&h->path5, bytes));
         h->path5_bytes = bytes;
     }
-    const size_t pre_bytes = shared ? 0 : (size_t)total * 4 * sizeof(float);
+    const size_t pre_bytes = shared ? 0 : (size_t)total * 2 * sizeof(uint32_t);
     if (pre_bytes > h->path_pre_bytes) {
         if (h->path_pre) HIP_TRY(hipFree(h->path_pre));
         h->path_pre = nullptr;
