@@ -425,6 +425,89 @@ def test_private_maps_and_paths_vs_oracle(torch_cuda, oracle, mode):
     assert tot_r > 100
 
 
+def test_private_path_prefilter_boundary_poses_vs_oracle(torch_cuda, oracle):
+    """The scan of a private path goes through 8-byte quantised prefilter records (uint16 x, y in steps from the corner of
+    the path's box, int16 cos / sin; `last_reached_prefiltered`): poses ON the limits of find_last_reached
+    (utilities/path_tools.py:408-448) -- the spatial precision, "not behind the way point" at -sp / 9 -- relative to a way
+    point, to within 1e-10 .. 1e-3 either side, on paths from 2 cm to 60 m across, at the origin and 100 m away from it,
+    must come out as the float64 scan has them."""
+    torch = torch_cuda
+    from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams
+    n, rounds, max_len = 4096, 6, 64
+    rng = np.random.RandomState(77)
+    res = 0.05
+    lens = rng.randint(2, max_len + 1, n)
+    lens[:8] = [2, 2, 2, 2, 3, max_len, max_len, max_len]
+    scale = np.exp(rng.uniform(np.log(0.02), np.log(60.0), n))
+    scale[:2] = 0.0   # (coincident way points: the box has no extent)
+    offset = rng.choice([0.0, 3.0, -40.0, 100.0], (n, 2)) + rng.uniform(-1, 1, (n, 2))
+    pbuf = np.zeros((n, max_len, 3))
+    paths = []
+    for i in range(n):
+        m = lens[i]
+        t = np.linspace(0, 1, m)
+        a0, a1, a2 = rng.uniform(-np.pi, np.pi), rng.uniform(-3, 3), rng.uniform(-3, 3)
+        th = a0 + a1 * t + a2 * t * t
+        seg = scale[i] / max(m - 1, 1)
+        x = offset[i, 0] + np.concatenate([[0.0], np.cumsum(np.cos(th[:-1]) * seg)])
+        y = offset[i, 1] + np.concatenate([[0.0], np.cumsum(np.sin(th[:-1]) * seg)])
+        pbuf[i, :m] = np.stack([x, y, th + rng.normal(0, 0.05, m)], axis=1)
+        pbuf[i, m - 1, 2] = pbuf[i, 0, 2] + np.pi   # (the goal must not count as reached from the start: env.py refuses such a path)
+        paths.append(pbuf[i, :m].copy())
+    free = np.zeros((16, 16), dtype=np.uint8)
+    costmaps = [CostMap2D(free, res, offset[i]) for i in range(n)]
+    params = EnvParams(resolution=res, refine_path=False)
+    env = BatchedPlanEnv(costmaps, paths, params, n_envs=n, noise_parameters=None, auto_reset=False, seed=1)
+    p = oracle.make_params("tricycle", noise=None)
+    ref = oracle.OracleBatch(p, n, np.zeros((n, 16, 16), np.uint8), offset.copy(), res, pbuf, lens=list(lens),
+                             rows=np.full(n, 16, np.int32), cols=np.full(n, 16, np.int32))
+    ref.reset_from_paths()
+    sp = float(p.spatial_precision)
+    # (no exact ties: on a limit itself the last bit of cos / sin / hypot decides, and the device's are not glibc's)
+    deltas = np.array([1e-10, -1e-10, 1e-9, -1e-9, 1e-7, -1e-7, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3, -1e-3, -0.02, -0.5, 0.3])
+    zero = np.zeros((n, 2))
+    reached = 0
+    for r in range(rounds):
+        k = (rng.rand(n) * lens).astype(np.int64)
+        wp = pbuf[np.arange(n), k]
+        d = deltas[rng.randint(0, len(deltas), n)]
+        kind = rng.randint(0, 3, n)
+        # kind 0: on the circle of radius sp (1 + d), anywhere in front;  kind 1: on the line "parallel = -sp / 9" (1 + d),
+        # inside the circle;  kind 2: both limits at once
+        rad = np.where(kind == 1, sp * rng.uniform(0.2, 0.99, n), sp * (1 + d))
+        par = np.where(kind == 0, rad * rng.uniform(-0.1, 1.0, n), -sp / 9 * (1 + np.where(kind == 2, rng.choice(deltas, n), d)))
+        par = np.clip(par, -rad, rad)
+        perp = np.sqrt(np.maximum(rad * rad - par * par, 0.0)) * rng.choice([-1.0, 1.0], n)
+        c, s_ = np.cos(wp[:, 2]), np.sin(wp[:, 2])
+        st = np.zeros((7, n))
+        st[0] = wp[:, 0] + par * c - perp * s_
+        st[1] = wp[:, 1] + par * s_ + perp * c
+        st[2] = wp[:, 2] + rng.uniform(-1.7, 1.7, n)
+        tgt = np.clip(k - rng.randint(0, 6, n), 0, lens - 1).astype(np.int32)
+        md = np.full(n, 1e3)
+        env.state.robot.copy_(torch.from_numpy(st))
+        env.state.min_spat_dist_so_far.copy_(torch.from_numpy(md))
+        env.state.target_idx.copy_(torch.from_numpy(tgt))
+        env.state.current_iter.zero_()
+        for f in range(7):
+            ref.st[f][:] = st[f]
+        ref.min_dist[:], ref.target_idx[:], ref.cur_iter[:] = md, tgt, 0
+        env.step(zero)
+        ref.step(zero, None, auto_reset=False, threads=8)
+        np.testing.assert_array_equal(env.state.robot.cpu().numpy()[:2], st[:2])   # (nobody moved)
+        np.testing.assert_allclose(env.state.robot.cpu().numpy(), np.stack(ref.st), rtol=0, atol=ATOL)
+        bad = np.nonzero(env.state.target_idx.cpu().numpy() != ref.target_idx)[0]
+        detail = ["env %d: len %d scale %.4g offset %s way point %d target %d kind %d d %.3g -> %d, oracle %d" % (
+            i, lens[i], scale[i], offset[i], k[i], tgt[i], kind[i], d[i], int(env.state.target_idx[i]), ref.target_idx[i])
+            for i in bad[:8]]
+        assert len(bad) == 0, "round %d: %s" % (r, "; ".join(detail))
+        np.testing.assert_allclose(env.reward.cpu().numpy(), ref.reward, rtol=0, atol=ATOL)
+        np.testing.assert_array_equal(env.done.cpu().numpy(), ref.done)
+        reached += int((ref.reward == 1.0).sum())
+    assert n * rounds // 5 < reached < n * rounds * 4 // 5, reached
+    env.check_errors()
+
+
 @pytest.mark.parametrize("combo", ["private-maps-shared-path", "shared-map-private-paths"])
 def test_mixed_shared_and_private_geometry_vs_oracle(torch_cuda, oracle, combo):
     """The two mixed cases: per-env costmaps (own origins) under one shared path, and one shared costmap under per-env
