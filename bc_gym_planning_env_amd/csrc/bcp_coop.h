@@ -416,7 +416,10 @@ __device__ __forceinline__ bool coop_raster(const DevParams& P, double qx, doubl
 }
 
 // Row sink testing coverage against the lethal bitmap (pose_collides, env.py:464-489)
-template <int NW, typename WordPtr>
+// TILED: `words` is the map's copy in tiles of 32 x 32 cells (pack_bitmap_kernel: word (r, w) of the row-major mask at
+// ((r >> 5) * wpr + w) * 32 + (r & 31)) -- the 64 rows a wave reads of one word column are two or three runs of 128 bytes,
+// where the row-major rows of a private map each sit in a sector of their own.
+template <int NW, typename WordPtr, bool TILED = false>
 struct CoopCollisionSink {
     WordPtr words;
     int n_rows, n_cols, wpr, px, py;
@@ -435,13 +438,15 @@ struct CoopCollisionSink {
         const int sh = c_lo & 31;
         const bool row_ok = valid && (unsigned)r < (unsigned)n_rows;
         uint32_t raw[NW + 1];
+        const int width = c_hi - c_lo + 1;  // columns beyond the image never matter
+        const int last_w = (sh + width - 1) >> 5;   // (... nor do the words that only hold such columns)
 #pragma unroll
         for (int w = 0; w <= NW; ++w) {
             const int wi = w0 + w;
-            raw[w] = (row_ok && (unsigned)wi < (unsigned)wpr) ? words[r * wpr + wi] : 0u;
+            const int at = TILED ? (((r >> 5) * wpr + wi) << 5) + (r & 31) : r * wpr + wi;
+            raw[w] = (row_ok && w <= last_w && (unsigned)wi < (unsigned)wpr) ? words[at] : 0u;
         }
         uint32_t any = 0;
-        const int width = c_hi - c_lo + 1;  // columns beyond the image never matter
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             uint32_t v = sh ? (raw[w] >> sh) | (raw[w + 1] << (32 - sh)) : raw[w];
@@ -539,7 +544,7 @@ __device__ __forceinline__ int row_max(int v)
     return max(v, dpp_ror<0x121>(v));
 }
 
-template <bool WIDE, typename WordPtr>
+template <bool WIDE, bool TILED = false, typename WordPtr>
 __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 qverts, double c, double s, int px, int py,
                                                     WordPtr words, int rows, int cols, int wpr, LdsU32 list,
                                                     [[maybe_unused]] unsigned long long* phase = nullptr)
@@ -585,7 +590,7 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 q
     if (!owner) dy = -1;        // inert: no run on any row
     // ---- the lethal cells under the image's columns, all row chunks into one list (lane = row of the chunk; the order
     //      of the cells does not matter, so a lane just reserves room for its row's cells with one LDS atomic)
-    CoopCollisionSink<NW, WordPtr> sink{words, rows, cols, wpr, px, py, 0, 0};
+    CoopCollisionSink<NW, WordPtr, TILED> sink{words, rows, cols, wpr, px, py, 0, 0};
     sink.extent(umin, umax);
 #ifdef BCP_DIAG
     if (phase) phase[0] = __builtin_amdgcn_s_memtime();   // the edges are set up

@@ -25,6 +25,7 @@ struct DevState {
 
 struct MapDesc {
     const uint32_t* bits;  // lethal bitmap, [rows][wpr] shared or [N][rows][wpr]
+    const uint32_t* tiles; // the same bits in tiles of 32 x 32 cells, [tile_words] per entry (pack_bitmap_kernel, CoopCollisionSink)
     int32_t rows, cols, wpr;
     int32_t shared;
     int32_t in_lds;        // shared bitmap small enough to be staged in LDS
@@ -144,6 +145,7 @@ struct StepArgs {
     int32_t* adapt_base;       // [2] thresholds + [2][kShards] in-place counters, or nullptr (no adaptation)
     uint64_t* parked_slots;    // [workgroups of step_local_kernel] parked poses so far, a word per workgroup (bcp_parked_poses)
     int32_t rollout_steps;     // step_local_kernel<.., ROLL = true> (bcp_rollout): steps per launch; actions / noise_z / outputs are [steps][N]..
+    const uint32_t* map_tiles; // MapDesc::tiles: what step_local_kernel's exact tests read when the map is not staged in LDS
 };
 constexpr int kTickWords = 16;
 constexpr int kTickLocalTicket = 8;   // step_local_kernel's ticket: not on the line the prologues read the counter and the seed from
@@ -211,8 +213,11 @@ struct EntrySelect {
 };
 
 // uint8 costmap -> 1-bit lethal mask.  One thread per 32-bit output word.
-__global__ void pack_bitmap_kernel(const uint8_t* __restrict__ data, uint32_t* __restrict__ bits, EntrySelect sel,
-                                   int rows, int cols, int wpr, const int32_t* __restrict__ valid_rows,
+// (tiles: the same words once more in tiles of 32 x 32 cells, map_tile_words() per entry -- see CoopCollisionSink)
+__host__ __device__ __forceinline__ int64_t map_tile_words(int rows, int wpr) { return (int64_t)((rows + 31) & ~31) * wpr; }
+
+__global__ void pack_bitmap_kernel(const uint8_t* __restrict__ data, uint32_t* __restrict__ bits, uint32_t* __restrict__ tiles,
+                                   EntrySelect sel, int rows, int cols, int wpr, const int32_t* __restrict__ valid_rows,
                                    const int32_t* __restrict__ valid_cols)
 {
     const int64_t total = sel.size() * rows * wpr;
@@ -231,6 +236,7 @@ __global__ void pack_bitmap_kernel(const uint8_t* __restrict__ data, uint32_t* _
             for (int b = 0; b < lim; ++b) word |= (uint32_t)(src[b] == BCP_LETHAL) << b;
         }
         bits[idx] = word;
+        if (tiles) tiles[m * map_tile_words(rows, wpr) + (((r >> 5) * wpr + w) << 5) + (r & 31)] = word;
     }
 }
 
@@ -2124,6 +2130,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
         const int64_t env = ((int64_t)e->env_hi << 32) | (uint32_t)e->env_lo;
         const int64_t g = a.hot.map_shared ? 0 : (a.hot.geom_of_env ? (int64_t)e->geom : env);
         const uint32_t* words = a.hot.map_bits + g * a.hot.map_env_stride;
+        const uint32_t* tiles = a.map_tiles + g * map_tile_words(a.hot.map_rows, a.hot.map_wpr);
         bool h = false;
         [[maybe_unused]] const unsigned long long test_from = DIAG_NOW();
         [[maybe_unused]] int how = 0;
@@ -2138,8 +2145,8 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
             const int verdict = map_words
                 ? coop_collides_sparse<WIDE>(P, (LdsF64)qv, c, s, px, py, (LdsWords)lds_map, a.hot.map_rows, a.hot.map_cols,
                                              a.hot.map_wpr, cell_list, phases)
-                : coop_collides_sparse<WIDE>(P, (LdsF64)qv, c, s, px, py, as_global(words), a.hot.map_rows, a.hot.map_cols,
-                                             a.hot.map_wpr, cell_list, phases);
+                : coop_collides_sparse<WIDE, true>(P, (LdsF64)qv, c, s, px, py, as_global(tiles), a.hot.map_rows, a.hot.map_cols,
+                                                   a.hot.map_wpr, cell_list, phases);
 #ifdef BCP_DIAG
             // wave 8's test: cycles for the edge set-up, for listing the cells, for the rest, and the list's length
             if (threadIdx.x == kWHelper1 * 64 && blockIdx.x < 2048) {

@@ -60,6 +60,8 @@ struct bcp_handle {
     double resolution;
     uint32_t* bitmap;      // owned
     size_t bitmap_bytes;
+    uint32_t* map_tiles;   // owned: the bitmap once more in tiles of 32 x 32 cells (MapDesc::tiles)
+    size_t map_tiles_bytes;
     double* path5;         // owned
     size_t path5_bytes;
     uint32_t* path_pre;    // owned: [paths][max_len][2] {x, y as uint16 steps | cos, sin as int16}: the prefilter record of private paths
@@ -1067,6 +1069,7 @@ extern "C" int bcp_destroy(bcp_handle* h)
     if (!h) return BCP_OK;
     (void)hipSetDevice(h->device);
     if (h->bitmap) (void)hipFree(h->bitmap);
+    if (h->map_tiles) (void)hipFree(h->map_tiles);
     if (h->path5) (void)hipFree(h->path5);
     if (h->path_pre) (void)hipFree(h->path_pre);
     if (h->path_bbox) (void)hipFree(h->path_bbox);
@@ -1196,7 +1199,7 @@ static void launch_pack_bitmap(bcp_handle* h, EntrySelect sel, int64_t max_entri
 {
     const MapDesc& m = h->map;
     hipLaunchKernelGGL(pack_bitmap_kernel, dim3(stride_grid(max_entries * m.rows * m.wpr, 256, sel.list != nullptr)), dim3(256), 0, s, h->map_data,
-                       h->bitmap, sel, m.rows, m.cols, m.wpr, h->map_valid_rows, h->map_valid_cols);
+                       h->bitmap, h->map_tiles, sel, m.rows, m.cols, m.wpr, h->map_valid_rows, h->map_valid_cols);
     // the cell lists of the sparse egocentric views follow the maps: all of them are rebuilt lazily after a re-bind
     // (sel.list == nullptr), the re-sampled entries of a pool refresh right here, in stream order
     if (h->ego_cells_built) {
@@ -1339,6 +1342,14 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
         HIP_TRY(hipMalloc((void**)&h->bitmap, bytes));
         h->bitmap_bytes = bytes;
     }
+    const size_t tile_bytes = (size_t)n_maps * map_tile_words(rows, wpr) * sizeof(uint32_t);
+    if (tile_bytes > h->map_tiles_bytes) {
+        if (h->map_tiles) HIP_TRY(hipFree(h->map_tiles));
+        h->map_tiles = nullptr;
+        h->map_tiles_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&h->map_tiles, tile_bytes));
+        h->map_tiles_bytes = tile_bytes;
+    }
     h->resolution = resolution;
     h->map_data = data;
     h->map_valid_rows = valid_rows;
@@ -1346,6 +1357,7 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
     fill_dev_params(h);
     MapDesc& m = h->map;
     m.bits = h->bitmap;
+    m.tiles = h->map_tiles;
     m.rows = rows;
     m.cols = cols;
     m.wpr = wpr;
@@ -1768,6 +1780,7 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     const bool adapt = h->adaptive && h->adapt && S.pending && S.dense_threshold >= 0;
     a.tick = h->tick;
     a.parked_slots = nullptr;
+    a.map_tiles = S.map.tiles;
     a.rollout_steps = 1;
     a.pending_base = h->pending_count;
     a.adapt_base = adapt ? h->adapt : nullptr;
