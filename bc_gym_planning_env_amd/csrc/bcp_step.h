@@ -39,9 +39,9 @@ struct PathDesc {
     const uint32_t* pre; // private paths: [N][max_len][2] = x, y (uint16 each, in steps from the box corner) and cos, sin of theta
                          // (int16, / 32767) -- the 8-byte prefilter record of
                          // the way-point scan (16 bytes: four way points per 64-byte sector); nullptr for a shared path
-    const double* bbox;  // [kBoxDoubles] per path, one 64-byte record: box of the way points and bucket grid as eight f32,
-                         // then the costmap origin and the path length of the entry as doubles -- see kBoxDoubles
-    const int16_t* index; // [2 axes][kPathBuckets][2] = first / last way point index that can be reached from a bucket
+    const double* bbox;  // [kBoxDoubles] per path, one 128-byte record: box of the way points and bucket grid as eight f32,
+                         // the costmap origin, the path length and, for private paths, the bucket tables -- see kBoxDoubles
+    const int16_t* index; // shared path: [2 axes][kPathBuckets][2] = first / last way point index that can be reached from a bucket
     const int32_t* lens;
     int32_t max_len, shared;
 };
@@ -240,21 +240,26 @@ __global__ void pack_bitmap_kernel(const uint8_t* __restrict__ data, uint32_t* _
     }
 }
 
-constexpr int kPathBuckets = 64;
-// One 64-byte record per path entry -- one memory sector.  With private paths an env needs a handful of small per-entry
-// values every step that would each cost a sector of their own, so they share one:
-//   floats  [0..3]  xmin, xmax, ymin, ymax of the way points, rounded OUTWARD to f32 (the box only ever prunes: a wider one
-//                   hands a few more poses to the bucket tables, whose windows the exact test then walks)
-//   floats  [4..7]  the bucket grid x0, 1/wx, y0, 1/wy, as f32 (the tables are built from these very values, below, so a
-//                   look-up and the table it reads agree whatever their rounding)
-//   doubles [4],[5] origin of the entry's costmap (world_record_kernel)
-//   double  [6]     number of way points, as a double
+constexpr int kPathBuckets = 64;          // buckets per axis of a shared path's tables (PathDesc::index, staged in LDS)
+constexpr int kPathBucketsCompact = 16;   // ... of a private path's, which live inside its record
+// One 128-byte record per path entry -- ONE line of memory: a load that misses L2 fetches the whole line whatever it asks
+// for (tools/sector_probe.hip: 128 bytes per lone 4-byte read, and no more for a second word 32 or 64 bytes further), so
+// every small per-entry array an env reads from costs it a line per step.  With private paths all of them share this one:
+//   floats  [0..3]    xmin, xmax, ymin, ymax of the way points, rounded OUTWARD to f32 (the box only ever prunes: a wider one
+//                     hands a few more poses to the bucket tables, whose windows the exact test then walks)
+//   floats  [4..7]    the bucket grid x0, 1/wx, y0, 1/wy, as f32 (the tables are built from these very values, below, so a
+//                     look-up and the table it reads agree whatever their rounding)
+//   doubles [4],[5]   origin of the entry's costmap (world_record_kernel)
+//   int32   [12],[13] number of way points; shift of the compact tables' indices (0 unless the paths have > 255 way points)
 //   floats  [14],[15] step of the quantised prefilter records (path_trig_kernel) and its reciprocal
-// (two sectors until round 4: box and grid as doubles in the first, origin and length in the second)
-constexpr int kBoxDoubles = 8;
+//   bytes   [64..127] private paths: the bucket tables, [2 axes][kPathBucketsCompact] {first, last} >> shift as uint8
+//                     (path_index_compact_kernel); until round 4 [2][64] int16 pairs in an array of their own, two lines per step
+// (rounds 2-3: 128 bytes in two halves -- box and grid as doubles, origin and length -- beside 512 bytes of tables)
+constexpr int kBoxDoubles = 16;
 constexpr int kBoxOrigin = 4;
-constexpr int kBoxLen = 6;
+constexpr int kBoxLenWord = 12;      // (int32 index; [13]: the index shift)
 constexpr int kBoxQuantStep = 14;    // (float index)
+constexpr int kBoxIndexU16 = 32;     // (uint16 index of the compact tables: {first | last << 8} per bucket)
 constexpr int kQuantSteps = 65000;   // the longer side of the box in steps (uint16 coordinates)
 constexpr int kQuantReach = 16384;   // spatial precision in steps, at most: poses the window lets through stay below 2^17 steps
 
@@ -298,9 +303,9 @@ __device__ __forceinline__ float f32_above(double v)
     return (double)f < v ? nextafterf(f, INFINITY) : f;
 }
 
-// Per path: bounding box of the way points and a 1-D bucket grid per axis over [min - sp, max + sp].
+// Per path: bounding box of the way points and a 1-D grid of `buckets` buckets per axis over [min - sp, max + sp].
 __device__ __forceinline__ void path_bbox_one(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
-                                              int64_t p, double sp_prune, double* __restrict__ bbox)
+                                              int64_t p, double sp_prune, int buckets, double* __restrict__ bbox)
 {
     const int m = lens ? lens[p] : max_len;
     const double* q = xyt + p * (int64_t)max_len * 3;
@@ -316,8 +321,8 @@ __device__ __forceinline__ void path_bbox_one(const double* __restrict__ xyt, co
     o[1] = f32_above(x1);
     o[2] = f32_below(y0);
     o[3] = f32_above(y1);
-    const double wx = fmax((x1 - x0 + 2.0 * sp_prune) / kPathBuckets, 1e-9);
-    const double wy = fmax((y1 - y0 + 2.0 * sp_prune) / kPathBuckets, 1e-9);
+    const double wx = fmax((x1 - x0 + 2.0 * sp_prune) / buckets, 1e-9);
+    const double wy = fmax((y1 - y0 + 2.0 * sp_prune) / buckets, 1e-9);
     o[4] = (float)(x0 - sp_prune);
     o[5] = (float)(1.0 / wx);
     o[6] = (float)(y0 - sp_prune);
@@ -328,19 +333,23 @@ __device__ __forceinline__ void path_bbox_one(const double* __restrict__ xyt, co
     const float step = (float)fmax(extent / kQuantSteps, sp_prune / kQuantReach);
     o[kBoxQuantStep] = step;
     o[kBoxQuantStep + 1] = 1.0f / step;
+    int shift = 0;
+    while (((max_len - 1) >> shift) > 254) ++shift;   // (255 marks an empty bucket)
+    reinterpret_cast<int32_t*>(o)[kBoxLenWord] = m;
+    reinterpret_cast<int32_t*>(o)[kBoxLenWord + 1] = shift;
 }
 
 __global__ void path_bbox_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
-                                 EntrySelect sel, double sp_prune, double* __restrict__ bbox)
+                                 EntrySelect sel, double sp_prune, int buckets, double* __restrict__ bbox)
 {
     const int64_t total = sel.size();
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x)
-        path_bbox_one(xyt, lens, max_len, sel.entry(it), sp_prune, bbox);
+        path_bbox_one(xyt, lens, max_len, sel.entry(it), sp_prune, buckets, bbox);
 }
 
-// the rest of a path entry's record: origin of the entry's costmap (or of the shared one) and its length
+// the rest of a path entry's record: origin of the entry's costmap (or of the shared one)
 __global__ void world_record_kernel(EntrySelect sel, const double* __restrict__ origins, double ox, double oy,
-                                    const int32_t* __restrict__ lens, int max_len, double* __restrict__ bbox)
+                                    double* __restrict__ bbox)
 {
     const int64_t total = sel.size();
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
@@ -348,7 +357,6 @@ __global__ void world_record_kernel(EntrySelect sel, const double* __restrict__ 
         double* o = bbox + kBoxDoubles * p;
         o[kBoxOrigin] = origins ? origins[2 * p] : ox;
         o[kBoxOrigin + 1] = origins ? origins[2 * p + 1] : oy;
-        o[kBoxLen] = (double)(lens ? lens[p] : max_len);
     }
 }
 
@@ -390,6 +398,35 @@ __global__ void path_index_kernel(const double* __restrict__ xyt, const int32_t*
                        sp_prune, bbox, index);
 }
 
+// The same tables for a private path, inside its record: kPathBucketsCompact buckets per axis, {first, last} >> shift as
+// uint8 ({255, 0} when there is none).  One thread per bucket.
+__global__ void path_index_compact_kernel(const double* __restrict__ xyt, const int32_t* __restrict__ lens, int max_len,
+                                          EntrySelect sel, double sp_prune, double* __restrict__ bbox)
+{
+    const int64_t total = sel.size() * 2 * kPathBucketsCompact;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(it % kPathBucketsCompact), axis = (int)((it / kPathBucketsCompact) % 2);
+        const int64_t p = sel.entry(it / (2 * kPathBucketsCompact));
+        const int m = lens ? lens[p] : max_len;
+        const double* q = xyt + p * (int64_t)max_len * 3;
+        const float* rec = reinterpret_cast<const float*>(bbox + kBoxDoubles * p);
+        const int shift = reinterpret_cast<const int32_t*>(rec)[kBoxLenWord + 1];
+        const double o = (double)rec[4 + 2 * axis], w = 1.0 / (double)rec[5 + 2 * axis];
+        const double guard = 1e-6 * w + 1e-12;
+        const double lo = o + b * w - sp_prune - guard, hi = o + (b + 1) * w + sp_prune + guard;
+        int first = -1, last = -1;
+        for (int j = 0; j < m; ++j) {
+            const double v = q[3 * j + axis];
+            if (v >= lo && v <= hi) {
+                if (first < 0) first = j;
+                last = j;
+            }
+        }
+        const uint32_t packed = first < 0 ? 255u : (uint32_t)(first >> shift) | ((uint32_t)(last >> shift) << 8);
+        reinterpret_cast<uint16_t*>(bbox + kBoxDoubles * p)[kBoxIndexU16 + axis * kPathBucketsCompact + b] = (uint16_t)packed;
+    }
+}
+
 // find_last_reached restricted to j >= target (utilities/path_tools.py:408-448): the reward only asks whether the
 // LAST reached index is >= target_idx (envs/base/reward.py:234), so indices below target never matter.
 // A way point can only be reached when |x_j - x| and |y_j - y| are both below spatial_precision, so the scan is
@@ -417,6 +454,36 @@ __device__ __forceinline__ PathWindow path_window(const DevParams& P, BoxPtr bbo
     w.lo = max((int)ix[0], (int)iy[0]);
     w.hi = min((int)ix[1], (int)iy[1]);
     return w;
+}
+
+// the same look-up in the compact tables of a private path (tables: the record's uint16 words from kBoxIndexU16 on;
+// shift: its int32 word kBoxLenWord + 1) -- a superset of the window the 64-bucket tables would give
+template <typename BoxPtr, typename TablePtr>
+__device__ __forceinline__ PathWindow path_window_compact(const DevParams& P, BoxPtr bbox, TablePtr tables, int shift, double x,
+                                                          double y)
+{
+    PathWindow w;
+    w.lo = 0;
+    w.hi = -1;
+    if (x < (double)bbox[0] - P.sp_prune || x > (double)bbox[1] + P.sp_prune || y < (double)bbox[2] - P.sp_prune ||
+        y > (double)bbox[3] + P.sp_prune)
+        return w;
+    const int bx = min(max((int)floor((x - (double)bbox[4]) * (double)bbox[5]), 0), kPathBucketsCompact - 1);
+    const int by = min(max((int)floor((y - (double)bbox[6]) * (double)bbox[7]), 0), kPathBucketsCompact - 1);
+    const uint32_t ix = tables[bx], iy = tables[kPathBucketsCompact + by];
+    w.lo = (int)max(ix & 0xFFu, iy & 0xFFu) << shift;
+    w.hi = (int)(((min(ix >> 8, iy >> 8) + 1u) << shift) - 1u);
+    return w;
+}
+
+// the window of entry g's path for a pose, whichever tables the path has (everything but the step kernels' hot paths)
+__device__ __forceinline__ PathWindow path_window_of(const DevParams& P, bool shared, const double* bbox, const int16_t* index,
+                                                     int64_t g, double x, double y)
+{
+    if (shared) return path_window(P, reinterpret_cast<const float*>(bbox), index, x, y);
+    const float* rec = reinterpret_cast<const float*>(bbox + g * kBoxDoubles);
+    return path_window_compact(P, rec, reinterpret_cast<const uint16_t*>(rec) + kBoxIndexU16,
+                               reinterpret_cast<const int32_t*>(rec)[kBoxLenWord + 1], x, y);
 }
 
 // one candidate way point (its five values already in registers) against the three reach conditions of
@@ -964,10 +1031,8 @@ __device__ __forceinline__ void finalize_env_from(const A& a, SP S, int64_t i, P
             target = score.target;
         } else if (!ABLATED(a, kAblateNoReward)) {
             // way-point window of the pose: the caller may have looked it up already for the un-rolled-back pose
-            const float* bbox = reinterpret_cast<const float*>(S->path.bbox + (S->path.shared ? 0 : g * kBoxDoubles));
-            const int16_t* index = S->path.index + (S->path.shared ? 0 : g * (int64_t)(4 * kPathBuckets));
             const PathWindow w =
-                (free_window && !hit && !pose_delay) ? *free_window : path_window(P, bbox, index, seen[0], seen[1]);
+                (free_window && !hit && !pose_delay) ? *free_window : path_window_of(P, S->path.shared != 0, S->path.bbox, S->path.index, g, seen[0], seen[1]);
             if (lds_path && S->path.shared)  // way points staged in LDS by the step kernel
                 rew = reward_step(P, lds_path, w, m, seen[0], seen[1], seen[2], min_dist, target);
             else
@@ -1300,7 +1365,8 @@ __global__ void __launch_bounds__(2 * kBlock) step_fast_pair_kernel(const StepAr
         if (a.S->path.shared)
             win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
         else
-            win = path_window(P, box, a.S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+            win = path_window_compact(P, box, reinterpret_cast<const uint16_t*>(a.hot.path_bbox + g * kBoxDoubles) + kBoxIndexU16,
+                                      reinterpret_cast<const int32_t*>(a.hot.path_bbox + g * kBoxDoubles)[kBoxLenWord + 1], x, y);
         const int m = a.S->path.shared ? a.S->path.max_len : a.S->path.lens[g];
         double min_dist = q.min_dist;
         int target = q.target;
@@ -1648,7 +1714,8 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
     float box[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (a private path's box and bucket grid: the f32 words of its record)
     float quant_inv = 0.0f;                    // (... and the reciprocal step of its prefilter records)
     double old_angle = 0.0;
-    double own_org_x = 0.0, own_org_y = 0.0, own_len = 0.0;   // (only ever written by the loads below: a later assignment
+    double own_org_x = 0.0, own_org_y = 0.0;                  // (only ever written by the loads below: a later assignment
+    uint64_t own_len_shift = 0;                                // (private path: way points | index shift << 32)
                                                                //  to a register a load is in flight to would wait for it)
     const bool own_origin = !hot_path_shared || L.hot.map_origins != nullptr;
     if (mover) {
@@ -1657,7 +1724,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
             const int64_t g = L.hot.geom_of_env ? (int64_t)q.geom : i;
             own_org_x = as_global(L.hot.path_bbox)[g * kBoxDoubles + kBoxOrigin];
             own_org_y = as_global(L.hot.path_bbox)[g * kBoxDoubles + kBoxOrigin + 1];
-            own_len = as_global(L.hot.path_bbox)[g * kBoxDoubles + kBoxLen];
+            own_len_shift = as_global(reinterpret_cast<const uint64_t*>(L.hot.path_bbox))[g * kBoxDoubles + kBoxLenWord / 2];
         } else if (L.hot.map_origins) {   // (private maps with a shared path)
             const int64_t g = L.hot.geom_of_env ? (int64_t)q.geom : i;
             own_org_x = as_global(L.hot.map_origins)[2 * g + 0];
@@ -1674,7 +1741,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
 #pragma unroll
                 for (int k = 0; k < 8; ++k) box[k] = as_global(reinterpret_cast<const float*>(L.hot.path_bbox + g * kBoxDoubles))[k];
                 quant_inv = as_global(reinterpret_cast<const float*>(L.hot.path_bbox + g * kBoxDoubles))[kBoxQuantStep + 1];
-                own_len = as_global(L.hot.path_bbox)[g * kBoxDoubles + kBoxLen];
+                own_len_shift = as_global(reinterpret_cast<const uint64_t*>(L.hot.path_bbox))[g * kBoxDoubles + kBoxLenWord / 2];
             }
         }
         if (member == 1) old_angle = as_global(L.hot.st.angle)[i];
@@ -1768,7 +1835,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
     __syncthreads();   // barrier 0: noise, old heading and the parameter block are in LDS
     const DevParams& P = *(const DevParams*)&SL->P;
     const int map_rows = hot_map_rows, map_cols = hot_map_cols;
-    const int my_len = hot_path_shared ? hot_max_len : (int)own_len;   // way points of this env's path
+    const int my_len = hot_path_shared ? hot_max_len : (int)(uint32_t)own_len_shift;   // way points of this env's path
     // (7) mover: the second half of the robot model; the pose the reward provider will see goes to the scanning waves
     Pose new_pose;
     new_pose.x = new_pose.y = new_pose.th = 0.0;
@@ -1964,7 +2031,8 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
         if (SL->path.shared)
             win = path_window(P, (LdsF64)lds_box, (const __attribute__((address_space(3))) int16_t*)lds_index, x, y);
         else
-            win = path_window(P, box, SL->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+            win = path_window_compact(P, box, as_global(reinterpret_cast<const uint16_t*>(L.hot.path_bbox + g * kBoxDoubles)) + kBoxIndexU16,
+                                      (int)(own_len_shift >> 32), x, y);
         DIAG_STAMP_U(kWScorer, 6);    // scorer: candidate window known
         if (PLAIN) {
             // way points in memory: this member's share of the candidate window [max(lo, target), min(hi, m - 1)] is a
@@ -2051,7 +2119,8 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
             float obox[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) obox[k] = bx[k];
-            const PathWindow ow = path_window(P, obox, SL->path.index + g * (int64_t)(4 * kPathBuckets), q.old.x, q.old.y);
+            const PathWindow ow = path_window_compact(P, obox, as_global(reinterpret_cast<const uint16_t*>(L.hot.path_bbox + g * kBoxDoubles)) + kBoxIndexU16,
+                                                      (int)(own_len_shift >> 32), q.old.x, q.old.y);
             const double* opath = SL->path.pts + g * (int64_t)SL->path.max_len * 5;
             const int olast = last_reached_prefiltered(P, opath, a.hot.path_pre + g * (int64_t)a.hot.path_max_len * 2, ow, my_len,
                                                        q.target, q.old.x, q.old.y, q.old.th, (double)obox[0], (double)obox[2],

@@ -767,7 +767,7 @@ __global__ void reward_kernel(const StepStatic* __restrict__ S, const double* __
         rew = reward_pure_pursuit(pts, m, x, y, collided && collided[i], min_dist, target);
         reached = hypot(pts[5 * (m - 1)] - x, pts[5 * (m - 1) + 1] - y) < 1.0;   // reward.py:141-150
     } else {
-        const PathWindow w = path_window(P, reinterpret_cast<const float*>(S->path.bbox + g * kBoxDoubles), S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+        const PathWindow w = path_window_of(P, S->path.shared != 0, S->path.bbox, S->path.index, g, x, y);
         rew = reward_step(P, pts, w, m, x, y, th, min_dist, target);
         reached = target > m - 1;                                                 // reward.py:66-69
     }
@@ -789,7 +789,7 @@ __global__ void find_last_reached_kernel(const StepStatic* __restrict__ S, const
     const double* pts = S->path.pts + g * (int64_t)S->path.max_len * 5;
     const int m = S->path.shared ? S->path.max_len : S->path.lens[g];
     const double x = poses[3 * i], y = poses[3 * i + 1], th = poses[3 * i + 2];
-    const PathWindow w = path_window(S->P, reinterpret_cast<const float*>(S->path.bbox + g * kBoxDoubles), S->path.index + g * (int64_t)(4 * kPathBuckets), x, y);
+    const PathWindow w = path_window_of(S->P, S->path.shared != 0, S->path.bbox, S->path.index, g, x, y);
     out[i] = last_reached_from(S->P, pts, w, m, 0, x, y, th);
 }
 
@@ -1302,23 +1302,27 @@ static int ensure_fields(bcp_handle* h, hipStream_t s)
     return BCP_OK;
 }
 
-// origin and length into the path records of private paths (kBoxOrigin, kBoxLen): needs both the costmaps and the paths
+// the costmap origins into the path records of private paths (kBoxOrigin): needs both the costmaps and the paths
 static void launch_world_records(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
 {
     if (!h->path_bbox || h->path.shared || !h->map.bits) return;
     hipLaunchKernelGGL(world_record_kernel, dim3(stride_grid(max_entries, 256, sel.list != nullptr)), dim3(256), 0, s, sel,
-                       h->map.origins, h->map.ox, h->map.oy, h->path.lens, h->path.max_len, h->path_bbox);
+                       h->map.origins, h->map.ox, h->map.oy, h->path_bbox);
 }
 
 static void launch_path_data(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
 {
     const PathDesc& p = h->path;
     hipLaunchKernelGGL(path_bbox_kernel, dim3(stride_grid(max_entries, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src, p.lens, p.max_len,
-                       sel, h->dev.sp_prune, h->path_bbox);
+                       sel, h->dev.sp_prune, p.shared ? kPathBuckets : kPathBucketsCompact, h->path_bbox);
     hipLaunchKernelGGL(path_trig_kernel, dim3(stride_grid(max_entries * p.max_len, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src, h->path5,
                        p.shared ? nullptr : h->path_pre, h->path_bbox, sel, p.max_len);
-    hipLaunchKernelGGL(path_index_kernel, dim3(stride_grid(max_entries * 2 * kPathBuckets, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src,
-                       p.lens, p.max_len, sel, h->dev.sp_prune, h->path_bbox, h->path_index);
+    if (p.shared)
+        hipLaunchKernelGGL(path_index_kernel, dim3(stride_grid(max_entries * 2 * kPathBuckets, 256, sel.list != nullptr)), dim3(256), 0, s, h->path_src,
+                           p.lens, p.max_len, sel, h->dev.sp_prune, h->path_bbox, h->path_index);
+    else   // (private paths: compact tables inside the records)
+        hipLaunchKernelGGL(path_index_compact_kernel, dim3(stride_grid(max_entries * 2 * kPathBucketsCompact, 256, sel.list != nullptr)), dim3(256), 0,
+                           s, h->path_src, p.lens, p.max_len, sel, h->dev.sp_prune, h->path_bbox);
     launch_world_records(h, sel, max_entries, s);
 }
 
@@ -1546,7 +1550,7 @@ extern "C" int bcp_set_paths(bcp_handle* h, const double* xytheta, const int32_t
         HIP_TRY(hipMalloc((void**)&h->path_bbox, bb_bytes));
         h->path_bbox_bytes = bb_bytes;
     }
-    const size_t ix_bytes = (size_t)n_paths * 4 * kPathBuckets * sizeof(int16_t);
+    const size_t ix_bytes = (size_t)4 * kPathBuckets * sizeof(int16_t);   // (a shared path's tables; private ones live in the records)
     if (ix_bytes > h->path_index_bytes) {
         if (h->path_index) HIP_TRY(hipFree(h->path_index));
         h->path_index = nullptr;
