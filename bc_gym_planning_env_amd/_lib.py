@@ -13,7 +13,7 @@ REWARD_CONTINUOUS, REWARD_PURE_PURSUIT = 0, 1
 STEP_AUTO_RESET, STEP_ACTIONS_F32 = 1, 2
 ERR_ANGLE_JUMP, ERR_TIME_ORDER, ERR_INTERNAL = 1, 2, 4
 TUNE_EXACT_MODE, TUNE_DENSE_THRESHOLD, TUNE_CULL, TUNE_DEFER, TUNE_EDT_LDS, TUNE_FUSED, TUNE_EGO_SPARSE, TUNE_NEAR_DILATE = 0, 1, 2, 3, 4, 5, 6, 7
-TUNE_LOCAL_PAIRS, TUNE_EGO_LIST_STRIDE = 8, 9
+TUNE_LOCAL_PAIRS, TUNE_EGO_LIST_STRIDE, TUNE_NEAR_SHIFT = 8, 9, 10
 E_NO_DEVICE = -2
 OPT_DIFFDRIVE_NOISE = 1
 EGO_KERNELS = {0: "none", 1: "ego_sparse_kernel", 2: "ego_costmap_kernel<staged>", 3: "ego_costmap_binned_kernel",

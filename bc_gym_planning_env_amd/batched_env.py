@@ -569,12 +569,13 @@ class BatchedPlanEnv(object):
         return env
 
     def set_tuning(self, exact_mode=None, dense_threshold=None, cull=None, defer=None, edt_lds=None, fused=None,
-                   ego_sparse=None, near_dilate=None, local_pairs=None, ego_list_stride=None):
-        """Execution knobs of libbcplan (bcp_set_tuning); results never depend on them."""
+                   ego_sparse=None, near_dilate=None, local_pairs=None, ego_list_stride=None, near_shift=None):
+        """Execution knobs of libbcplan (bcp_set_tuning); results never depend on them.
+        (near_shift takes effect when the costmaps are bound the next time.)"""
         for key, val in ((_lib.TUNE_EXACT_MODE, exact_mode), (_lib.TUNE_DENSE_THRESHOLD, dense_threshold),
                          (_lib.TUNE_CULL, cull), (_lib.TUNE_DEFER, defer), (_lib.TUNE_EDT_LDS, edt_lds),
                          (_lib.TUNE_FUSED, fused), (_lib.TUNE_EGO_SPARSE, ego_sparse), (_lib.TUNE_LOCAL_PAIRS, local_pairs), (_lib.TUNE_EGO_LIST_STRIDE, ego_list_stride),
-                         (_lib.TUNE_NEAR_DILATE, near_dilate)):
+                         (_lib.TUNE_NEAR_DILATE, near_dilate), (_lib.TUNE_NEAR_SHIFT, near_shift)):
             if val is not None:
                 _lib.check(self._lib.bcp_set_tuning(self._h, key, int(val)))
 

@@ -42,6 +42,13 @@ struct CullDesc {
     const uint32_t* near;
     int64_t near_stride;  // words per env (0: shared)
     int32_t near_tx, near_words;   // tiles per tile row; words of one entry
+    // What step_local_kernel's outer test reads: `near` itself (shift 0), or a copy at 1/2 or 1/4 of the resolution -- a bit
+    // of it is the OR of the 2 x 2 / 4 x 4 cells it stands for (near_coarsen_kernel), so "not near" still holds for every
+    // one of them.  A 128-byte line then covers 64 x 64 / 128 x 128 cells: the samples of a pose meet fewer lines (each a
+    // full line of memory traffic for maps that do not stay in cache), at the price of a few more undecided poses.
+    const uint32_t* step_near;
+    int64_t step_near_stride;
+    int32_t step_near_tx, step_near_shift;
 };
 
 enum { kFree = 0, kHit = 1, kAmbiguous = 2 };
@@ -111,7 +118,7 @@ __device__ __forceinline__ OuterLookups outer_lookups_issue(const CullDesc& C, i
 // What the outer test needs of a CullDesc, as a value: a kernel fetches it (scalar loads) before its barriers, so that
 // the loads are not queued behind them on the critical path.
 struct OuterParams {
-    int32_t reach, pad, width, height, n_out, near_tx, t_out;
+    int32_t reach, pad, width, height, n_out, near_tx, near_shift, t_out;
     double out_x[kMaxSamples], axis_y;
 };
 
@@ -124,6 +131,7 @@ __device__ __forceinline__ OuterParams outer_params(const CullDesc& C)
     o.height = C.height;
     o.n_out = C.n_out;
     o.near_tx = C.near_tx;
+    o.near_shift = 0;
     o.t_out = C.t_out;
 #pragma unroll
     for (int i = 0; i < kMaxSamples; ++i) o.out_x[i] = C.out_x[i];
@@ -178,8 +186,9 @@ __device__ __forceinline__ int classify_near(const OuterParams& C, WordPtr tiles
         const float ox = (float)C.out_x[i];
         const int x = x0 + (int)rintf(fmaf(ox, cf, -ay_s)), y = y0 + (int)rintf(fmaf(ox, sf, ay_c));
         const bool stored = (i < C.n_out) & ((unsigned)x < (unsigned)C.width) & ((unsigned)y < (unsigned)C.height);
-        const int at = ((y >> 5) * C.near_tx + (x >> 5)) * 32 + (y & 31);
-        bit[i] = stored ? (x & 31) : 32;
+        const int xs = x >> C.near_shift, ys = y >> C.near_shift;   // (the tiles may be at a fraction of the resolution)
+        const int at = ((ys >> 5) * C.near_tx + (xs >> 5)) * 32 + (ys & 31);
+        bit[i] = stored ? (xs & 31) : 32;
         word[i] = tiles[stored ? at : 0];
     }
     // a sample outside the stored (padded) rectangle is more than `pad` px away from every cell of the map

@@ -1916,9 +1916,11 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
         // (3a) collision: distance-field classification; an undecided env is parked below
         // (its parameters are read from the LDS copy of *S here, where they are used: held from barrier 0 on they cost
         //  25 vector registers across the robot model)
-        const OuterParams outer = outer_params(*(const CullDesc*)&SL->cull);
+        OuterParams outer = outer_params(*(const CullDesc*)&SL->cull);
+        outer.near_tx = SL->cull.step_near_tx;
+        outer.near_shift = SL->cull.step_near_shift;
         const double map_inv_res = SL->map.inv_res;
-        const int64_t near_stride = SL->cull.near_stride;
+        const int64_t near_stride = SL->cull.step_near_stride;
         const double org_x = own_origin ? own_org_x : SL->map.ox, org_y = own_origin ? own_org_y : SL->map.oy;
         const int64_t g = slot_of(SL, i, q);
         const int px = (int)rint((r.p.x - org_x) * map_inv_res);  // world_to_pixel, coordinate_transformations.py:185-205

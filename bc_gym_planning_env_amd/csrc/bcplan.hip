@@ -60,6 +60,9 @@ struct bcp_handle {
     double resolution;
     uint32_t* bitmap;      // owned
     size_t bitmap_bytes;
+    uint32_t* near_coarse; // owned: CullDesc::step_near when it is not the tiles themselves
+    size_t near_coarse_bytes;
+    int32_t near_shift;    // BCP_NEAR_SHIFT / BCP_TUNE_NEAR_SHIFT: resolution of step_near for private maps (-1: the library's rule)
     uint32_t* map_tiles;   // owned: the bitmap once more in tiles of 32 x 32 cells (MapDesc::tiles)
     size_t map_tiles_bytes;
     double* path5;         // owned
@@ -480,6 +483,33 @@ __global__ void near_tiles_kernel(const uint8_t* __restrict__ edt, EntrySelect s
             }
         }
         tiles[e * per + ((int64_t)(y >> 5) * tiles_x + tx) * 32 + (y & 31)] = word;
+    }
+}
+
+// CullDesc::step_near: the tiles at 1 / 2^shift of the resolution, a bit = the OR of the 2^shift x 2^shift bits it stands
+// for.  One thread per output word: 2^shift rows of 2^shift neighbouring tiles, OR-ed and squeezed.
+__global__ void near_coarsen_kernel(const uint32_t* __restrict__ tiles, EntrySelect sel, int tiles_x, int tiles_y, int shift,
+                                    int ctx, int cty, uint32_t* __restrict__ coarse)
+{
+    const int64_t per = (int64_t)tiles_x * tiles_y * 32, cper = (int64_t)ctx * cty * 32, total = sel.size() * cper;
+    const int f = 1 << shift, bits_out = 32 >> shift;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = sel.entry(it / cper);
+        const int k = (int)(it % cper);
+        const int Y = (k / (32 * ctx)) * 32 + (k & 31), TX = (k >> 5) % ctx;   // coarse row, coarse tile column
+        uint32_t word = 0;
+        for (int part = 0; part < f; ++part) {          // fine tile column part of this coarse word
+            const int tx = TX * f + part;
+            uint32_t rows = 0;
+            for (int dy = 0; dy < f; ++dy) {
+                const int y = Y * f + dy;
+                if (tx < tiles_x && y < tiles_y * 32) rows |= tiles[e * per + ((int64_t)(y >> 5) * tiles_x + tx) * 32 + (y & 31)];
+            }
+            uint32_t squeezed = 0;
+            for (int b = 0; b < bits_out; ++b) squeezed |= (uint32_t)(((rows >> (b << shift)) & ((1u << f) - 1u)) != 0) << b;
+            word |= squeezed << (part * bits_out);
+        }
+        coarse[e * cper + k] = word;
     }
 }
 
@@ -1050,6 +1080,11 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->ego_sparse = 1;
     h->ego_cells_max = -1;
     h->static_dirty = true;
+    h->near_shift = -1;
+    if (const char* e = getenv("BCP_NEAR_SHIFT")) {   // (default of BCP_TUNE_NEAR_SHIFT for every handle of the process)
+        const int v = atoi(e);
+        if (v >= 0 && v <= 2) h->near_shift = v;
+    }
     if (const char* e = getenv("BCP_LOCAL_PAIRS")) {   // (default of BCP_TUNE_LOCAL_PAIRS for every handle of the process)
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4) h->local_pairs = v;
@@ -1070,6 +1105,7 @@ extern "C" int bcp_destroy(bcp_handle* h)
     (void)hipSetDevice(h->device);
     if (h->bitmap) (void)hipFree(h->bitmap);
     if (h->map_tiles) (void)hipFree(h->map_tiles);
+    if (h->near_coarse) (void)hipFree(h->near_coarse);
     if (h->path5) (void)hipFree(h->path5);
     if (h->path_pre) (void)hipFree(h->path_pre);
     if (h->path_bbox) (void)hipFree(h->path_bbox);
@@ -1170,6 +1206,10 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
         case BCP_TUNE_FUSED:
             h->fused = value ? 1 : 0;
             return BCP_OK;
+        case BCP_TUNE_NEAR_SHIFT:
+            if (value < -1 || value > 2) return fail(BCP_E_INVALID, "bcp_set_tuning: BCP_TUNE_NEAR_SHIFT takes -1 (default), 0, 1 or 2");
+            h->near_shift = value;   // (in force from the next bcp_set_costmaps on)
+            return BCP_OK;
         case BCP_TUNE_LOCAL_PAIRS:
             if (value != 0 && value != 1 && value != 2 && value != 4)
                 return fail(BCP_E_INVALID, "bcp_set_tuning: BCP_TUNE_LOCAL_PAIRS takes 0 (default), 1, 2 or 4");
@@ -1258,6 +1298,21 @@ static void launch_edt(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipS
                        sel, C.width, C.height, C.clamp, h->edt);
 }
 
+// CullDesc::step_near of private maps unless BCP_TUNE_NEAR_SHIFT says otherwise: a quarter of the resolution (measured on one
+// box, shift 0 / 1 / 2: one private 64 x 64 world per env 821 / 751 / 719 bytes of memory traffic per env-step and 21.1 / 20.6 /
+// 20.6 us per step; 65 536 private 256 x 141 aisle maps 2.58 / 2.53 / 2.60e9 env-steps/s -- profiles/r04_near_shift.txt)
+constexpr int kNearShiftPrivate = 2;
+
+static void launch_near_coarse(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)
+{
+    const CullDesc& C = h->cull;
+    if (!C.near || C.step_near_shift == 0) return;
+    const int tiles_y = C.near_words / (32 * C.near_tx);
+    const int cty = (int)(C.step_near_stride / (32 * C.step_near_tx));   // (private maps only: the stride is an entry's words)
+    hipLaunchKernelGGL(near_coarsen_kernel, dim3(stride_grid(max_entries * C.step_near_tx * cty * 32, 256, sel.list != nullptr)), dim3(256),
+                       0, s, h->near, sel, C.near_tx, tiles_y, C.step_near_shift, C.step_near_tx, cty, h->near_coarse);
+}
+
 // Distance field + tiles of the selected entries.  `tiles_only`: the caller's consumers read nothing but the tiles (a pool
 // refresh under the single-launch step) -- when near_dilate_kernel can serve the maps, the uint8 field is left stale and
 // marked so; ensure_fields() brings it up to date for whoever asks for it later.
@@ -1265,12 +1320,14 @@ static int launch_distance_field(bcp_handle* h, EntrySelect sel, int64_t max_ent
 {
     if (tiles_only && h->near_dilate >= 1 && near_dilate_lds(h) && h->edt_stale && h->edt_stale_cap >= n_slots(h)) {
         launch_near_dilate(h, sel, max_entries, h->edt_stale, s);
+        launch_near_coarse(h, sel, max_entries, s);
         h->edt_lazy = true;
         return BCP_OK;
     }
     launch_edt(h, sel, max_entries, s);
     launch_near_tiles(h, sel, max_entries, s);
     if (h->near_dilate == 2 && near_dilate_lds(h)) launch_near_dilate(h, sel, max_entries, nullptr, s);
+    launch_near_coarse(h, sel, max_entries, s);
     return BCP_OK;
 }
 
@@ -1422,6 +1479,29 @@ extern "C" int bcp_set_costmaps(bcp_handle* h, const uint8_t* data, int32_t rows
         C.near_tx = tiles_x;
         C.near_words = tiles_x * tiles_y * 32;
         C.near_stride = shared ? 0 : (int64_t)C.near_words;
+        // what the single-launch step reads: the tiles themselves for a shared map (it stays in cache), a coarser copy for
+        // private maps -- see CullDesc::step_near
+        const int shift = shared ? 0 : (h->near_shift >= 0 ? h->near_shift : kNearShiftPrivate);
+        C.step_near = h->near;
+        C.step_near_stride = C.near_stride;
+        C.step_near_tx = tiles_x;
+        C.step_near_shift = 0;
+        if (shift > 0) {
+            const int cw = (W + (1 << shift) - 1) >> shift, ch = (H + (1 << shift) - 1) >> shift;
+            const int ctx = (cw + 31) / 32, cty = (ch + 31) / 32;
+            const size_t coarse_bytes = (size_t)n_maps * ctx * cty * 32 * sizeof(uint32_t);
+            if (coarse_bytes > h->near_coarse_bytes) {
+                if (h->near_coarse) HIP_TRY(hipFree(h->near_coarse));
+                h->near_coarse = nullptr;
+                h->near_coarse_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&h->near_coarse, coarse_bytes));
+                h->near_coarse_bytes = coarse_bytes;
+            }
+            C.step_near = h->near_coarse;
+            C.step_near_stride = (int64_t)ctx * cty * 32;
+            C.step_near_tx = ctx;
+            C.step_near_shift = shift;
+        }
         C.edt = h->edt;
         C.width = W;
         C.height = H;
@@ -1756,7 +1836,7 @@ static int launch_step(bcp_handle* h, const bcp_step_io* io, uint32_t flags, hip
     hot.map_wpr = S.map.wpr;
     hot.map_shared = S.map.shared;
     hot.path_max_len = S.path.max_len;
-    hot.near = S.cull.on ? S.cull.near : nullptr;
+    hot.near = S.cull.on ? S.cull.step_near : nullptr;
     hot.noise_on = S.P.noise_on;
     hot.n_verts = S.P.n_verts;
     hot.control_delay = S.P.control_delay;

@@ -190,10 +190,16 @@ int bcp_seed(bcp_handle *h, uint64_t seed);
  *   BCP_TUNE_EGO_LIST_STRIDE  0 (default) = the cell lists of the sparse egocentric route are sized from the counted cells;
  *                             a multiple of 64 = this many cells per map entry: an entry with more is drawn pixel by pixel
  *                             inside the same launch (what happens to a pool entry that is re-sampled with more cells than
- *                             the lists were sized for; the knob lets tests reach that path) */
+ *                             the lists were sized for; the knob lets tests reach that path)
+ *   BCP_TUNE_NEAR_SHIFT       resolution of the 1-bit tiles the single-launch step classifies poses on when the costmaps are
+ *                             private: 0 = the tiles of bcp_get_near_field, 1 / 2 = a copy at 1/2 / 1/4 of the resolution (a
+ *                             bit is the OR of the 2 x 2 / 4 x 4 cells it stands for: fewer lines of memory per pose, a few more
+ *                             poses left to the exact test); -1 (default) = the library's choice.  In force from the next
+ *                             bcp_set_costmaps on; results are the same bit for bit.  (Environment variable BCP_NEAR_SHIFT,
+ *                             read by bcp_create: the knob's initial value.) */
 enum { BCP_TUNE_EXACT_MODE = 0, BCP_TUNE_DENSE_THRESHOLD = 1, BCP_TUNE_CULL = 2, BCP_TUNE_DEFER = 3, BCP_TUNE_EDT_LDS = 4,
        BCP_TUNE_FUSED = 5, BCP_TUNE_EGO_SPARSE = 6, BCP_TUNE_NEAR_DILATE = 7, BCP_TUNE_LOCAL_PAIRS = 8,
-       BCP_TUNE_EGO_LIST_STRIDE = 9 };
+       BCP_TUNE_EGO_LIST_STRIDE = 9, BCP_TUNE_NEAR_SHIFT = 10 };
 int bcp_set_tuning(bcp_handle *h, int32_t key, int32_t value);
 
 /* ---- static per-episode inputs ------------------------------------------------------------------------ */
