@@ -369,7 +369,8 @@ def test_diffdrive_shared_64x64_vs_oracle(torch_cuda, oracle):
 
 
 @pytest.mark.parametrize("mode", [dict(), dict(fused=0), dict(defer=0), dict(cull=0, exact_mode=1), dict(cull=0, exact_mode=2),
-                                  dict(dense_threshold=0), dict(dense_threshold=64)],
+                                  dict(dense_threshold=0), dict(dense_threshold=64), dict(near_shift=0), dict(near_shift=1),
+                                  dict(near_shift=2)],
                          ids=lambda m: "-".join("%s%d" % (k[:4], v) for k, v in sorted(m.items())) or "default")
 def test_private_maps_and_paths_vs_oracle(torch_cuda, oracle, mode):
     """C4 shape at reduced N: per-env costmaps (different shapes, padded) and per-env paths of different length,
@@ -401,6 +402,8 @@ def test_private_maps_and_paths_vs_oracle(torch_cuda, oracle, mode):
     for i, p_ in enumerate(paths):
         pbuf[i, :len(p_)] = p_
     # give the HIP path the poisoned maps as well
+    if "near_shift" in mode:   # (resolution of the tiles the step classifies on: in force from the next binding of the maps)
+        env.set_tuning(near_shift=mode["near_shift"])
     env.set_costmap_tensors(torch.from_numpy(maps).cuda(), torch.from_numpy(origins).cuda(), res,
                             torch.from_numpy(vr).cuda(), torch.from_numpy(vc).cuda())
     env.set_tuning(**mode)
