@@ -350,7 +350,7 @@ def aux_other_configs(device):
                                             "quotient_of_peak": survey / HBM_PEAK_GBS, "not_a_utilisation": True,
                                             "note": "SURVEY 8(d)'s 163 B state I/O + 900 footprint cells of the private uint8 map + "
                                                     "3120 B of private path per env-step; the kernel reads 1-bit lethal masks, 1-bit "
-                                                    "distance tiles, float32 prefilter records and a bucketed path window instead and "
+                                                    "distance tiles, 8-byte quantised prefilter records and a bucketed path window instead and "
                                                     "does not move these bytes"}}}
     env.close()
     return out
