@@ -439,14 +439,14 @@ struct CoopCollisionSink {
         c_lo = px + umin;
         c_hi = px + umax;
     }
-    // Loads the lane's row once per chunk; returns whether ANY row of the chunk holds a lethal cell under the image.
-    __device__ __forceinline__ bool chunk_matters(int y, bool valid)
+    // The lane's row of one chunk, as stored: the words that hold map columns c_lo .. c_hi (the rest zero).  In two halves, so
+    // that a caller can put work between the loads and their use (coop_collides_sparse: the edge parameters).
+    __device__ __forceinline__ void load_row(int y, bool valid, uint32_t raw[NW + 1]) const
     {
         const int r = py + y;
         const int w0 = c_lo >> 5;  // arithmetic shift: floor
         const int sh = c_lo & 31;
         const bool row_ok = valid && (unsigned)r < (unsigned)n_rows;
-        uint32_t raw[NW + 1];
         const int width = c_hi - c_lo + 1;  // columns beyond the image never matter
         const int last_w = (sh + width - 1) >> 5;   // (... nor do the words that only hold such columns)
 #pragma unroll
@@ -455,6 +455,18 @@ struct CoopCollisionSink {
             const int at = TILED ? (((r >> 5) * wpr + wi) << 5) + (r & 31) : r * wpr + wi;
             raw[w] = (row_ok && w <= last_w && (unsigned)wi < (unsigned)wpr) ? words[at] : 0u;
         }
+    }
+    // Loads the lane's row once per chunk; returns whether ANY row of the chunk holds a lethal cell under the image.
+    __device__ __forceinline__ bool chunk_matters(int y, bool valid)
+    {
+        uint32_t raw[NW + 1];
+        load_row(y, valid, raw);
+        return rows_matter(raw);
+    }
+    __device__ __forceinline__ bool rows_matter(const uint32_t raw[NW + 1])
+    {
+        const int sh = c_lo & 31;
+        const int width = c_hi - c_lo + 1;
         uint32_t any = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
@@ -580,6 +592,13 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 q
     vmax = bcast_i(vmax, 0);
     umin = bcast_i(umin, 0);
     umax = bcast_i(umax, 0);
+    // the lethal words of the image's first 64 rows are asked for right away: with the map in global memory (private maps)
+    // their round trip -- 1.6 k cycles of a 3.9 k-cycle test on C4 -- then runs under the edge parameters below
+    CoopCollisionSink<NW, WordPtr, TILED> sink{words, rows, cols, wpr, px, py, 0, 0};
+    sink.extent(umin, umax);
+    // (a map in LDS is read where it is used, as before: asked for early its words only sit in registers -- C3 0.8 % slower)
+    uint32_t first_rows[NW + 1];
+    if constexpr (TILED) sink.load_row(vmin + lane, vmin + lane <= vmax, first_rows);
     // span edge (CollectPolyEdges): active for y0 <= y < y1, x in 16.16 from the end with the smaller y
     const int ddy = v - vp;
     const int y0 = min(v, vp), y1 = owner ? max(v, vp) : y0;
@@ -599,8 +618,6 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 q
     if (!owner) dy = -1;        // inert: no run on any row
     // ---- the lethal cells under the image's columns, all row chunks into one list (lane = row of the chunk; the order
     //      of the cells does not matter, so a lane just reserves room for its row's cells with one LDS atomic)
-    CoopCollisionSink<NW, WordPtr, TILED> sink{words, rows, cols, wpr, px, py, 0, 0};
-    sink.extent(umin, umax);
 #ifdef BCP_DIAG
     if (phase) phase[0] = __builtin_amdgcn_s_memtime();   // the edges are set up
 #endif
@@ -609,7 +626,8 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 q
     const int n_chunks = (vmax - vmin) / 64 + 1;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const int y_row = vmin + 64 * chunk + lane;
-        if (!sink.chunk_matters(y_row, y_row <= vmax)) continue;   // (loads the lane's row; wave-uniform result)
+        // (the lane's row of the chunk; wave-uniform result)
+        if (!((TILED && chunk == 0) ? sink.rows_matter(first_rows) : sink.chunk_matters(y_row, y_row <= vmax))) continue;
         int count = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) count += (int)__popc(sink.leth[w]);

@@ -1,7 +1,10 @@
 """Informational timing of the geometry-pool configuration: 65 536 RandomMiniEnv instances, every reset moving the
 env to the next pre-sampled world of its chain.  Usage: python tools/bench_pool.py [n] [chains] [episodes]"""
-import sys, time, numpy as np, torch
+import sys, os, time, numpy as np, torch
 sys.path.insert(0, '.')
+from bc_gym_planning_env_amd import _lib
+if os.environ.get('BCP_LIB'):   # A/B of kernel variants: another build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ['BCP_LIB'])
 from bc_gym_planning_env_amd import mini_env
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
