@@ -41,6 +41,7 @@ struct DevParams {
     float qbox[4];                    // bounding box of qverts in the robot frame: xmin, xmax, ymin, ymax (pixels)
     int32_t reward_provider;          // BCP_REWARD_*
     int32_t control_delay, pose_delay, state_delay;   // EnvParams delays (envs/base/params.py:28-30)
+    float ap_cos_min;                 // cos(ap) - 1e-4 (-2 when ap >= pi): the heading test of the quantised prefilter records
 };
 
 // numpy float `%`: the result takes the sign of the divisor (npy_divmod)

@@ -576,7 +576,12 @@ __device__ __forceinline__ int coop_last_reached(const DevParams& P, LdsF64 path
 // difference is within 0.52 step of the true one, the distance within 0.74 -- the position limits carry +1.  "Not behind the
 // way point" (path_tools.py:405): cos and sin are off by 1.53e-5 each, times a difference of at most kQuantReach + 1 steps =
 // 0.25 step per term, plus 0.52 (|cos| + |sin|) <= 0.74 for the differences and ~0.002 of float32 rounding: below 1.3 -- the
-// limit carries -2.  So whatever the prefilter rejects fails the float64 test too: the result is the exact scan's, bit for bit.
+// limit carries -2.  The heading (path_tools.py:419, |normalize(th - th_j)| < ap  <=>  cos(th - th_j) > cos ap for ap < pi): the
+// cosine of the difference from the record's cos / sin and float32 cos / sin of the pose's heading is within 2.5e-5 of the true
+// one -- its limit, DevParams::ap_cos_min, carries -1e-4.  (Without it a pose that is near a way point but turned away from it
+// went through the exact test of every such way point, one memory round trip each: the waves that scan the part of the window
+// next to the target took 9 k cycles longer than the others on C4.)
+// So whatever the prefilter rejects fails the float64 test too: the result is the exact scan's, bit for bit.
 #ifndef BCP_PREFILTER_TRIP
 #define BCP_PREFILTER_TRIP 8
 #endif
@@ -591,6 +596,9 @@ __device__ __forceinline__ int last_reached_prefiltered(const DevParams& P, cons
     const float xr = (float)((x - ox) * inv), yr = (float)((y - oy) * inv);
     const float lim = (float)(P.sp * inv) + 1.0f, par_min = (float)(P.par_thr * inv) - 2.0f;
     const float q_max = lim * lim * 1.000001f;
+    float sin_th, cos_th;
+    sincosf((float)th, &sin_th, &cos_th);
+    const float cos_min = P.ap_cos_min * 32767.0f;
     constexpr int TRIP = BCP_PREFILTER_TRIP;
     for (int j = hi; j >= lo; j -= TRIP) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -604,7 +612,8 @@ __device__ __forceinline__ int last_reached_prefiltered(const DevParams& P, cons
             const float dx = (float)(p[u].x & 0xFFFFu) - xr, dy = (float)(p[u].x >> 16) - yr;
             const float qc = (float)(int16_t)(p[u].y & 0xFFFFu), qs = (float)((int32_t)p[u].y >> 16);
             const float par = -(qc * dx + qs * dy) * (1.0f / 32767.0f);
-            const bool out = fabsf(dx) > lim || fabsf(dy) > lim || dx * dx + dy * dy > q_max || par < par_min || j - u < lo;
+            const bool out = fabsf(dx) > lim || fabsf(dy) > lim || dx * dx + dy * dy > q_max || par < par_min ||
+                             qc * cos_th + qs * sin_th < cos_min || j - u < lo;
             maybe |= (uint32_t)!out << u;
         }
         while (maybe) {

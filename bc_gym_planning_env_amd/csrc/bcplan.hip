@@ -1013,6 +1013,7 @@ static void fill_dev_params(bcp_handle* h)
     d.ap = p.angular_precision;
     d.progress_mult = p.spatial_progress_multiplier;
     d.par_thr = -p.spatial_precision / 9;
+    d.ap_cos_min = p.angular_precision >= 3.14159265358979 ? -2.0f : (float)(std::cos(p.angular_precision) - 1e-4);
     d.sp_prune = std::nextafter(std::nextafter(p.spatial_precision, INFINITY), INFINITY);
     d.sp2_lo = p.spatial_precision * p.spatial_precision * (1.0 - 1e-13);
     d.sp2_hi = p.spatial_precision * p.spatial_precision * (1.0 + 1e-13);

@@ -431,7 +431,7 @@ def test_private_maps_and_paths_vs_oracle(torch_cuda, oracle, mode):
 def test_private_path_prefilter_boundary_poses_vs_oracle(torch_cuda, oracle):
     """The scan of a private path goes through 8-byte quantised prefilter records (uint16 x, y in steps from the corner of
     the path's box, int16 cos / sin; `last_reached_prefiltered`): poses ON the limits of find_last_reached
-    (utilities/path_tools.py:408-448) -- the spatial precision, "not behind the way point" at -sp / 9 -- relative to a way
+    (utilities/path_tools.py:408-448) -- the spatial precision, "not behind the way point" at -sp / 9, the angular precision -- relative to a way
     point, to within 1e-10 .. 1e-3 either side, on paths from 2 cm to 60 m across, at the origin and 100 m away from it,
     must come out as the float64 scan has them."""
     torch = torch_cuda
@@ -486,6 +486,10 @@ def test_private_path_prefilter_boundary_poses_vs_oracle(torch_cuda, oracle):
         st[0] = wp[:, 0] + par * c - perp * s_
         st[1] = wp[:, 1] + par * s_ + perp * c
         st[2] = wp[:, 2] + rng.uniform(-1.7, 1.7, n)
+        # every fourth env: well inside the circle, in front, the heading on the angular limit (1 + d) either side
+        turn = (np.arange(n) % 4 == 3) & (kind == 1)
+        ap = float(p.angular_precision)
+        st[2] = np.where(turn, wp[:, 2] + rng.choice([-1.0, 1.0], n) * ap * (1 + d), st[2])
         tgt = np.clip(k - rng.randint(0, 6, n), 0, lens - 1).astype(np.int32)
         md = np.full(n, 1e3)
         env.state.robot.copy_(torch.from_numpy(st))
