@@ -1084,7 +1084,7 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     h->near_shift = -1;
     if (const char* e = getenv("BCP_NEAR_SHIFT")) {   // (default of BCP_TUNE_NEAR_SHIFT for every handle of the process)
         const int v = atoi(e);
-        if (v >= 0 && v <= 2) h->near_shift = v;
+        if (v >= 0 && v <= 3) h->near_shift = v;
     }
     if (const char* e = getenv("BCP_LOCAL_PAIRS")) {   // (default of BCP_TUNE_LOCAL_PAIRS for every handle of the process)
         const int v = atoi(e);
@@ -1208,7 +1208,7 @@ extern "C" int bcp_set_tuning(bcp_handle* h, int32_t key, int32_t value)
             h->fused = value ? 1 : 0;
             return BCP_OK;
         case BCP_TUNE_NEAR_SHIFT:
-            if (value < -1 || value > 2) return fail(BCP_E_INVALID, "bcp_set_tuning: BCP_TUNE_NEAR_SHIFT takes -1 (default), 0, 1 or 2");
+            if (value < -1 || value > 3) return fail(BCP_E_INVALID, "bcp_set_tuning: BCP_TUNE_NEAR_SHIFT takes -1 (default), 0, 1, 2 or 3");
             h->near_shift = value;   // (in force from the next bcp_set_costmaps on)
             return BCP_OK;
         case BCP_TUNE_LOCAL_PAIRS:
@@ -1301,7 +1301,8 @@ static void launch_edt(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipS
 
 // CullDesc::step_near of private maps unless BCP_TUNE_NEAR_SHIFT says otherwise: a quarter of the resolution (measured on one
 // box, shift 0 / 1 / 2: one private 64 x 64 world per env 821 / 751 / 719 bytes of memory traffic per env-step and 21.1 / 20.6 /
-// 20.6 us per step; 65 536 private 256 x 141 aisle maps 2.58 / 2.53 / 2.60e9 env-steps/s -- profiles/r04_near_shift.txt)
+// 20.6 us per step; 65 536 private 256 x 141 aisle maps 2.58 / 2.53 / 2.60e9 env-steps/s -- profiles/r04_near_shift.txt;
+// shift 3, an eighth: 687 bytes, but 19.6 against 19.1 us and the aisle maps 2.24e9 -- more poses go to the exact test)
 constexpr int kNearShiftPrivate = 2;
 
 static void launch_near_coarse(bcp_handle* h, EntrySelect sel, int64_t max_entries, hipStream_t s)

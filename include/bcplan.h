@@ -192,8 +192,8 @@ int bcp_seed(bcp_handle *h, uint64_t seed);
  *                             inside the same launch (what happens to a pool entry that is re-sampled with more cells than
  *                             the lists were sized for; the knob lets tests reach that path)
  *   BCP_TUNE_NEAR_SHIFT       resolution of the 1-bit tiles the single-launch step classifies poses on when the costmaps are
- *                             private: 0 = the tiles of bcp_get_near_field, 1 / 2 = a copy at 1/2 / 1/4 of the resolution (a
- *                             bit is the OR of the 2 x 2 / 4 x 4 cells it stands for: fewer lines of memory per pose, a few more
+ *                             private: 0 = the tiles of bcp_get_near_field, 1 / 2 / 3 = a copy at 1/2, 1/4, 1/8 of the resolution (a
+ *                             bit is the OR of the 2 x 2 / 4 x 4 / 8 x 8 cells it stands for: fewer lines of memory per pose, a few more
  *                             poses left to the exact test); -1 (default) = the library's choice.  In force from the next
  *                             bcp_set_costmaps on; results are the same bit for bit.  (Environment variable BCP_NEAR_SHIFT,
  *                             read by bcp_create: the knob's initial value.) */

@@ -370,7 +370,7 @@ def test_diffdrive_shared_64x64_vs_oracle(torch_cuda, oracle):
 
 @pytest.mark.parametrize("mode", [dict(), dict(fused=0), dict(defer=0), dict(cull=0, exact_mode=1), dict(cull=0, exact_mode=2),
                                   dict(dense_threshold=0), dict(dense_threshold=64), dict(near_shift=0), dict(near_shift=1),
-                                  dict(near_shift=2)],
+                                  dict(near_shift=2), dict(near_shift=3)],
                          ids=lambda m: "-".join("%s%d" % (k[:4], v) for k, v in sorted(m.items())) or "default")
 def test_private_maps_and_paths_vs_oracle(torch_cuda, oracle, mode):
     """C4 shape at reduced N: per-env costmaps (different shapes, padded) and per-env paths of different length,
