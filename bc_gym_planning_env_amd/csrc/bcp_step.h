@@ -989,9 +989,8 @@ template <bool PLAIN, typename A, typename SP>
 __device__ __forceinline__ void finalize_env_from(const A& a, SP S, int64_t i, Pending& q, bool hit, LdsF64 lds_path = nullptr,
                                              const PathWindow* free_window = nullptr, bool have_score = false,
                                              ScoredFree score = ScoredFree(), int known_len = -1, bool score_fits_hit = false,
-                                             int64_t out_base = 0, bool have_init = false, InitAhead init_ahead = InitAhead())
-{   // (have_init: `init_ahead` holds this lane's initial state, fetched by the caller while it waited for something else;
-    //  the score travels by value: a pointer to a local made the compiler keep it in scratch memory;
+                                             int64_t out_base = 0)
+{   // (the score travels by value: a pointer to a local made the compiler keep it in scratch memory;
     //  out_base: element offset of this step's rows in the output arrays -- step k of a rollout writes row k, bcp_rollout --;
     //  known_len >= 0: the caller already holds the length of this env's path;
     //  score_fits_hit: `score` was computed for the rolled-back pose of a colliding env -- continuous provider only)
@@ -1072,8 +1071,7 @@ __device__ __forceinline__ void finalize_env_from(const A& a, SP S, int64_t i, P
             k = S->next_geom ? as_global(S->next_geom)[g] : g;
             as_global(S->geom_of_env)[i] = (int32_t)k;
         }
-        InitAhead ahead = init_ahead;
-        if (!have_init) ahead = fetch_init_ahead(S, k, tri);
+        const InitAhead ahead = fetch_init_ahead(S, k, tri);
         r.p.x = ahead.x;
         r.p.y = ahead.y;
         r.p.th = ahead.th;
@@ -2162,8 +2160,6 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
     sc.rew = 0.0;
     sc.min_dist = 0.0;
     sc.target = 0;
-    InitAhead init_ahead = InitAhead();   // (see below: the initial state of an env that may end its episode)
-    bool have_init = false;
     if (mover) {
         if (PLAIN) {
             const __attribute__((address_space(3))) int32_t* found = (__attribute__((address_space(3))) int32_t*)hand_score;
@@ -2183,18 +2179,6 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
             sc.target = (int)hand_score[2 * kBlock + lane];
         }
         DIAG_STAMP(6);    // mover: reward provider done
-        // An env that ends its episode restarts from its initial state (in-kernel reset): eleven loads that finalize_env_from
-        // issued behind the verdicts, a round trip at the very end of the step in every wave that holds such an env -- more
-        // than half of them on the metric workload.  Which envs MAY end is known here: goal reached, time-out, already
-        // collided, or parked (its pose may collide).  The mover is about to wait for verdicts, so it asks for their initial
-        // states now and finds them in registers when it finishes its envs.  (Round 3 fetched them at the top of the step for the
-        // envs that time out: the loads then sat on the chain, 12.24 against 12.00 us.  Geometry pools: the entry to restart from
-        // is next_geom[entry], one more dependent load -- left to finalize_env_from.)
-        if (PLAIN && (L.flags & BCP_STEP_AUTO_RESET) && !SL->geom_of_env && active &&
-            (park || q.collided != 0 || q.iter + 1 >= P.iteration_timeout || sc.target > my_len - 1)) {
-            init_ahead = fetch_init_ahead(SL, i, P.model == BCP_MODEL_TRICYCLE);
-            have_init = true;
-        }
         // (Round 4: the envs are finished in ONE pass at the end, the decided ones together with the parked ones.  Rounds 2-3
         //  finished the decided lanes here and the parked ones behind their verdicts: two passes of the same ~2.5 k-cycle
         //  latency chain -- stores, the reset loads of lanes whose episode ends -- in the waves that end the step, and two
@@ -2322,8 +2306,7 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
 #pragma unroll
                 for (int k = 0; k < 7; ++k) q.popped_state[k] = fifo_stash[(3 + k) * kLocalEnvs];
             }
-            finalize_env_from<PLAIN>(a, SL, i, q, hit_now, lds_path, nullptr, !ABLATED(a, kAblateNoReward), sc, my_len, fits, out_base,
-                                     have_init, init_ahead);
+            finalize_env_from<PLAIN>(a, SL, i, q, hit_now, lds_path, nullptr, !ABLATED(a, kAblateNoReward), sc, my_len, fits, out_base);
         }
     }
     DIAG_STAMP(13);            // mover: out of tickets

@@ -1,7 +1,11 @@
 """Workload for the PMC passes: steady-state pre-roll, then 40 fused steps, then a calibration copy of known size.
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 tools/pmc_run.py   (and a second pass with WRITE_SIZE)"""
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
+if os.environ.get("BCP_LIB"):   # (another build of the library: A/B of counters)
+    from _variant import use_lib
+    use_lib(os.environ["BCP_LIB"])
 import bench
 n = 65536
 env, g = bench.make_env(n, 0, 0, 2024)
