@@ -330,6 +330,12 @@ typedef uint64_t __attribute__((aligned(1))) SampleU64Unaligned;
 // counts / first_world (optional): see "ring mode" below
 // WIDE as in coop_collides: one copy of the rasteriser per kernel
 constexpr int kSampleLdsWords = 2 * kMtWords + 2;   // the bitmap follows the window (on an even word)
+// ... and behind the bitmap (rounded up to an even word): the footprint vertices / resolution as doubles [2 * BCP_MAX_VERTS] and the
+// cell list of the sparse exact test [kSparseLdsWords] (coop_collides_sparse: what the step kernels settle their parked poses with)
+__host__ __device__ __forceinline__ size_t sample_lds_words(int rows, int wpr)
+{
+    return (size_t)((kSampleLdsWords + rows * wpr + 1) & ~1) + 4 * BCP_MAX_VERTS + kSparseLdsWords;
+}
 
 template <bool WIDE>
 __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, MiniWorldParams mp, uint32_t* __restrict__ mt_state,
@@ -347,6 +353,14 @@ __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, Mini
     if (counts && counts[chain] <= 0) return;   // ring mode: nothing to top up behind this chain's env
     MtStream mt{(MtLds)sample_lds, 0};
     const MtLds bits = mt.buf + kSampleLdsWords;
+    __attribute__((address_space(3))) double* const qv_w =
+        (__attribute__((address_space(3))) double*)(mt.buf + ((kSampleLdsWords + rows * wpr + 1) & ~1));
+    const LdsF64 qv = qv_w;
+    const LdsU32 cell_list = (LdsU32)(qv_w + 2 * BCP_MAX_VERTS);
+    if (lane < P.n_verts) {
+        qv_w[2 * lane] = P.qverts[lane][0];
+        qv_w[2 * lane + 1] = P.qverts[lane][1];
+    }
     uint32_t* record = mt_state + chain * kMtRecord;   // numpy's: 624 key words + position (624 = "regenerate first")
     for (int k = lane; k < kMtWords; k += 64) mt.buf[k] = record[k];
     if (lane == 0) mt.set_pos(min(record[kMtWords], (uint32_t)kMtWords));
@@ -383,7 +397,13 @@ __global__ void __launch_bounds__(64) mini_world_sample_kernel(DevParams P, Mini
                 const double x = end ? W.end[0] : W.start[0], y = end ? W.end[1] : W.start[1];
                 const double th = end ? W.end[2] : W.start[2];
                 const int px = (int)rint((x - ox) * inv_res), py = (int)rint((y - oy) * inv_res);
-                const bool hit = coop_collides<WIDE>(P, vqx, vqy, cos(th), sin(th), px, py, (LdsWords)bits, rows, cols, wpr);
+                // (the walls are one cell thick: the lethal cells under the footprint's image, tested one by one --
+                //  coop_collides_sparse, the same verdict pixel for pixel -- instead of the image rasterised row by row; a
+                //  map too dense for the list falls back to the rasteriser)
+                const double c = cos(th), s = sin(th);
+                const int verdict = coop_collides_sparse<WIDE>(P, qv, c, s, px, py, (LdsWords)bits, rows, cols, wpr, cell_list);
+                bool hit = verdict == kSparseHit;
+                if (verdict == kSparseTooMany) hit = coop_collides<WIDE>(P, vqx, vqy, c, s, px, py, (LdsWords)bits, rows, cols, wpr);
                 collides = collides || hit;
             }
             // beginning and goal must not be immediately too close (:345-351)

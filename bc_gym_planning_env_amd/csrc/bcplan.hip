@@ -2723,7 +2723,7 @@ static int sample_mini_worlds(bcp_handle* h, const bcp_mini_world_params* p, uin
     if ((int)(0.05 / p->resolution) > 1)   // Wall.render: thickness = max(1, int(width / resolution))
         return fail(BCP_E_INVALID, "bcp_sample_mini_worlds: walls thicker than one pixel are not supported");
     const int wpr = (cols + 31) / 32;
-    const size_t lds = ((size_t)kSampleLdsWords + (size_t)rows * wpr) * sizeof(uint32_t);
+    const size_t lds = sample_lds_words(rows, wpr) * sizeof(uint32_t);
     if (rows <= 0 || cols <= 0 || lds > 60 * 1024) return fail(BCP_E_INVALID, "bcp_sample_mini_worlds: unsupported map shape");
     HIP_TRY(hipSetDevice(h->device));
     DevParams P = h->dev;
