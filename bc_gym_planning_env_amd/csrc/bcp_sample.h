@@ -515,9 +515,10 @@ __device__ __forceinline__ void mini_world_path(const double* __restrict__ world
         for (int j = 0; j < m; ++j) {
             const double xj = p[3 * j], yj = p[3 * j + 1], tj = p[3 * j + 2];
             const bool near = hypot(xj - x0, yj - y0) < sp;
+            if (!near) continue;   // (three independent predicates: the other two cost a cos, a sin and an fmod per way point)
             const bool aligned = fabs(normalize_angle(th0 - tj)) < ap;
             const bool ahead = cos(tj) * (x0 - xj) + sin(tj) * (y0 - yj) >= -sp / 9;
-            if (near && aligned && ahead) last = j;
+            if (aligned && ahead) last = j;
         }
         if (last == m - 1) rc = 2;
         target = min(last + 1, m - 1);
