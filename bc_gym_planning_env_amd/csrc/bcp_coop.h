@@ -565,6 +565,45 @@ __device__ __forceinline__ int row_max(int v)
     return max(v, dpp_ror<0x121>(v));
 }
 
+// minimum and maximum of TWO 16-bit values at once over the 16 lanes of a DPP row (v_pk_min_i16 / v_pk_max_i16): the extents of the
+// footprint's image, u in the low half, v in the high half (|u|, |v| < 2^15: the image is a few hundred pixels across at most)
+typedef short CoopS16x2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ CoopS16x2 dpp_ror_pk(CoopS16x2 x)
+{
+    return __builtin_bit_cast(CoopS16x2, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ CoopS16x2 row_min_pk(CoopS16x2 x)
+{
+    x = __builtin_elementwise_min(x, dpp_ror_pk<0x128>(x));
+    x = __builtin_elementwise_min(x, dpp_ror_pk<0x124>(x));
+    x = __builtin_elementwise_min(x, dpp_ror_pk<0x122>(x));
+    return __builtin_elementwise_min(x, dpp_ror_pk<0x121>(x));
+}
+
+__device__ __forceinline__ CoopS16x2 row_max_pk(CoopS16x2 x)
+{
+    x = __builtin_elementwise_max(x, dpp_ror_pk<0x128>(x));
+    x = __builtin_elementwise_max(x, dpp_ror_pk<0x124>(x));
+    x = __builtin_elementwise_max(x, dpp_ror_pk<0x122>(x));
+    return __builtin_elementwise_max(x, dpp_ror_pk<0x121>(x));
+}
+
+// 1 / d for an integer 0 < |d| < 2^15, good to the last bits of a double: the float32 reciprocal (1 ulp) and two Newton steps.
+// What the two exact integer divisions of an edge's set-up are made of below: a quotient n / d with |n / d| < 2^32 then comes
+// out within 2^-19 of the true value, a non-integral true value is at least 1 / |d| > 2^-15 away from the next integer, and an
+// integral one is restored by the small push before the truncation -- the same integers as the / of the rasteriser
+// (tests/test_host_logic.py checks the identities over every divisor and dividend the set-up can meet).
+__device__ __forceinline__ double coop_exact_rcp(int d)
+{
+    const double dd = (double)d;
+    double r = (double)__builtin_amdgcn_rcpf((float)d);
+    r = fma(fma(-dd, r, 1.0), r, r);
+    return fma(fma(-dd, r, 1.0), r, r);
+}
+
 template <bool WIDE, bool TILED = false, typename WordPtr>
 __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 qverts, double c, double s, int px, int py,
                                                     WordPtr words, int rows, int cols, int wpr, LdsU32 list,
@@ -581,17 +620,18 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 q
     const double qx = qverts[2 * ve], qy = qverts[2 * ve + 1], pqx = qverts[2 * vp_i], pqy = qverts[2 * vp_i + 1];
     const int u = (int)rint(fma(qy, -s, qx * c)), v = (int)rint(fma(qy, c, qx * s));       // path_tools.py:142-150
     const int up = (int)rint(fma(pqy, -s, pqx * c)), vp = (int)rint(fma(pqy, c, pqx * s));
-    int vmin = row_min(v), vmax = row_max(v), umin = row_min(u), umax = row_max(u);
+    // (u and v as one packed pair: two reductions instead of four)
+    CoopS16x2 uv;
+    uv.x = (short)u;
+    uv.y = (short)v;
+    CoopS16x2 lo2 = row_min_pk(uv), hi2 = row_max_pk(uv);
     if (G == 32) {   // the group spans two DPP rows
-        vmin = min(vmin, __shfl_xor(vmin, 16));
-        vmax = max(vmax, __shfl_xor(vmax, 16));
-        umin = min(umin, __shfl_xor(umin, 16));
-        umax = max(umax, __shfl_xor(umax, 16));
+        lo2 = __builtin_elementwise_min(lo2, __builtin_bit_cast(CoopS16x2, __shfl_xor(__builtin_bit_cast(int, lo2), 16)));
+        hi2 = __builtin_elementwise_max(hi2, __builtin_bit_cast(CoopS16x2, __shfl_xor(__builtin_bit_cast(int, hi2), 16)));
     }
-    vmin = bcast_i(vmin, 0);   // (the same in every group; scalar from here on)
-    vmax = bcast_i(vmax, 0);
-    umin = bcast_i(umin, 0);
-    umax = bcast_i(umax, 0);
+    lo2 = __builtin_bit_cast(CoopS16x2, bcast_i(__builtin_bit_cast(int, lo2), 0));   // (the same in every group; scalar from here on)
+    hi2 = __builtin_bit_cast(CoopS16x2, bcast_i(__builtin_bit_cast(int, hi2), 0));
+    const int umin = (int)lo2.x, vmin = (int)lo2.y, umax = (int)hi2.x, vmax = (int)hi2.y;
     // the lethal words of the image's first 64 rows are asked for right away: with the map in global memory (private maps)
     // their round trip -- 1.6 k cycles of a 3.9 k-cycle test on C4 -- then runs under the edge parameters below
     CoopCollisionSink<NW, WordPtr, TILED> sink{words, rows, cols, wpr, px, py, 0, 0};
@@ -603,7 +643,12 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 q
     const int ddy = v - vp;
     const int y0 = min(v, vp), y1 = owner ? max(v, vp) : y0;
     const int x0fp = (vp < v ? up : u) << 16;
-    const int dxfp = ddy != 0 ? ((u - up) * 65536) / ddy : 0;
+    // ((u - up) * 65536) / ddy, truncated towards zero like the integer division it stands for (coop_exact_rcp)
+    int dxfp = 0;
+    if (ddy != 0) {
+        const double q0 = (double)((u - up) * 65536) * coop_exact_rcp(ddy);
+        dxfp = (int)(q0 + copysign(0x1p-12, q0));
+    }
     // Bresenham (LineIterator, leftToRight): from the end with the smaller x
     int sx = up, sy = vp, dx = u - up, dy = v - vp;
     if (dx < 0) {
@@ -614,7 +659,8 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 q
     }
     const bool down = dy < 0;   // ystep = -1
     if (down) dy = -dy;
-    const uint32_t inv = (uint32_t)(4294967296.0 / (double)(2u * (uint32_t)(dy > 0 ? dy : 1))) + 1u;   // see coop_raster
+    // floor(2^32 / (2 dy)) + 1 (see coop_raster), without the float64 division
+    const uint32_t inv = (uint32_t)(4294967296.0 * coop_exact_rcp(2 * (dy > 0 ? dy : 1)) + 0x1p-17) + 1u;
     if (!owner) dy = -1;        // inert: no run on any row
     // ---- the lethal cells under the image's columns, all row chunks into one list (lane = row of the chunk; the order
     //      of the cells does not matter, so a lane just reserves room for its row's cells with one LDS atomic)

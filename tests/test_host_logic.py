@@ -210,3 +210,34 @@ def test_c_client_compiles_against_the_header(tmp_path):
            "-lamdhip64", "-lm", "-o", str(tmp_path / "step_from_c")]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+
+
+def test_exact_division_identities_of_the_sparse_exact_test():
+    """coop_collides_sparse (csrc/bcp_coop.h) replaces the two exact integer divisions of an edge's set-up --
+    ((u - up) * 65536) / ddy, truncated, and floor(2^32 / (2 dy)) + 1 -- by a float32 reciprocal, two Newton steps in float64,
+    a product and a small push before the truncation (coop_exact_rcp).  The identities, for every divisor and dividend a
+    footprint image of up to 512 pixels can produce and a hardware reciprocal that is off by up to two units in the last place."""
+    def newton(d, r0):
+        d, r = d.astype(np.longdouble), r0.astype(np.longdouble)
+        for _ in range(2):   # fma(fma(-d, r, 1), r, r): one rounding per fma
+            e = (1.0 - d * r).astype(np.float64).astype(np.longdouble)
+            r = (r + e * r).astype(np.float64).astype(np.longdouble)
+        return r.astype(np.float64)
+
+    def rcp32(d, ulps):
+        r = (np.float32(1.0) / d.astype(np.float32))
+        for _ in range(abs(ulps)):
+            r = np.nextafter(r, np.float32(np.inf if ulps > 0 else -np.inf))
+        return r.astype(np.float64)
+
+    d = np.arange(1, 513, dtype=np.float64)
+    k = np.arange(-512, 513, dtype=np.int64)
+    N, D = np.meshgrid(k * 65536, np.arange(1, 513, dtype=np.int64))
+    for ulps in (-2, -1, 0, 1, 2):
+        inv = np.floor(4294967296.0 * newton(2 * d, rcp32(2 * d, ulps)) + 2.0 ** -17).astype(np.uint64) + 1
+        assert (inv == np.uint64(4294967296) // (2 * d).astype(np.uint64) + 1).all()
+        r = newton(d, rcp32(d, ulps))[:, None]
+        for sign in (1, -1):   # (a negative divisor: the reciprocal and its Newton steps are odd in d)
+            q0 = N.astype(np.float64) * (sign * r)
+            q = np.trunc(q0 + np.copysign(2.0 ** -12, q0)).astype(np.int64)
+            assert (q == (np.abs(N) // D) * np.sign(N) * sign).all()
