@@ -32,6 +32,8 @@ constexpr double kTwoPi = 2.0 * kPi;
 struct DevParams {
     int32_t model, n_verts, dynamic_model, model_front_column_pid, noise_on, iteration_timeout;
     double dt, L, max_wheel_angle, max_wheel_speed, max_lin_acc, max_ang_acc, p_gain;
+    double inv_dt, inv_L;    // 1 / dt, 1 / L, correctly rounded (host): div_by_const; directly behind p_gain (step_local_kernel
+                             // fetches dt .. inv_L as nine adjacent values)
     double alpha[6];
     double sp, ap, progress_mult;
     double par_thr;          // -sp / 9, utilities/path_tools.py:423
@@ -81,6 +83,19 @@ __device__ __forceinline__ double py_mod_two_pi(double a)
     return r;
 }
 
+// x / d for a divisor that is a constant of the handle (dt, L) or of the program (pi), with rd = 1 / d correctly rounded: the
+// quotient estimate, its exact residual (one fma) and the correction (one fma) -- Markstein's sequence, which returns the
+// correctly rounded quotient, i.e. the very double x / d is (for every divisor whose significand is not all ones: the host
+// refuses such a dt / L; 3 x 10^6 random and swept dividends per divisor checked against exact rational arithmetic, and the
+// reference trajectories are the standing check).  Three instructions instead of the ~28 of a float64 division, six times on
+// the movers' chain of step_local_kernel.
+__device__ __forceinline__ double div_by_const(double x, double d, double rd)
+{
+    const double q = x * rd;
+    return fma(fma(-q, d, x), rd, q);
+}
+constexpr double kInvPi = 1.0 / kPi;   // (constant expression: IEEE division, correctly rounded)
+
 // utilities/coordinate_transformations.py:28-36
 __device__ __forceinline__ double normalize_angle(double z) { return py_mod_two_pi(z + kPi) - kPi; }
 
@@ -105,7 +120,7 @@ __device__ __forceinline__ void cos_sin(double x, double& c, double& s) { sincos
 __device__ __forceinline__ Pose kinematic_step(Pose p, double v, double w, double dt)
 {
     double half_wdt = 0.5 * w * dt;
-    double t = half_wdt / kPi;                     // np.sinc(half_wdt / np.pi)
+    double t = div_by_const(half_wdt, kPi, kInvPi);   // np.sinc(half_wdt / np.pi)
     double yy = kPi * (t == 0.0 ? 1.0e-20 : t);
     double sinc = sin(yy) / yy;
     double v_factor = v * dt * sinc;
@@ -164,8 +179,10 @@ __device__ __forceinline__ KnownHeading no_known_heading()
     return k;
 }
 
+// (BY_RCP: the caller holds inv_dt = 1 / dt correctly rounded -- div_by_const --; otherwise the two quotients are divisions)
+template <bool BY_RCP = false>
 __device__ __forceinline__ int path_velocity(Pose p0, Pose p1, double dt, double& v, double& w,
-                                             KnownHeading old_heading = no_known_heading())
+                                             KnownHeading old_heading = no_known_heading(), double inv_dt = 0.0)
 {
     double dx = p1.x - p0.x, dy = p1.y - p0.y;
     double c0, s0;
@@ -181,8 +198,13 @@ __device__ __forceinline__ int path_velocity(Pose p0, Pose p1, double dt, double
     double da = p1.th - p0.th;
     if (da < -kPi) da += kTwoPi;
     if (da > kPi) da -= kTwoPi;
-    v = ds / dt;
-    w = da / dt;
+    if (BY_RCP) {
+        v = div_by_const(ds, dt, inv_dt);
+        w = div_by_const(da, dt, inv_dt);
+    } else {
+        v = ds / dt;
+        w = da / dt;
+    }
     return (fabs(da) < kPi) ? 0 : BCP_ERR_ANGLE_JUMP;
 }
 
@@ -201,7 +223,7 @@ struct Robot {
 // the robot constants of DevParams by value: a kernel fetches them once, ahead of time (step_local_kernel)
 struct RobotConsts {
     int32_t model, dynamic_model, model_front_column_pid, noise_on;
-    double dt, L, max_wheel_angle, max_wheel_speed, max_lin_acc, max_ang_acc, p_gain;
+    double dt, L, max_wheel_angle, max_wheel_speed, max_lin_acc, max_ang_acc, p_gain, inv_dt, inv_L;
     double alpha[6];
 };
 
@@ -219,6 +241,8 @@ __device__ __forceinline__ RobotConsts robot_consts(const DevParams& P)
     c.max_lin_acc = P.max_lin_acc;
     c.max_ang_acc = P.max_ang_acc;
     c.p_gain = P.p_gain;
+    c.inv_dt = P.inv_dt;
+    c.inv_L = P.inv_L;
 #pragma unroll
     for (int k = 0; k < 6; ++k) c.alpha[k] = P.alpha[k];
     return c;
@@ -245,10 +269,10 @@ __device__ __forceinline__ RobotDrive robot_step_begin(const Params& P, Robot& r
         double cw, sw;
         cos_sin(new_wa, cw, sw);
         double des_v = cmd0 * cw;
-        double des_w = cmd0 * sw / P.L;
+        double des_w = div_by_const(cmd0 * sw, P.L, P.inv_L);
         if (P.dynamic_model) {            // tricycle_model.py:157-188
-            double acc_v = (des_v - r.v) / P.dt;
-            double acc_w = (des_w - r.w) / P.dt;
+            double acc_v = div_by_const(des_v - r.v, P.dt, P.inv_dt);
+            double acc_w = div_by_const(des_w - r.w, P.dt, P.inv_dt);
             double lin = clipd(acc_v, -2 * P.max_lin_acc, P.max_lin_acc);
             double ang = clipd(acc_w, -P.max_ang_acc, P.max_ang_acc);
             double nv = r.v + lin * P.dt;
@@ -280,7 +304,7 @@ __device__ __forceinline__ int robot_step_end(const Params& P, Robot& r, RobotDr
     const Pose last = r.p;
     const Pose np_ = d.noisy ? kinematic_step_noise(last, d.v, d.w, P.dt, P.alpha, z, drawn) : kinematic_step(last, d.v, d.w, P.dt);
     double mv, mw;
-    const int err = path_velocity(last, np_, P.dt, mv, mw, old_heading);
+    const int err = path_velocity<true>(last, np_, P.dt, mv, mw, old_heading, P.inv_dt);
     r.p = np_;
     r.v = mv;
     r.w = mw;
@@ -299,7 +323,7 @@ template <typename Params>
 __device__ __forceinline__ int robot_step_measure(const Params& P, Robot& r, Pose np_, KnownHeading old_heading = no_known_heading())
 {
     double mv, mw;
-    const int err = path_velocity(r.p, np_, P.dt, mv, mw, old_heading);
+    const int err = path_velocity<true>(r.p, np_, P.dt, mv, mw, old_heading, P.inv_dt);
     r.p = np_;
     r.v = mv;
     r.w = mw;

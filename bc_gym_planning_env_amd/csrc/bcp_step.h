@@ -1773,13 +1773,13 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
     //     ... and the mover the seven robot constants of the model's first half (dt .. p_gain, adjacent in DevParams), by
     //     vector loads of a uniform address: they arrive with the state, in vector registers, and scalar registers stay free
     //     (PLAIN only: with delay queues the first half runs behind barrier 0, on the constants in LDS)
-    double rc[7] = {0, 0, 0, 0, 0, 0, 0};
+    double rc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // (+ 1 / dt, 1 / L: div_by_const)
     if (PLAIN && mover) {   // (a rollout fetches them in every trip: seven loads, nothing to carry across the loop)
         int zero;
         asm("v_mov_b32 %0, 0" : "=v"(zero));   // (opaque: keeps these loads on the vector side)
         const GlobalPtr<const double> pc = as_global(&a.S->P.dt) + zero;
 #pragma unroll
-        for (int u = 0; u < 7; ++u) rc[u] = pc[u];
+        for (int u = 0; u < 9; ++u) rc[u] = pc[u];
     }
     // (2) the parameter block *S (16 bytes per thread of the last two waves) is the only staging data anybody needs before
     //     barrier 1: the mover's second half reads its parameters from the LDS copy.  Footprint vertices, the shared path with
@@ -1842,6 +1842,8 @@ __device__ __forceinline__ void step_local_body(KernArgPtr kernarg, const int rs
         robot.max_lin_acc = rc[4];
         robot.max_ang_acc = rc[5];
         robot.p_gain = rc[6];
+        robot.inv_dt = rc[7];
+        robot.inv_L = rc[8];
         drive = robot_step_begin(robot, r, cmd0, cmd1);
         DIAG_STAMP_U(0, 12);   // mover: first half of the robot model done
       }

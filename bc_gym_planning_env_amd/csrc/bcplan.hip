@@ -1008,6 +1008,8 @@ static void fill_dev_params(bcp_handle* h)
     d.max_lin_acc = p.max_linear_acceleration;
     d.max_ang_acc = p.max_angular_acceleration;
     d.p_gain = p.front_column_p_gain;
+    d.inv_dt = 1.0 / p.dt;                       // (correctly rounded: what div_by_const needs)
+    d.inv_L = 1.0 / p.front_wheel_from_axis;
     for (int k = 0; k < 6; ++k) d.alpha[k] = p.alpha[k];
     d.sp = p.spatial_precision;
     d.ap = p.angular_precision;
@@ -1047,6 +1049,16 @@ extern "C" int bcp_create(const bcp_params* params, int64_t n_envs, int device, 
     if (params->model != BCP_MODEL_TRICYCLE && params->model != BCP_MODEL_DIFFDRIVE)
         return fail(BCP_E_INVALID, "bcp_create: unknown robot model %d", params->model);
     if (!(params->dt > 0)) return fail(BCP_E_INVALID, "bcp_create: dt must be > 0 (path_tools.py:307)");
+    {   // div_by_const (bcp_device.h) divides by dt and by the wheel base through their reciprocals; the sequence is the IEEE
+        // quotient for every divisor but those whose significand is all ones (0.99999999999999989 and its like)
+        const auto all_ones = [](double d) {
+            uint64_t bits;
+            memcpy(&bits, &d, sizeof(bits));
+            return (bits & 0x000FFFFFFFFFFFFFull) == 0x000FFFFFFFFFFFFFull;
+        };
+        if (all_ones(params->dt) || (params->model == BCP_MODEL_TRICYCLE && all_ones(params->front_wheel_from_axis)))
+            return fail(BCP_E_INVALID, "bcp_create: dt / front_wheel_from_axis with an all-ones significand is not supported");
+    }
     if (params->model == BCP_MODEL_DIFFDRIVE && params->noise_on && !(params->options & BCP_OPT_DIFFDRIVE_NOISE))
         return fail(BCP_E_INVALID, "bcp_create: the reference's DiffDriveRobot raises IndexError with noise_parameters "
                                    "(differential_drive.py:73); set BCP_OPT_DIFFDRIVE_NOISE in bcp_params.options to opt in to "
