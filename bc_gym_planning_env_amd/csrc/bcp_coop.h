@@ -613,7 +613,8 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 q
     const int K = P.n_verts;
     const int lane = lane_id();
     const int G = K <= 16 ? 16 : 32;            // lanes per cell; lane e of a group owns edge e = (V[e-1] -> V[e])
-    const int e = lane & (G - 1), group = lane / G;
+    const int gshift = K <= 16 ? 4 : 5;         // (G = 1 << gshift: shifts, not the divisions lane / G and 64 / G compile to)
+    const int e = lane & (G - 1), group = lane >> gshift;
     const bool owner = e < K;
     // ---- this lane's edge, from its two vertices (inert lanes take vertex 0 twice: no effect on the extents)
     const int ve = owner ? e : 0, vp_i = owner ? (e == 0 ? K - 1 : e - 1) : 0;
@@ -722,8 +723,8 @@ __device__ __forceinline__ int coop_collides_sparse(const DevParams& P, LdsF64 q
         total = kept;
     }
     // ---- a group of lanes per cell, a lane per edge
-    const int per_pass = 64 / G;
-    const uint64_t group_mask = (G == 16 ? 0xFFFFull : 0xFFFFFFFFull) << (G * group);
+    const int per_pass = 64 >> gshift;
+    const uint64_t group_mask = (G == 16 ? 0xFFFFull : 0xFFFFFFFFull) << (group << gshift);
     for (int base = 0; base < total; base += per_pass) {
         const bool valid = base + group < total;
         const uint32_t cell = valid ? list[base + group] : 0u;
