@@ -8,7 +8,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams  # noqa: E402
+from bc_gym_planning_env_amd import BatchedPlanEnv, CostMap2D, EnvParams, _lib  # noqa: E402
+if os.environ.get("BCP_LIB"):   # A/B of kernel variants: another build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["BCP_LIB"])
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "g8_traj_mini_00.npz"))
